@@ -1,0 +1,170 @@
+"""Generate tests/golden/* by running the REFERENCE itself (imported from /root/reference in
+the build container through oracle/_ref_shims.py).  The reference cannot travel to the GPU
+box, so its outputs are committed as small fixtures together with this script.
+
+    python -m oracle.make_goldens            # all fixtures (a few minutes of CPU)
+
+Fixtures are data only: seeds, boxes, and reference outputs (sub-sampled where large).
+Inputs are regenerated from seeds (det_sam2_amd.synth / det_sam2_amd.weights), never stored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from det_sam2_amd.config import resolve_config  # noqa: E402
+from det_sam2_amd.synth import SyntheticDetector, synthetic_frame  # noqa: E402
+from det_sam2_amd.weights import synthetic_state_dict  # noqa: E402
+from oracle import _ref_shims as RS  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def l1_inputs(seed=1234):
+    """Seeded module-level inputs shared by the golden generator and the tests."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    B, Nk = 2, 4096 * 2 + 8
+    return dict(
+        img=r(1, 3, 1024, 1024), curr=r(4096, B, 256), curr_pos=r(4096, B, 256), mem=r(Nk, B, 64),
+        mem_pos=r(Nk, B, 64), pix=r(B, 256, 64, 64), masks=r(B, 1, 1024, 1024),
+        coords=torch.rand(B, 2, 2, generator=g) * 1024, labels=torch.tensor([[2, 3]] * B, dtype=torch.int32),
+        mask_prompt=r(B, 1, 256, 256), emb=r(B, 256, 64, 64), hr0=r(B, 32, 256, 256), hr1=r(B, 64, 128, 128),
+    )
+
+
+def schema():
+    for name in ("sam2.1_hiera_t", "sam2.1_hiera_s", "sam2.1_hiera_b+", "sam2.1_hiera_l"):
+        m = RS.instantiate_from_yaml(f"configs/sam2.1/{name}.yaml")
+        sd = {k: list(v.shape) for k, v in m.state_dict().items()}
+        with open(os.path.join(GOLD, f"schema_{name}.json"), "w") as f:
+            json.dump(sd, f, indent=0)
+        print("schema", name, len(sd))
+
+
+def l1(name="sam2.1_hiera_t"):
+    cfg = resolve_config(name)
+    sd = synthetic_state_dict(cfg, 0)
+    ref = RS.instantiate_from_yaml(f"configs/sam2.1/{name}.yaml", sd)
+    x = l1_inputs()
+    out = {}
+    with torch.inference_mode():
+        bo = ref.forward_image(x["img"])
+        for i, f in enumerate(bo["backbone_fpn"]):
+            out[f"fpn{i}"] = f[0, ::4, ::8, ::8].numpy()
+        out["pos2"] = bo["vision_pos_enc"][2][0, ::8, ::8, ::8].numpy()
+        ma = ref.memory_attention(curr=[x["curr"]], curr_pos=[x["curr_pos"]], memory=x["mem"],
+                                  memory_pos=x["mem_pos"], num_obj_ptr_tokens=8)
+        out["memattn"] = ma[::32, :, ::4].numpy()
+        me = ref.memory_encoder(x["pix"], x["masks"], skip_mask_sigmoid=True)
+        out["memenc"] = me["vision_features"][:, ::2, ::4, ::4].numpy()
+        out["memenc_pos"] = me["vision_pos_enc"][0][0, :, ::8, ::8].numpy()
+        s, d = ref.sam_prompt_encoder(points=(x["coords"], x["labels"]), boxes=None, masks=x["mask_prompt"])
+        out["sparse"] = s.numpy()
+        out["dense"] = d[:, ::8, ::4, ::4].numpy()
+        pe = ref.sam_prompt_encoder.get_dense_pe()
+        out["dense_pe"] = pe[0, ::8, ::4, ::4].numpy()
+        s, d = ref.sam_prompt_encoder(points=(x["coords"], x["labels"]), boxes=None, masks=None)
+        for mm in (True, False):
+            r = ref.sam_mask_decoder(image_embeddings=x["emb"], image_pe=pe, sparse_prompt_embeddings=s,
+                                     dense_prompt_embeddings=d, multimask_output=mm, repeat_image=False,
+                                     high_res_features=[x["hr0"], x["hr1"]])
+            out[f"dec{int(mm)}_masks"] = r[0][:, :, ::4, ::4].numpy()
+            out[f"dec{int(mm)}_iou"] = r[1].numpy()
+            out[f"dec{int(mm)}_tok"] = r[2].numpy()
+            out[f"dec{int(mm)}_obj"] = r[3].numpy()
+        fs = ref._forward_sam_heads(backbone_features=x["emb"], point_inputs=None, mask_inputs=None,
+                                    high_res_features=[x["hr0"], x["hr1"]], multimask_output=True)
+        out["heads_low"] = fs[3][:, :, ::4, ::4].numpy()
+        out["heads_high"] = fs[4][:, :, ::16, ::16].numpy()
+        out["heads_ptr"] = fs[5].numpy()
+        out["heads_obj"] = fs[6].numpy()
+    np.savez_compressed(os.path.join(GOLD, f"l1_{name}.npz"), **out)
+    print("l1", name, {k: v.shape for k, v in out.items()})
+
+
+def _run_reference_stream(name, n_frames, detector, **vp_kwargs):
+    """Drive the reference VideoProcessor.process_frame (det_sam2_RT.py:421) over synthetic frames,
+    capturing every propagate_in_video yield."""
+    cfg = resolve_config(name)
+    sd = synthetic_state_dict(cfg, 0)
+    vp = RS.make_reference_video_processor(f"configs/sam2.1/{name}.yaml", sd, **vp_kwargs)
+    script = []
+    for t in range(n_frames):
+        if vp.detect_interval != -1 and t % vp.detect_interval == 0:
+            script.append([(d["coordinates"], d["class"][0], d["confidence"][0]) for d in detector(t)])
+    RS.ScriptedDetector.script, RS.ScriptedDetector.cursor = script, 0
+    yields, passes = [], []
+    orig = vp.predictor.propagate_in_video
+
+    def capturing(state, **kw):
+        ys = []
+        for t, ids, logits in orig(state, **kw):
+            od = state["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            low = od[key][t]["pred_masks"].clone()
+            yields.append((len(passes), t, list(ids), low.numpy(), (logits > 0).numpy()))
+            ys.append(t)
+            yield t, ids, logits
+        passes.append((kw["start_frame_idx"], ys))
+
+    vp.predictor.propagate_in_video = capturing
+    t0 = time.time()
+    for t in range(n_frames):
+        vp.process_frame(t, synthetic_frame(t))
+    if vp.frame_buffer:
+        vp.Detect_and_SAM2_inference(frame_idx=n_frames - 1)
+    dt = time.time() - t0
+    od = vp.inference_state["output_dict"]
+    final_keys = (sorted(od["cond_frame_outputs"]), sorted(od["non_cond_frame_outputs"]))
+    return vp, yields, passes, final_keys, dt
+
+
+def e2e_cfg1(name="sam2.1_hiera_t"):
+    """BASELINE config 1: tiny, 8 frames, 1 bbox on frame 0."""
+    det = SyntheticDetector(1)
+    kw = dict(skip_classes=set(), frame_buffer_size=8, detect_interval=8, max_frame_num_to_track=8,
+              max_inference_state_frames=-1)
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 8, det, **kw)
+    out = {"seconds": np.float64(dt), "frames": np.array([y[1] for y in yields]),
+           "low": np.stack([y[3] for y in yields]),                      # [8,1,1,256,256] fp32 logits
+           "bits": np.stack([np.packbits(y[4]) for y in yields])}       # video-res (1024^2) masks, packed
+    np.savez_compressed(os.path.join(GOLD, "e2e_cfg1.npz"), **out)
+    print("e2e_cfg1", dt, "s", out["frames"], passes, final_keys)
+
+
+def e2e_stream2(name="sam2.1_hiera_t"):
+    """Two-pass stream exercising second-visit tracking, release_old_frames and the online
+    new-object path (A17): 8 frames, buffer 4, detect every 4, track 8, keep 6; objects 0,1 from
+    frame 0 and object 2 first detected on frame 4."""
+    det = SyntheticDetector(3, appear={2: 4})
+    kw = dict(skip_classes=set(), frame_buffer_size=4, detect_interval=4, max_frame_num_to_track=8,
+              max_inference_state_frames=6)
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 8, det, **kw)
+    out = {"seconds": np.float64(dt), "pass_id": np.array([y[0] for y in yields]),
+           "frames": np.array([y[1] for y in yields]), "nobj": np.array([len(y[2]) for y in yields]),
+           "final_cond": np.array(final_keys[0]), "final_noncond": np.array(final_keys[1]),
+           "images_idx": np.array(vp.inference_state["images_idx"])}
+    for i, y in enumerate(yields):
+        out[f"low{i}"] = y[3].astype(np.float16)                              # [B,1,256,256] logits (fp16)
+        out[f"lowbits{i}"] = np.packbits(y[3] > 0)                            # exact sign of low-res logits
+        out[f"bits{i}"] = np.packbits(y[4][:, :, ::2, ::2])                   # video-res masks, 2x decimated
+    np.savez_compressed(os.path.join(GOLD, "e2e_stream2.npz"), **out)
+    print("e2e_stream2", dt, "s", passes, final_keys, vp.inference_state["images_idx"])
+
+
+if __name__ == "__main__":
+    assert RS.reference_available(), "needs /root/reference (build container only)"
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["schema", "l1", "e2e_cfg1", "e2e_stream2"]
+    torch.set_num_threads(8)
+    for w in which:
+        globals()[w]()

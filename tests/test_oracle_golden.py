@@ -1,0 +1,101 @@
+"""Oracle (CPU restatement) vs the committed golden vectors produced by the reference itself
+(oracle/make_goldens.py).  Runs anywhere, no GPU, no /root/reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from det_sam2_amd.config import CONFIGS, resolve_config
+from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
+from det_sam2_amd.weights import param_shapes, synthetic_state_dict
+from oracle import modeling as M
+from oracle.make_goldens import l1_inputs
+from oracle.predictor import OraclePredictor
+from oracle.video_processor import OracleVideoProcessor
+
+TINY = "sam2.1_hiera_t"
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = resolve_config(TINY)
+    return cfg, synthetic_state_dict(cfg, 0)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_checkpoint_schema_matches_reference(name, golden_dir):
+    with open(os.path.join(golden_dir, f"schema_{name}.json")) as f:
+        ref = json.load(f)
+    ours = param_shapes(name)
+    assert list(ours.keys()) != [] and set(ours) == set(ref)
+    for k, s in ours.items():
+        assert list(s) == ref[k], k
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    err = float(np.abs(a - b).max())
+    assert err <= tol, err
+
+
+def test_l1_modules_match_reference_golden(tiny, golden_dir):
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, f"l1_{TINY}.npz"))
+    x = l1_inputs()
+    with torch.inference_mode():
+        fpn, pos = M.forward_image(sd, cfg, x["img"])
+        for i, f in enumerate(fpn):
+            _close(f[0, ::4, ::8, ::8], g[f"fpn{i}"], 1e-4)
+        _close(pos[2][0, ::8, ::8, ::8], g["pos2"], 1e-6)
+        ma = M.memory_attention(sd, cfg, x["curr"], x["curr_pos"], x["mem"], x["mem_pos"], 8)
+        _close(ma[::32, :, ::4], g["memattn"], 2e-5)
+        f, p = M.memory_encoder(sd, cfg, x["pix"], x["masks"])
+        _close(f[:, ::2, ::4, ::4], g["memenc"], 2e-5)
+        _close(p[0, :, ::8, ::8], g["memenc_pos"], 1e-6)
+        s, d = M.prompt_encoder(sd, cfg, x["coords"], x["labels"], x["mask_prompt"])
+        _close(s, g["sparse"], 1e-5)
+        _close(d[:, ::8, ::4, ::4], g["dense"], 1e-5)
+        pe = M.dense_pe(sd, cfg)
+        _close(pe[0, ::8, ::4, ::4], g["dense_pe"], 1e-6)
+        s, d = M.prompt_encoder(sd, cfg, x["coords"], x["labels"])
+        for mm in (True, False):
+            r = M.mask_decoder(sd, cfg, x["emb"], pe, s, d, mm, [x["hr0"], x["hr1"]])
+            _close(r[0][:, :, ::4, ::4], g[f"dec{int(mm)}_masks"], 5e-5)
+            _close(r[1], g[f"dec{int(mm)}_iou"], 1e-5)
+            _close(r[2], g[f"dec{int(mm)}_tok"], 2e-5)
+            _close(r[3], g[f"dec{int(mm)}_obj"], 1e-5)
+        fs = OraclePredictor(sd, cfg).forward_sam_heads(x["emb"], None, None, [x["hr0"], x["hr1"]], True)
+        _close(fs[3][:, :, ::4, ::4], g["heads_low"], 5e-5)
+        _close(fs[4][:, :, ::16, ::16], g["heads_high"], 5e-5)
+        _close(fs[5], g["heads_ptr"], 2e-5)
+        _close(fs[6], g["heads_obj"], 1e-5)
+
+
+def _iou(a, b):
+    """sav_dataset/utils/sav_benchmark.py:215-222 semantics (both empty -> 1)."""
+    inter = np.logical_and(a, b).sum()
+    union = np.logical_or(a, b).sum()
+    return 1.0 if union == 0 else inter / union
+
+
+def test_e2e_config1_matches_reference_golden(tiny, golden_dir):
+    """BASELINE config 1 (tiny, 8 frames, 1 box on frame 0) through the oracle VideoProcessor."""
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_cfg1.npz"))
+    vp = OracleVideoProcessor(sd, cfg, SyntheticDetector(1), skip_classes=set(), frame_buffer_size=8,
+                              detect_interval=8, max_frame_num_to_track=8, max_inference_state_frames=-1)
+    with torch.inference_mode():
+        for t in range(8):
+            vp.process_frame(t, synthetic_frame(t))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].numpy()
+        assert np.abs(low - g["low"][i]).max() <= 2e-4
+        ref_mask = np.unpackbits(g["bits"][i]).reshape(1, 1, 1024, 1024).astype(bool)
+        ours = vp.video_segments[int(t)][0]
+        assert 1.0 - _iou(ours, ref_mask[0]) <= 1e-3
