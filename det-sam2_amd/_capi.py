@@ -1,0 +1,82 @@
+"""ctypes binding of libdetsam2_hip.so (C-ABI: include/detsam2_hip.h).
+
+There is NO CPU fallback: if the library is missing, or a call fails, this raises.  Build it with
+``python -c 'import __graft_entry__ as g; g.build()'`` (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdetsam2_hip.so")
+
+c_f32p = C.c_void_p
+c_vp = C.c_void_p
+i32 = C.c_int32
+
+
+class Ds2Config(C.Structure):
+    _fields_ = [
+        ("image_size", i32), ("embed_dim", i32), ("num_heads", i32), ("stages", i32 * 4),
+        ("global_att_blocks", i32 * 4), ("n_global_att_blocks", i32), ("window_spec", i32 * 4),
+        ("d_model", i32), ("mem_dim", i32), ("num_maskmem", i32), ("mem_attn_layers", i32),
+        ("mem_attn_ffn", i32), ("max_batch", i32),
+        ("sigmoid_scale_for_mem_enc", C.c_float), ("sigmoid_bias_for_mem_enc", C.c_float),
+        ("dynamic_multimask_stability_delta", C.c_float), ("dynamic_multimask_stability_thresh", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/detsam2_hip.h declares
+SIGNATURES = {
+    "ds2_last_error": (C.c_char_p, []),
+    "ds2_abi_version": (C.c_int, []),
+    "ds2_model_create": (C.c_int, [C.POINTER(Ds2Config), C.POINTER(c_vp)]),
+    "ds2_model_destroy": (None, [c_vp]),
+    "ds2_model_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, C.c_int64]),
+    "ds2_model_finalize": (C.c_int, [c_vp, c_vp]),
+    "ds2_ingest_frames": (C.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
+    "ds2_image_encoder": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_bank_assemble": (C.c_int, [c_vp, i32, i32, C.POINTER(c_vp), C.POINTER(i32), i32, C.POINTER(c_vp),
+                                    C.POINTER(C.c_float), c_vp, c_vp, c_vp]),
+    "ds2_memory_attention": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp]),
+    "ds2_sam_heads": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_memory_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
+    "ds2_mask_output": (C.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
+    "ds2_op_gemm": (C.c_int, [i32, i32, i32, c_vp, i32, c_vp, i32, c_vp, c_vp, i32, i32, c_vp, c_vp, i32, i32, c_vp]),
+    "ds2_op_layernorm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, C.c_float, i32, c_vp]),
+    "ds2_op_attention": (C.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float,
+                                   i32, i32, i32, i32, i32, i32, i32, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class Ds2Error(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once) and attach signatures.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is required (no CPU fallback exists). "
+            "Build it with: python -c 'import __graft_entry__ as g; g.build()'")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ds2_abi_version() != 1:
+        raise ImportError("libdetsam2_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ds2_last_error()
+        raise Ds2Error(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

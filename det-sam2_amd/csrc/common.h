@@ -1,0 +1,83 @@
+// Common declarations for the det-sam2 gfx950 kernels (internal; the public C-ABI is
+// include/detsam2_hip.h).  Everything here targets CDNA4 / wave64 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define DS2_OK 0
+#define DS2_ERR_ARG 1
+#define DS2_ERR_HIP 2
+#define DS2_ERR_STATE 3
+#define DS2_ERR_UNSUPPORTED 4
+
+void ds2_set_error(const char* fmt, ...);
+
+#define DS2_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ds2_set_error("%s:%d HIP error %s in %s", __FILE__, __LINE__, hipGetErrorString(_e), #expr); \
+      return DS2_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+#define DS2_CHECK_LAUNCH() DS2_CHECK_HIP(hipGetLastError())
+
+#define DS2_REQUIRE(cond, ...)                     \
+  do {                                             \
+    if (!(cond)) {                                 \
+      ds2_set_error(__VA_ARGS__);                  \
+      return DS2_ERR_ARG;                          \
+    }                                              \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane in half h
+// (lane>>5): row = (r&3) + 8*(r>>2) + 4*h; the column is lane&31.
+__device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- epilogue / activation codes shared by GEMM and LayerNorm
+enum { DS2_ACT_NONE = 0, DS2_ACT_RELU = 1, DS2_ACT_GELU = 2, DS2_ACT_SIGMOID = 3 };
+
+__device__ __forceinline__ float ds2_act(float x, int act) {
+  if (act == DS2_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == DS2_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+  if (act == DS2_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
+  return x;
+}
+
+// ---- primitive launchers (implemented in the .hip files; all asynchronous on `st`)
+struct GemmArgs {
+  int M, N, K;            // C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) * gamma[N] + R[M,N]
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;      // may be null
+  float* C; int ldc;
+  int act;
+  const float* gamma;     // may be null (per-column scale applied after act)
+  const float* R; int ldr; // may be null; residual added last
+  int r_mod;              // if >0 the residual row is (m % r_mod) (broadcast over a leading batch)
+};
+int launch_gemm(const GemmArgs& g, hipStream_t st);
+
+int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
+                     float eps, int act, hipStream_t st);
+
+struct AttnArgs {
+  const float *q, *k, *v; float* o;
+  int ldq, ldk, ldv, ldo;       // row strides in floats
+  int batch, heads, D, DV;      // q/k head dim D, v head dim DV; head h lives at column h*D (h*DV for v,o)
+  int Lq, Lk;                   // tokens per batch item (for windowed mode: window area)
+  float scale;                  // softmax scale (1/sqrt(D))
+  // windowed mode (Hiera): batch item = window (wy*nwx + wx) of one image stored in natural (y,x) row order
+  int win_q, win_k;             // 0 = plain [batch, L] rows
+  int Hq, Wq, Hk, Wk, nwx;
+  const float *k_pad, *v_pad;   // row used for padded key positions (the qkv bias), may be null
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);

@@ -1,0 +1,61 @@
+// Launchers of the HBM-bound / glue kernels (kernels.hip).  All asynchronous on `st`.
+// Activations are fp32, token-major ("NHWC"): [rows, C] with C contiguous.
+#pragma once
+#include "common.h"
+
+int launch_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, float* out, int ldo,
+                     int rows, int C, hipStream_t st);  // out[r,c] = a[r,c] + alpha*b[r % b_mod, c]  (b_mod<=0: r)
+int launch_add_rowvec(const float* a, int lda, const float* vec, float* out, int ldo, int rows, int C, hipStream_t st);
+int launch_maxpool2x2(const float* in, int ld_in, float* out, int ld_out, int H, int W, int C, hipStream_t st);
+int launch_up2_add(const float* lat, const float* coarse, float* out, int H, int W, int C, hipStream_t st);
+int launch_rope(float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens, hipStream_t st);
+int launch_im2col_patch(const uint16_t* frame_f16, float* out, int S, hipStream_t st);  // [3,S,S] fp16 -> [(S/4)^2,148]
+int launch_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* out, int n, int S, hipStream_t st);
+int launch_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                    hipStream_t st);
+int launch_pad_cols(const float* in, int rows, int cols, float* out, int cols_out, hipStream_t st);
+
+// memory encoder
+int launch_mask_upsample_transform(const float* low, float* high, int B, int hin, int hout, int mode, float scale,
+                                   float bias, hipStream_t st);  // mode 0: sigmoid, 1: binarize(>0), 2: identity
+int launch_conv3x3s2_small(const float* in, const float* w, const float* bias, const float* lnw, const float* lnb,
+                           float* out, int B, int Hin, int Cin, int Cout, hipStream_t st);  // + LN2d(1e-6) + GELU
+int launch_im2col3x3s2(const float* in, float* out, int B, int Hin, int Cin, hipStream_t st);
+int launch_dwconv7(const float* in, const float* w49c, const float* bias, float* out, int B, int H, int C, hipStream_t st);
+int launch_memfeat_finish(const float* feat, const float* obj_logits, const float* no_obj_embed, uint16_t* out_bf16,
+                          int B, int tokens, int C, hipStream_t st);
+
+// SAM heads
+int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4, const float* not_a_point,
+                         const float* coords, const int* labels, int B, int P, float image_size, float* tokens,
+                         hipStream_t st);  // tokens [B, 6+P+1, 256]
+int launch_upscale1(const float* g1, const float* feat_s1, const float* lnw, const float* lnb, float* u1, int B,
+                    hipStream_t st);
+int launch_upscale2_masks(const float* g2, const float* feat_s0, const float* hyper, float* masks, int B, hipStream_t st);
+int launch_gather_rows(const float* in, int ld_in, int row_stride, int row_off, float* out, int ld_out, int B, int C,
+                       hipStream_t st);  // out[b,:] = in[(b*row_stride+row_off), :]
+int launch_select_masks(const float* masks4, const float* iou4, const float* obj_logits, const float* tokens_out,
+                        int tok_ld, int multimask, float delta, float thresh, float* low_res, float* sel_token,
+                        float* iou_out, int B, hipStream_t st);
+int launch_ptr_gate(float* ptr, const float* obj_logits, const float* no_obj_ptr, int B, int C, hipStream_t st);
+
+// memory bank
+#define DS2_MAX_MEM_ENTRIES 40
+#define DS2_MAX_PTR_ENTRIES 40
+struct BankArgs {
+  int B, n_mem, n_ptr, tokens;             // tokens = 4096
+  const uint16_t* feats[DS2_MAX_MEM_ENTRIES];  // bf16 [B, tokens, 64]
+  int tpos_row[DS2_MAX_MEM_ENTRIES];           // row of maskmem_tpos_enc to add
+  const float* ptrs[DS2_MAX_PTR_ENTRIES];      // fp32 [B, 256]
+  float ptr_pos[DS2_MAX_PTR_ENTRIES];          // signed temporal distance (already divided by t_diff_max)
+  const float* maskmem_pos;                    // [tokens, 64]
+  const float* tpos_enc;                       // [7, 64]
+  const float* tpos_w; const float* tpos_b;    // obj_ptr_tpos_proj [64,256],[64]
+  float* mem; float* mem_pos;                  // [B, Nk, 64] each, Nk = n_mem*tokens + 4*n_ptr
+};
+int launch_bank_assemble(const BankArgs& a, hipStream_t st);
+int launch_bank_ptr(const BankArgs& a, const float* dim_t /*[128]*/, hipStream_t st);
+
+// outputs
+int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits /*nullable*/,
+                       uint8_t* packed /*nullable*/, hipStream_t st);

@@ -1,0 +1,653 @@
+// HBM-bound and glue kernels of the Det-SAM2 hot path (everything that is not a GEMM or an
+// attention).  fp32 token-major activations; coalescing along the channel dimension; 64-lane wave
+// reductions via __shfl_xor.  Each kernel cites the reference code it reproduces.
+#include "kernels.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {  // torch .to(bfloat16): round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float half_bits_to_f32(uint16_t h) {
+  __half_raw r;
+  r.x = h;
+  return __half2float(__half(r));
+}
+
+// ------------------------------------------------------------------ LayerNorm (rows x C), one wave / row
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                   const float* __restrict__ b, float* __restrict__ y, int ldy,
+                                                   int rows, int C, float eps, int act) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(v) / (float)C + eps);
+  float* yr = y + (size_t)row * ldy;
+  for (int c = lane; c < C; c += 64) yr[c] = ds2_act((xr[c] - mean) * rstd * w[c] + b[c], act);
+}
+
+// ------------------------------------------------------------------ simple elementwise
+__global__ void k_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, float* out,
+                            int ldo, int rows, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int r = (int)(i / C), c = (int)(i - (size_t)r * C);
+  const int rb = b_mod > 0 ? r % b_mod : r;
+  out[(size_t)r * ldo + c] = a[(size_t)r * lda + c] + alpha * b[(size_t)rb * ldb + c];
+}
+
+__global__ void k_add_rowvec(const float* a, int lda, const float* vec, float* out, int ldo, int rows, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int r = (int)(i / C), c = (int)(i - (size_t)r * C);
+  out[(size_t)r * ldo + c] = a[(size_t)r * lda + c] + vec[c];
+}
+
+// 2x2/stride-2 max pooling on a channels-last map (do_pool, hieradet.py:25-36).
+__global__ void k_maxpool2x2(const float* in, int ld_in, float* out, int ld_out, int H, int W, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ho = H / 2, Wo = W / 2;
+  if (i >= (size_t)Ho * Wo * C) return;
+  const int c = (int)(i % C);
+  const int p = (int)(i / C), ox = p % Wo, oy = p / Wo;
+  const float* p00 = in + ((size_t)(2 * oy) * W + 2 * ox) * ld_in + c;
+  const float v = fmaxf(fmaxf(p00[0], p00[ld_in]), fmaxf(p00[(size_t)W * ld_in], p00[(size_t)W * ld_in + ld_in]));
+  out[(size_t)p * ld_out + c] = v;
+}
+
+// FPN top-down: out = lateral + nearest-2x(coarse)   (image_encoder.py:112-125)
+__global__ void k_up2_add(const float* lat, const float* coarse, float* out, int H, int W, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)H * W * C) return;
+  const int c = (int)(i % C);
+  const int p = (int)(i / C), x = p % W, y = p / W;
+  out[i] = lat[i] + coarse[((size_t)(y / 2) * (W / 2) + x / 2) * C + c];
+}
+
+// Axial RoPE applied in place to 256-wide rows (apply_rotary_enc, position_encoding.py:196-220):
+// consecutive pairs are complex numbers multiplied by cis[pos][pair]; pos = token index modulo the
+// 64x64 grid (rope_k_repeat); the last (L - n_rope) rows of every batch item are left untouched
+// (object-pointer tokens, transformer.py:335-341).
+__global__ void k_rope(float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one complex pair per thread
+  if (i >= (size_t)batch * n_rope * 128) return;
+  const int pr = (int)(i % 128);
+  const size_t rt = i / 128;
+  const int t = (int)(rt % n_rope), b = (int)(rt / n_rope);
+  float2* px = reinterpret_cast<float2*>(x + ((size_t)b * L + t) * ldx) + pr;
+  const float2 c = reinterpret_cast<const float2*>(cis)[(size_t)(t % grid_tokens) * 128 + pr];
+  const float2 v = *px;
+  *px = make_float2(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x);
+}
+
+// PatchEmbed 7x7 / stride 4 / pad 3 as im2col (backbones/utils.py:69-96): frame fp16 [3,S,S]
+// (the reference's stored frame, .float()'ed at sam2_video_predictor.py:1186) -> [(S/4)^2, 148] fp32,
+// column = c*49 + ky*7 + kx (the flattened conv weight order), column 147 = 0.
+__global__ void k_im2col_patch(const uint16_t* frame, float* out, int S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = S / 4;
+  if (i >= (size_t)G * G * 148) return;
+  const int col = (int)(i % 148);
+  const int p = (int)(i / 148), ox = p % G, oy = p / G;
+  float v = 0.f;
+  if (col < 147) {
+    const int c = col / 49, r = col % 49, ky = r / 7, kx = r % 7;
+    const int iy = oy * 4 - 3 + ky, ix = ox * 4 - 3 + kx;
+    if (iy >= 0 && iy < S && ix >= 0 && ix < S) v = half_bits_to_f32(frame[((size_t)c * S + iy) * S + ix]);
+  }
+  out[i] = v;
+}
+
+// Frame ingest (load_video_frames, misc.py:328-359) for S x S uint8 RGB input (identity resize):
+// fp16(x/255) then fp16 in-place normalisation is a pure function of (channel, byte) -> 3x256 LUT.
+__global__ void k_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* out, int n, int S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)S * S;
+  if (i >= (size_t)n * per) return;
+  const size_t f = i / per, p = i - f * per;
+  const uint8_t* px = rgb + (f * per + p) * 3;
+  uint16_t* o = out + f * 3 * per + p;
+  o[0] = lut[px[0]];
+  o[per] = lut[256 + px[1]];
+  o[2 * per] = lut[512 + px[2]];
+}
+
+__global__ void k_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)d0 * d1 * d2 * d3;
+  if (i >= n) return;
+  int idx[4];
+  size_t r = i;
+  idx[3] = (int)(r % d3); r /= d3;
+  idx[2] = (int)(r % d2); r /= d2;
+  idx[1] = (int)(r % d1); r /= d1;
+  idx[0] = (int)r;
+  const int d[4] = {d0, d1, d2, d3};
+  const int p[4] = {p0, p1, p2, p3};
+  size_t o = 0;
+  for (int k = 0; k < 4; ++k) o = o * d[p[k]] + idx[p[k]];
+  out[o] = in[i];
+}
+
+__global__ void k_pad_cols(const float* in, int rows, int cols, float* out, int cols_out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * cols_out) return;
+  const int c = (int)(i % cols_out), r = (int)(i / cols_out);
+  out[i] = c < cols ? in[(size_t)r * cols + c] : 0.f;
+}
+
+// ------------------------------------------------------------------ bilinear helpers (align_corners=False)
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_coef(int o, float scale, int in_size) {
+  float src = scale * ((float)o + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lerp l;
+  l.i0 = (int)src;
+  if (l.i0 > in_size - 1) l.i0 = in_size - 1;
+  l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+  l.w1 = src - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+__device__ __forceinline__ float bilerp(const float* img, int w, const Lerp& ly, const Lerp& lx) {
+  const float t0 = lx.w0 * img[(size_t)ly.i0 * w + lx.i0] + lx.w1 * img[(size_t)ly.i0 * w + lx.i1];
+  const float t1 = lx.w0 * img[(size_t)ly.i1 * w + lx.i0] + lx.w1 * img[(size_t)ly.i1 * w + lx.i1];
+  return ly.w0 * t0 + ly.w1 * t1;
+}
+
+// low-res logits -> high-res mask input of the memory encoder:
+// F.interpolate(bilinear) (sam2_base.py:355-360 / sam2_video_predictor.py:747) followed by
+// sigmoid or binarise, *scale + bias (sam2_base.py:713-725).
+__global__ void k_mask_upsample_transform(const float* low, float* high, int B, int hin, int hout, int mode,
+                                          float scale, float bias) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * hout * hout) return;
+  const int x = (int)(i % hout);
+  const int y = (int)((i / hout) % hout);
+  const int b = (int)(i / ((size_t)hout * hout));
+  const float s = (float)hin / (float)hout;
+  const float v = bilerp(low + (size_t)b * hin * hin, hin, lerp_coef(y, s, hin), lerp_coef(x, s, hin));
+  float m;
+  if (mode == 0) m = 1.f / (1.f + expf(-v));
+  else if (mode == 1) m = v > 0.f ? 1.f : 0.f;
+  else { high[i] = v; return; }
+  high[i] = m * scale + bias;
+}
+
+// MaskDownSampler stage with tiny channel counts (memory_encoder.py:36-52): conv3x3/s2/p1 -> LayerNorm2d
+// (eps 1e-6) -> GELU, one thread per output pixel, all COUT channels in registers.  in/out NHWC.
+template <int CIN, int COUT>
+__global__ void k_conv3x3s2_small(const float* in, const float* w, const float* bias, const float* lnw,
+                                  const float* lnb, float* out, int B, int Hin) {
+  __shared__ float ws[COUT * CIN * 9];
+  for (int i = threadIdx.x; i < COUT * CIN * 9; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int Ho = Hin / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Ho * Ho) return;
+  const int ox = (int)(i % Ho), oy = (int)((i / Ho) % Ho), b = (int)(i / ((size_t)Ho * Ho));
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * ox - 1 + kx;
+      if (ix < 0 || ix >= Hin) continue;
+      const float* px = in + (((size_t)b * Hin + iy) * Hin + ix) * CIN;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        const float v = px[c];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] += v * ws[(o * CIN + c) * 9 + ky * 3 + kx];
+      }
+    }
+  }
+  float mean = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) mean += acc[o];
+  mean /= (float)COUT;
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) { const float d = acc[o] - mean; var += d * d; }
+  const float rstd = 1.f / sqrtf(var / (float)COUT + 1e-6f);
+  float* po = out + i * COUT;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) po[o] = ds2_act((acc[o] - mean) * rstd * lnw[o] + lnb[o], DS2_ACT_GELU);
+}
+
+// im2col for conv3x3/s2/p1 on NHWC input; column = (ky*3+kx)*Cin + c (weights are repacked to match).
+__global__ void k_im2col3x3s2(const float* in, float* out, int B, int Hin, int Cin) {
+  const int Ho = Hin / 2, c4n = Cin / 4;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Ho * Ho * 9 * c4n) return;
+  const int c4 = (int)(i % c4n);
+  size_t r = i / c4n;
+  const int tap = (int)(r % 9); r /= 9;
+  const int ox = (int)(r % Ho), oy = (int)((r / Ho) % Ho), b = (int)(r / ((size_t)Ho * Ho));
+  const int iy = 2 * oy - 1 + tap / 3, ix = 2 * ox - 1 + tap % 3;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin)
+    v = *reinterpret_cast<const float4*>(in + (((size_t)b * Hin + iy) * Hin + ix) * Cin + c4 * 4);
+  *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Ho + ox) * 9 * Cin + tap * Cin + c4 * 4) = v;
+}
+
+// CXBlock depth-wise 7x7 / pad 3 (memory_encoder.py:86-92), NHWC, weights repacked [49][C].
+__global__ void k_dwconv7(const float* in, const float* w, const float* bias, float* out, int B, int H, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * H * H * C) return;
+  const int c = (int)(i % C);
+  size_t r = i / C;
+  const int x = (int)(r % H), y = (int)((r / H) % H), b = (int)(r / ((size_t)H * H));
+  float acc = bias[c];
+  for (int ky = 0; ky < 7; ++ky) {
+    const int iy = y + ky - 3;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      const int ix = x + kx - 3;
+      if (ix < 0 || ix >= H) continue;
+      acc += in[(((size_t)b * H + iy) * H + ix) * C + c] * w[(ky * 7 + kx) * C + c];
+    }
+  }
+  out[i] = acc;
+}
+
+// + (1 - is_obj) * no_obj_embed_spatial (sam2_base.py:735-741), then bf16 storage
+// (sam2_video_predictor.py:1337,1396).
+__global__ void k_memfeat_finish(const float* feat, const float* obj_logits, const float* no_obj_embed,
+                                 uint16_t* out, int B, int tokens, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * tokens * C) return;
+  const int c = (int)(i % C), b = (int)(i / ((size_t)tokens * C));
+  float v = feat[i];
+  if (!(obj_logits[b] > 0.f)) v += no_obj_embed[c];
+  out[i] = f32_to_bf16_rne(v);
+}
+
+// ------------------------------------------------------------------ SAM heads
+// tokens[b] = [obj_score_token, iou_token, mask_tokens(4)] ++ sparse point embeddings (P points + the
+// padding point)  (mask_decoder.py:174-195; prompt_encoder.py:73-95; position_encoding.py:129-158).
+__global__ void k_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4,
+                                const float* not_a_point, const float* coords, const int* labels, int B, int P,
+                                float image_size, float* tokens) {
+  const int T = 6 + P + 1;
+  const int bt = blockIdx.x, b = bt / T, t = bt % T, j = threadIdx.x;  // 256 threads = 256 channels
+  float v;
+  if (t < 6) {
+    v = out_tokens6[t * 256 + j];
+  } else {
+    const int p = t - 6;
+    int lab = -1;
+    float cx = 0.f, cy = 0.f;
+    if (p < P) {
+      lab = labels[b * P + p];
+      cx = coords[(b * P + p) * 2 + 0] + 0.5f;
+      cy = coords[(b * P + p) * 2 + 1] + 0.5f;
+    }
+    if (lab == -1) {
+      v = not_a_point[j];
+    } else {
+      const float x = 2.f * (cx / image_size) - 1.f, y = 2.f * (cy / image_size) - 1.f;
+      const int jj = j & 127;
+      const float ang = 6.283185307179586f * (x * gauss[jj] + y * gauss[128 + jj]);
+      v = (j < 128 ? sinf(ang) : cosf(ang));
+      if (lab >= 0 && lab < 4) v += point_emb4[lab * 256 + j];
+    }
+  }
+  tokens[(size_t)bt * 256 + j] = v;
+}
+
+// upscaled = GELU(LayerNorm2d(ConvT1(src) + feat_s1))  (mask_decoder.py:220-223): g1 holds the
+// ConvTranspose2d(2x2,s2) as a GEMM result [B*4096, 4*64] with column (dy*2+dx)*64 + c.
+// One wave per output pixel: the 64 channels are the 64 lanes.
+__global__ __launch_bounds__(256) void k_upscale1(const float* g1, const float* feat_s1, const float* lnw,
+                                                  const float* lnb, float* u1, int B) {
+  const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = threadIdx.x & 63;
+  if (pix >= (size_t)B * 128 * 128) return;
+  const int X = (int)(pix % 128), Y = (int)((pix / 128) % 128), b = (int)(pix / (128 * 128));
+  const int tok = (Y / 2) * 64 + X / 2, sub = (Y & 1) * 2 + (X & 1);
+  const float v = g1[((size_t)b * 4096 + tok) * 256 + sub * 64 + c] + feat_s1[((size_t)Y * 128 + X) * 64 + c];
+  const float mean = wave_sum(v) / 64.f;
+  const float d = v - mean;
+  const float rstd = 1.f / sqrtf(wave_sum(d * d) / 64.f + 1e-6f);
+  u1[pix * 64 + c] = ds2_act(d * rstd * lnw[c] + lnb[c], DS2_ACT_GELU);
+}
+
+// masks[b,m] = hyper_in[b,m,:] . GELU(ConvT2(u1) + feat_s0)   (mask_decoder.py:224,235) without ever
+// materialising the [B,32,256,256] upscaled embedding.  g2: [B*16384, 4*32].
+__global__ __launch_bounds__(256) void k_upscale2_masks(const float* g2, const float* feat_s0, const float* hyper,
+                                                        float* masks, int B) {
+  __shared__ float hs[4 * 32];
+  const size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = (int)(((size_t)blockIdx.x * 256) / 65536);
+  if (threadIdx.x < 128) hs[threadIdx.x] = hyper[b * 128 + threadIdx.x];
+  __syncthreads();
+  if (pix >= (size_t)B * 65536) return;
+  const int X = (int)(pix % 256), Y = (int)((pix / 256) % 256);
+  const int tok = (Y / 2) * 128 + X / 2, sub = (Y & 1) * 2 + (X & 1);
+  const float4* pg = reinterpret_cast<const float4*>(g2 + ((size_t)b * 16384 + tok) * 128 + sub * 32);
+  const float4* pf = reinterpret_cast<const float4*>(feat_s0 + ((size_t)Y * 256 + X) * 32);
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 g = pg[q], f = pf[q];
+    const float u[4] = {ds2_act(g.x + f.x, DS2_ACT_GELU), ds2_act(g.y + f.y, DS2_ACT_GELU),
+                        ds2_act(g.z + f.z, DS2_ACT_GELU), ds2_act(g.w + f.w, DS2_ACT_GELU)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = q * 4 + k;
+      m0 += hs[c] * u[k]; m1 += hs[32 + c] * u[k]; m2 += hs[64 + c] * u[k]; m3 += hs[96 + c] * u[k];
+    }
+  }
+  const size_t o = (size_t)b * 4 * 65536 + (size_t)Y * 256 + X;
+  masks[o] = m0; masks[o + 65536] = m1; masks[o + 2 * 65536] = m2; masks[o + 3 * 65536] = m3;
+}
+
+__global__ void k_gather_rows(const float* in, int ld_in, int row_stride, int row_off, float* out, int ld_out, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  out[(size_t)b * ld_out + c] = in[((size_t)b * row_stride + row_off) * ld_in + c];
+}
+
+// Mask selection glue of MaskDecoder.forward + _forward_sam_heads (mask_decoder.py:140-155,246-296;
+// sam2_base.py:343-370): multimask -> best of masks 1..3 by predicted IoU; otherwise mask 0 unless its
+// stability score < thresh, then the best multimask.  Objectness gate -> NO_OBJ_SCORE.  One block / object.
+__global__ __launch_bounds__(1024) void k_select_masks(const float* masks4, const float* iou4, const float* obj_logits,
+                                                       const float* tokens_out, int tok_ld, int multimask, float delta,
+                                                       float thresh, float* low_res, float* sel_token, float* iou_out) {
+  __shared__ unsigned int cnt[2];
+  __shared__ int s_idx;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* mb = masks4 + (size_t)b * 4 * 65536;
+  if (tid < 2) cnt[tid] = 0;
+  __syncthreads();
+  if (!multimask) {
+    unsigned int ci = 0, cu = 0;
+    for (int i = tid; i < 65536; i += 1024) {
+      const float v = mb[i];
+      ci += v > delta;
+      cu += v > -delta;
+    }
+    atomicAdd(&cnt[0], ci);
+    atomicAdd(&cnt[1], cu);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float* io = iou4 + b * 4;
+    int best = 1;
+    if (io[2] > io[best]) best = 2;
+    if (io[3] > io[best]) best = 3;
+    int idx = best;
+    if (!multimask) {
+      const float ai = (float)cnt[0], au = (float)cnt[1];
+      const float stab = au > 0.f ? ai / au : 1.f;
+      idx = stab >= thresh ? 0 : best;
+    }
+    s_idx = idx;
+    if (iou_out) iou_out[b] = io[idx];
+  }
+  __syncthreads();
+  const int idx = s_idx;
+  const bool appearing = obj_logits[b] > 0.f;
+  const float* src = mb + (size_t)idx * 65536;
+  float* dst = low_res + (size_t)b * 65536;
+  for (int i = tid; i < 65536; i += 1024) dst[i] = appearing ? src[i] : -1024.f;
+  // SAM output token for the object pointer: mask token 0 unless multimask (then the best one).
+  const int tok = 2 + (multimask ? idx : 0);
+  if (tid < 256) sel_token[b * 256 + tid] = tokens_out[(size_t)b * tok_ld + tok * 256 + tid];
+}
+
+// obj_ptr = lam*ptr + (1-lam)*no_obj_ptr  (sam2_base.py:375-387, fixed_no_obj_ptr)
+__global__ void k_ptr_gate(float* ptr, const float* obj_logits, const float* no_obj_ptr, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  const float lam = obj_logits[b] > 0.f ? 1.f : 0.f;
+  ptr[i] = lam * ptr[i] + (1.f - lam) * no_obj_ptr[c];
+}
+
+// ------------------------------------------------------------------ memory bank assembly (sam2_base.py:565-648)
+__global__ void k_bank_mem(BankArgs a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B * n_mem * tokens * 16 (float4 granules)
+  const size_t per_e = (size_t)a.tokens * 16;
+  if (i >= (size_t)a.B * a.n_mem * per_e) return;
+  const int c4 = (int)(i % 16);
+  size_t r = i / 16;
+  const int t = (int)(r % a.tokens); r /= a.tokens;
+  const int e = (int)(r % a.n_mem), b = (int)(r / a.n_mem);
+  const int Nk = a.n_mem * a.tokens + 4 * a.n_ptr;
+  const uint16_t* src = a.feats[e] + ((size_t)b * a.tokens + t) * 64 + c4 * 4;
+  const ushort4 h = *reinterpret_cast<const ushort4*>(src);
+  const float4 m = make_float4(bf16_bits_to_f32(h.x), bf16_bits_to_f32(h.y), bf16_bits_to_f32(h.z), bf16_bits_to_f32(h.w));
+  const float4 pe = *reinterpret_cast<const float4*>(a.maskmem_pos + (size_t)t * 64 + c4 * 4);
+  const float4 tp = *reinterpret_cast<const float4*>(a.tpos_enc + (size_t)a.tpos_row[e] * 64 + c4 * 4);
+  const size_t o = ((size_t)b * Nk + (size_t)e * a.tokens + t) * 64 + c4 * 4;
+  *reinterpret_cast<float4*>(a.mem + o) = m;
+  *reinterpret_cast<float4*>(a.mem_pos + o) = make_float4(pe.x + tp.x, pe.y + tp.y, pe.z + tp.z, pe.w + tp.w);
+}
+
+// pointer tokens: split each 256-d pointer into 4 tokens of 64; pos = obj_ptr_tpos_proj(sine_pe(pos))
+// (get_1d_sine_pe, sam2_utils.py:69-79).  One block (64 threads) per (pointer entry).
+__global__ __launch_bounds__(64) void k_bank_ptr(BankArgs a, const float* dim_t) {
+  __shared__ float pe[256];
+  const int e = blockIdx.x, c = threadIdx.x;
+  const float pos = a.ptr_pos[e];
+  for (int k = c; k < 128; k += 64) {
+    const float v = pos / dim_t[k];
+    pe[k] = sinf(v);
+    pe[128 + k] = cosf(v);
+  }
+  __syncthreads();
+  float tp = 0.f;
+  for (int k = 0; k < 256; ++k) tp += pe[k] * a.tpos_w[c * 256 + k];
+  tp += a.tpos_b[c];
+  const int Nk = a.n_mem * a.tokens + 4 * a.n_ptr;
+  for (int b = 0; b < a.B; ++b)
+    for (int j = 0; j < 4; ++j) {
+      const float m = a.ptrs[e][(size_t)b * 256 + j * 64 + c];
+      const size_t o = ((size_t)b * Nk + (size_t)a.n_mem * a.tokens + e * 4 + j) * 64 + c;
+      a.mem[o] = m;
+      a.mem_pos[o] = tp;
+    }
+}
+
+// ------------------------------------------------------------------ output (A15): bilinear 256^2 -> video
+// resolution (sam2_video_predictor.py:618-642) fused with `> 0` and bit-packing (det_sam2_RT.py:396-399);
+// packing order = numpy.packbits (MSB first).  One thread per 8 output pixels.
+__global__ void k_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits, uint8_t* packed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int wb = Wv / 8;
+  if (i >= (size_t)B * Hv * wb) return;
+  const int xb = (int)(i % wb), y = (int)((i / wb) % Hv), b = (int)(i / ((size_t)wb * Hv));
+  const float sy = (float)hin / (float)Hv, sx = (float)hin / (float)Wv;
+  const Lerp ly = lerp_coef(y, sy, hin);
+  const float* img = low + (size_t)b * hin * hin;
+  unsigned int bits = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int x = xb * 8 + k;
+    const float v = (hin == Hv && hin == Wv) ? img[(size_t)y * hin + x] : bilerp(img, hin, ly, lerp_coef(x, sx, hin));
+    if (logits) logits[((size_t)b * Hv + y) * Wv + x] = v;
+    bits |= (v > 0.f ? 1u : 0u) << (7 - k);
+  }
+  if (packed) packed[i] = (uint8_t)bits;
+}
+
+inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+// ====================================================================== launchers
+int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
+                     float eps, int act, hipStream_t st) {
+  DS2_REQUIRE(rows > 0 && C > 0, "layernorm: bad dims");
+  hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, w, b, y, ldy, rows, C, eps, act);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, float* out, int ldo,
+                     int rows, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_add_bcast, grid1((size_t)rows * C), dim3(256), 0, st, a, lda, b, ldb, b_mod, alpha, out, ldo, rows, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_add_rowvec(const float* a, int lda, const float* vec, float* out, int ldo, int rows, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_add_rowvec, grid1((size_t)rows * C), dim3(256), 0, st, a, lda, vec, out, ldo, rows, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_maxpool2x2(const float* in, int ld_in, float* out, int ld_out, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_maxpool2x2, grid1((size_t)(H / 2) * (W / 2) * C), dim3(256), 0, st, in, ld_in, out, ld_out, H, W, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_up2_add(const float* lat, const float* coarse, float* out, int H, int W, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_up2_add, grid1((size_t)H * W * C), dim3(256), 0, st, lat, coarse, out, H, W, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_rope(float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens, hipStream_t st) {
+  if (n_rope <= 0) return DS2_OK;
+  hipLaunchKernelGGL(k_rope, grid1((size_t)batch * n_rope * 128), dim3(256), 0, st, x, ldx, cis, batch, L, n_rope, grid_tokens);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_im2col_patch(const uint16_t* frame_f16, float* out, int S, hipStream_t st) {
+  hipLaunchKernelGGL(k_im2col_patch, grid1((size_t)(S / 4) * (S / 4) * 148), dim3(256), 0, st, frame_f16, out, S);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* out, int n, int S, hipStream_t st) {
+  hipLaunchKernelGGL(k_ingest_u8, grid1((size_t)n * S * S), dim3(256), 0, st, rgb, lut, out, n, S);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(k_permute4, grid1((size_t)d0 * d1 * d2 * d3), dim3(256), 0, st, in, out, d0, d1, d2, d3, p0, p1, p2, p3);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_pad_cols(const float* in, int rows, int cols, float* out, int cols_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_pad_cols, grid1((size_t)rows * cols_out), dim3(256), 0, st, in, rows, cols, out, cols_out);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_mask_upsample_transform(const float* low, float* high, int B, int hin, int hout, int mode, float scale,
+                                   float bias, hipStream_t st) {
+  hipLaunchKernelGGL(k_mask_upsample_transform, grid1((size_t)B * hout * hout), dim3(256), 0, st, low, high, B, hin, hout,
+                     mode, scale, bias);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_conv3x3s2_small(const float* in, const float* w, const float* bias, const float* lnw, const float* lnb,
+                           float* out, int B, int Hin, int Cin, int Cout, hipStream_t st) {
+  const size_t n = (size_t)B * (Hin / 2) * (Hin / 2);
+  if (Cin == 1 && Cout == 4)
+    hipLaunchKernelGGL((k_conv3x3s2_small<1, 4>), grid1(n), dim3(256), 0, st, in, w, bias, lnw, lnb, out, B, Hin);
+  else if (Cin == 4 && Cout == 16)
+    hipLaunchKernelGGL((k_conv3x3s2_small<4, 16>), grid1(n), dim3(256), 0, st, in, w, bias, lnw, lnb, out, B, Hin);
+  else {
+    ds2_set_error("conv3x3s2_small: unsupported channels %d->%d", Cin, Cout);
+    return DS2_ERR_UNSUPPORTED;
+  }
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_im2col3x3s2(const float* in, float* out, int B, int Hin, int Cin, hipStream_t st) {
+  DS2_REQUIRE(Cin % 4 == 0, "im2col3x3s2: Cin must be a multiple of 4");
+  hipLaunchKernelGGL(k_im2col3x3s2, grid1((size_t)B * (Hin / 2) * (Hin / 2) * 9 * (Cin / 4)), dim3(256), 0, st, in, out, B, Hin, Cin);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_dwconv7(const float* in, const float* w49c, const float* bias, float* out, int B, int H, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_dwconv7, grid1((size_t)B * H * H * C), dim3(256), 0, st, in, w49c, bias, out, B, H, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_memfeat_finish(const float* feat, const float* obj_logits, const float* no_obj_embed, uint16_t* out_bf16,
+                          int B, int tokens, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_memfeat_finish, grid1((size_t)B * tokens * C), dim3(256), 0, st, feat, obj_logits, no_obj_embed,
+                     out_bf16, B, tokens, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4, const float* not_a_point,
+                         const float* coords, const int* labels, int B, int P, float image_size, float* tokens,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_prompt_tokens, dim3(B * (6 + P + 1)), dim3(256), 0, st, out_tokens6, gauss, point_emb4, not_a_point,
+                     coords, labels, B, P, image_size, tokens);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_upscale1(const float* g1, const float* feat_s1, const float* lnw, const float* lnb, float* u1, int B,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(k_upscale1, dim3((unsigned)((size_t)B * 128 * 128 / 4)), dim3(256), 0, st, g1, feat_s1, lnw, lnb, u1, B);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_upscale2_masks(const float* g2, const float* feat_s0, const float* hyper, float* masks, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_upscale2_masks, dim3((unsigned)((size_t)B * 65536 / 256)), dim3(256), 0, st, g2, feat_s0, hyper, masks, B);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_gather_rows(const float* in, int ld_in, int row_stride, int row_off, float* out, int ld_out, int B, int C,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_gather_rows, grid1((size_t)B * C), dim3(256), 0, st, in, ld_in, row_stride, row_off, out, ld_out, B, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_select_masks(const float* masks4, const float* iou4, const float* obj_logits, const float* tokens_out,
+                        int tok_ld, int multimask, float delta, float thresh, float* low_res, float* sel_token,
+                        float* iou_out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_select_masks, dim3(B), dim3(1024), 0, st, masks4, iou4, obj_logits, tokens_out, tok_ld, multimask,
+                     delta, thresh, low_res, sel_token, iou_out);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_ptr_gate(float* ptr, const float* obj_logits, const float* no_obj_ptr, int B, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_ptr_gate, grid1((size_t)B * C), dim3(256), 0, st, ptr, obj_logits, no_obj_ptr, B, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_bank_assemble(const BankArgs& a, hipStream_t st) {
+  DS2_REQUIRE(a.n_mem >= 0 && a.n_mem <= DS2_MAX_MEM_ENTRIES && a.n_ptr >= 0 && a.n_ptr <= DS2_MAX_PTR_ENTRIES,
+              "bank_assemble: too many entries (n_mem=%d n_ptr=%d)", a.n_mem, a.n_ptr);
+  if (a.n_mem > 0) {
+    hipLaunchKernelGGL(k_bank_mem, grid1((size_t)a.B * a.n_mem * a.tokens * 16), dim3(256), 0, st, a);
+    DS2_CHECK_LAUNCH();
+  }
+  return DS2_OK;
+}
+int launch_bank_ptr(const BankArgs& a, const float* dim_t, hipStream_t st) {
+  if (a.n_ptr > 0) {
+    hipLaunchKernelGGL(k_bank_ptr, dim3(a.n_ptr), dim3(64), 0, st, a, dim_t);
+    DS2_CHECK_LAUNCH();
+  }
+  return DS2_OK;
+}
+int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits, uint8_t* packed, hipStream_t st) {
+  DS2_REQUIRE(Wv % 8 == 0, "mask_output: video width must be a multiple of 8 (got %d)", Wv);
+  hipLaunchKernelGGL(k_mask_output, grid1((size_t)B * Hv * (Wv / 8)), dim3(256), 0, st, low, B, hin, Hv, Wv, logits, packed);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}

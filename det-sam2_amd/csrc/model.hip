@@ -1,0 +1,737 @@
+// Stage-level orchestration behind the C-ABI of include/detsam2_hip.h: owns the model parameters,
+// the packed/derived weights and one growable device workspace, and strings the gfx950 kernels
+// (gemm.hip, attention.hip, kernels.hip) into the reference's stages.  Host code only launches
+// kernels on the caller's stream - no host<->device synchronisation on the hot path.
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/detsam2_hip.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+void ds2_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ds2_last_error(void) { return g_err; }
+extern "C" int ds2_abi_version(void) { return DS2_ABI_VERSION; }
+
+#define TRY(x)              \
+  do {                      \
+    int _r = (x);           \
+    if (_r != DS2_OK) return _r; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ model
+namespace {
+
+struct Blob { void* ptr = nullptr; size_t bytes = 0; };
+
+struct BlockCfg { int dim, dim_out, heads, window, q_stride; };
+
+constexpr int TOK = 4096;  // 64x64 tokens at stride 16
+
+}  // namespace
+
+struct ds2_model {
+  ds2_config cfg;
+  std::vector<BlockCfg> blocks;
+  std::vector<int> stage_ends;
+  std::unordered_map<std::string, Blob> params;
+  bool finalized = false;
+  // workspace arena (bump allocator, reset per stage)
+  char* ws = nullptr;
+  size_t ws_cap = 0, ws_top = 0;
+  std::string missing;  // first missing parameter seen by P()
+
+  const float* P(const std::string& name) {
+    auto it = params.find(name);
+    if (it == params.end()) {
+      if (missing.empty()) missing = name;
+      return nullptr;
+    }
+    return reinterpret_cast<const float*>(it->second.ptr);
+  }
+  size_t Pbytes(const std::string& name) {
+    auto it = params.find(name);
+    return it == params.end() ? 0 : it->second.bytes;
+  }
+  float* alloc(size_t n_floats) { return reinterpret_cast<float*>(alloc_bytes(n_floats * sizeof(float))); }
+  void* alloc_bytes(size_t bytes) {
+    const size_t aligned = (bytes + 255) & ~(size_t)255;
+    if (ws_top + aligned > ws_cap) return nullptr;
+    void* p = ws + ws_top;
+    ws_top += aligned;
+    return p;
+  }
+  int require(size_t bytes, hipStream_t st) {   // (re)size the arena; only syncs when it has to grow
+    ws_top = 0;
+    if (bytes <= ws_cap) return DS2_OK;
+    DS2_CHECK_HIP(hipStreamSynchronize(st));
+    if (ws) DS2_CHECK_HIP(hipFree(ws));
+    ws = nullptr;
+    ws_cap = 0;
+    const size_t want = bytes + bytes / 8 + (64u << 20);
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ws), want));
+    ws_cap = want;
+    return DS2_OK;
+  }
+  int add_derived(const std::string& name, size_t n_floats, float** out) {
+    Blob b;
+    b.bytes = n_floats * sizeof(float);
+    DS2_CHECK_HIP(hipMalloc(&b.ptr, b.bytes));
+    params[name] = b;
+    *out = reinterpret_cast<float*>(b.ptr);
+    return DS2_OK;
+  }
+};
+
+#define ALLOC(var, n)                                                        \
+  float* var = m->alloc(n);                                                  \
+  if (!var) {                                                                \
+    ds2_set_error("%s:%d workspace exhausted allocating %zu floats (cap %zu)", __FILE__, __LINE__, (size_t)(n), m->ws_cap); \
+    return DS2_ERR_STATE;                                                    \
+  }
+
+#define CHECK_PARAMS()                                                          \
+  if (!m->missing.empty()) {                                                    \
+    ds2_set_error("missing parameter '%s'", m->missing.c_str());                \
+    m->missing.clear();                                                         \
+    return DS2_ERR_STATE;                                                       \
+  }
+
+static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
+                float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
+                const float* gamma = nullptr) {
+  if (!A || !W || !C) {
+    ds2_set_error("gemm: null operand (missing parameter?)");
+    return DS2_ERR_STATE;
+  }
+  GemmArgs g{M, N, K, A, lda, W, ldw, bias, C, ldc, act, gamma, R, ldr, r_mod};
+  return launch_gemm(g, st);
+}
+// Linear layer by state_dict prefix: y = act(x W^T + b) (+ R)
+static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int N, int K, const float* A, int lda,
+                  float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
+                  const float* gamma = nullptr) {
+  return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma);
+}
+static int layernorm(ds2_model* m, hipStream_t st, const std::string& p, const float* x, float* y, int rows, int C, float eps,
+                     int act = DS2_ACT_NONE) {
+  const float* w = m->P(p + ".weight");
+  const float* b = m->P(p + ".bias");
+  if (!w || !b) { ds2_set_error("missing parameter '%s'", p.c_str()); return DS2_ERR_STATE; }
+  return launch_layernorm(x, C, w, b, y, C, rows, C, eps, act, st);
+}
+
+// ------------------------------------------------------------------------------------------------ lifetime
+extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
+  DS2_REQUIRE(cfg && out, "ds2_model_create: null argument");
+  DS2_REQUIRE(cfg->image_size == 1024 && cfg->d_model == 256 && cfg->mem_dim == 64,
+              "ds2_model_create: only image_size=1024, d_model=256, mem_dim=64 are supported");
+  ds2_model* m = new ds2_model();
+  m->cfg = *cfg;
+  // per-block geometry: Hiera.__init__ loop (hieradet.py:236-267)
+  int depth = 0;
+  for (int s = 0; s < 4; ++s) { depth += cfg->stages[s]; m->stage_ends.push_back(depth - 1); }
+  int dim = cfg->embed_dim, heads = cfg->num_heads, cur_stage = 1;
+  for (int i = 0; i < depth; ++i) {
+    int dim_out = dim, window = cfg->window_spec[cur_stage - 1];
+    for (int g = 0; g < cfg->n_global_att_blocks; ++g)
+      if (cfg->global_att_blocks[g] == i) window = 0;
+    bool after_end = false;
+    for (int s = 0; s < 4; ++s) after_end |= (m->stage_ends[s] == i - 1);
+    if (after_end) { dim_out = dim * 2; heads *= 2; cur_stage += 1; }
+    bool qpool = false;
+    for (int s = 0; s < 3; ++s) qpool |= (m->stage_ends[s] + 1 == i);
+    m->blocks.push_back({dim, dim_out, heads, window, qpool ? 2 : 0});
+    dim = dim_out;
+  }
+  *out = m;
+  return DS2_OK;
+}
+
+extern "C" void ds2_model_destroy(ds2_model* m) {
+  if (!m) return;
+  for (auto& kv : m->params)
+    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  if (m->ws) (void)hipFree(m->ws);
+  delete m;
+}
+
+extern "C" int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_t nbytes) {
+  DS2_REQUIRE(m && name && data && nbytes > 0, "ds2_model_set_param: bad argument");
+  DS2_REQUIRE(!m->finalized, "ds2_model_set_param: model already finalized");
+  Blob b;
+  b.bytes = (size_t)nbytes;
+  DS2_CHECK_HIP(hipMalloc(&b.ptr, b.bytes));
+  DS2_CHECK_HIP(hipMemcpy(b.ptr, data, b.bytes, hipMemcpyDefault));
+  auto it = m->params.find(name);
+  if (it != m->params.end() && it->second.ptr) (void)hipFree(it->second.ptr);
+  m->params[name] = b;
+  return DS2_OK;
+}
+
+static int expect(ds2_model* m, const std::string& name, size_t n_floats) {
+  const size_t got = m->Pbytes(name);
+  if (got == 0) { ds2_set_error("missing parameter '%s'", name.c_str()); return DS2_ERR_STATE; }
+  if (got != n_floats * sizeof(float)) {
+    ds2_set_error("parameter '%s' has %zu bytes, expected %zu", name.c_str(), got, n_floats * sizeof(float));
+    return DS2_ERR_STATE;
+  }
+  return DS2_OK;
+}
+
+extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
+  DS2_REQUIRE(m, "ds2_model_finalize: null model");
+  hipStream_t st = (hipStream_t)stream;
+  const int C0 = m->cfg.embed_dim, D = 256;
+  // ---- strict presence / size check of everything the stages read
+  TRY(expect(m, "#pos_embed", (size_t)65536 * C0));
+  TRY(expect(m, "#rope_cis", (size_t)TOK * 256));
+  TRY(expect(m, "#vision_pos", (size_t)TOK * 256));
+  TRY(expect(m, "#maskmem_pos", (size_t)TOK * 64));
+  TRY(expect(m, "#dense_pe", (size_t)TOK * 256));
+  TRY(expect(m, "#ptr_dim_t", 128));
+  if (m->Pbytes("#ingest_lut") != 768 * sizeof(uint16_t)) { ds2_set_error("missing/bad '#ingest_lut'"); return DS2_ERR_STATE; }
+  TRY(expect(m, "image_encoder.trunk.patch_embed.proj.weight", (size_t)C0 * 147));
+  for (size_t i = 0; i < m->blocks.size(); ++i) {
+    const BlockCfg& b = m->blocks[i];
+    const std::string p = "image_encoder.trunk.blocks." + std::to_string(i);
+    TRY(expect(m, p + ".norm1.weight", b.dim));
+    TRY(expect(m, p + ".attn.qkv.weight", (size_t)3 * b.dim_out * b.dim));
+    TRY(expect(m, p + ".attn.qkv.bias", (size_t)3 * b.dim_out));
+    TRY(expect(m, p + ".attn.proj.weight", (size_t)b.dim_out * b.dim_out));
+    TRY(expect(m, p + ".mlp.layers.0.weight", (size_t)4 * b.dim_out * b.dim_out));
+    TRY(expect(m, p + ".mlp.layers.1.weight", (size_t)4 * b.dim_out * b.dim_out));
+    if (b.dim != b.dim_out) TRY(expect(m, p + ".proj.weight", (size_t)b.dim_out * b.dim));
+  }
+  TRY(expect(m, "maskmem_tpos_enc", (size_t)m->cfg.num_maskmem * 64));
+  TRY(expect(m, "obj_ptr_tpos_proj.weight", 64 * 256));
+  TRY(expect(m, "memory_encoder.out_proj.weight", 64 * 256));
+  TRY(expect(m, "sam_mask_decoder.output_upscaling.0.weight", 256 * 64 * 4));
+  TRY(expect(m, "sam_mask_decoder.output_upscaling.3.weight", 64 * 32 * 4));
+
+  float* w;
+  // patch-embed weight [C,147] -> [C,148] (K padded to a multiple of 4)
+  TRY(m->add_derived("@patch_w", (size_t)C0 * 148, &w));
+  TRY(launch_pad_cols(m->P("image_encoder.trunk.patch_embed.proj.weight"), C0, 147, w, 148, st));
+  // memory-attention self-attention: fused q|k|v projection [768,256]
+  for (int l = 0; l < m->cfg.mem_attn_layers; ++l) {
+    const std::string p = "memory_attention.layers." + std::to_string(l) + ".self_attn.";
+    float *fw, *fb;
+    TRY(m->add_derived("@ma_qkv_w." + std::to_string(l), 768 * 256, &fw));
+    TRY(m->add_derived("@ma_qkv_b." + std::to_string(l), 768, &fb));
+    const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+    for (int j = 0; j < 3; ++j) {
+      TRY(expect(m, p + names[j] + ".weight", 256 * 256));
+      TRY(expect(m, p + names[j] + ".bias", 256));
+      DS2_CHECK_HIP(hipMemcpyAsync(fw + j * 256 * 256, m->P(p + names[j] + ".weight"), 256 * 256 * 4, hipMemcpyDeviceToDevice, st));
+      DS2_CHECK_HIP(hipMemcpyAsync(fb + j * 256, m->P(p + names[j] + ".bias"), 256 * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  // ConvTranspose2d(2x2,s2) as GEMM: weight [Cin,Cout,2,2] -> [(dy,dx,cout), cin]; bias tiled 4x
+  {
+    float *w1, *b1, *w2, *b2;
+    TRY(m->add_derived("@up1_w", 256 * 256, &w1));
+    TRY(m->add_derived("@up1_b", 256, &b1));
+    TRY(launch_permute4(m->P("sam_mask_decoder.output_upscaling.0.weight"), w1, 256, 64, 2, 2, 2, 3, 1, 0, st));
+    TRY(m->add_derived("@up2_w", 128 * 64, &w2));
+    TRY(m->add_derived("@up2_b", 128, &b2));
+    TRY(launch_permute4(m->P("sam_mask_decoder.output_upscaling.3.weight"), w2, 64, 32, 2, 2, 2, 3, 1, 0, st));
+    for (int j = 0; j < 4; ++j) {
+      DS2_CHECK_HIP(hipMemcpyAsync(b1 + j * 64, m->P("sam_mask_decoder.output_upscaling.0.bias"), 64 * 4, hipMemcpyDeviceToDevice, st));
+      DS2_CHECK_HIP(hipMemcpyAsync(b2 + j * 32, m->P("sam_mask_decoder.output_upscaling.3.bias"), 32 * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  // mask-downsampler 3x3 convs as im2col GEMMs: [Cout,Cin,3,3] -> [Cout,(ky,kx,cin)]
+  TRY(m->add_derived("@mds6_w", 64 * 144, &w));
+  TRY(launch_permute4(m->P("memory_encoder.mask_downsampler.encoder.6.weight"), w, 64, 16, 3, 3, 0, 2, 3, 1, st));
+  TRY(m->add_derived("@mds9_w", 256 * 576, &w));
+  TRY(launch_permute4(m->P("memory_encoder.mask_downsampler.encoder.9.weight"), w, 256, 64, 3, 3, 0, 2, 3, 1, st));
+  // CXBlock depth-wise weights [C,1,7,7] -> [49][C]
+  for (int l = 0; l < 2; ++l) {
+    TRY(m->add_derived("@dw_w." + std::to_string(l), 49 * 256, &w));
+    TRY(launch_permute4(m->P("memory_encoder.fuser.layers." + std::to_string(l) + ".dwconv.weight"), w, 256, 1, 7, 7, 2, 3, 0, 1, st));
+  }
+  // decoder output tokens [obj_score, iou, mask0..3] and point-label embeddings [4,256]
+  TRY(m->add_derived("@out_tokens6", 6 * 256, &w));
+  DS2_CHECK_HIP(hipMemcpyAsync(w, m->P("sam_mask_decoder.obj_score_token.weight"), 256 * 4, hipMemcpyDeviceToDevice, st));
+  DS2_CHECK_HIP(hipMemcpyAsync(w + 256, m->P("sam_mask_decoder.iou_token.weight"), 256 * 4, hipMemcpyDeviceToDevice, st));
+  DS2_CHECK_HIP(hipMemcpyAsync(w + 512, m->P("sam_mask_decoder.mask_tokens.weight"), 4 * 256 * 4, hipMemcpyDeviceToDevice, st));
+  TRY(m->add_derived("@point_emb4", 4 * 256, &w));
+  for (int j = 0; j < 4; ++j)
+    DS2_CHECK_HIP(hipMemcpyAsync(w + j * 256, m->P("sam_prompt_encoder.point_embeddings." + std::to_string(j) + ".weight"),
+                                 256 * 4, hipMemcpyDeviceToDevice, st));
+  // dense-prompt vectors: no_mask_embed, and no_mask_embed + no_mem_embed (init-cond frames)
+  TRY(m->add_derived("@dense_vec", 256, &w));
+  DS2_CHECK_HIP(hipMemcpyAsync(w, m->P("sam_prompt_encoder.no_mask_embed.weight"), 256 * 4, hipMemcpyDeviceToDevice, st));
+  CHECK_PARAMS();
+  DS2_CHECK_HIP(hipStreamSynchronize(st));
+  m->finalized = true;
+  (void)D;
+  return DS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A3
+extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t height, int32_t width,
+                                 uint16_t* frames_f16, void* stream) {
+  DS2_REQUIRE(m && m->finalized && rgb_u8 && frames_f16 && n > 0, "ds2_ingest_frames: bad argument");
+  if (height != m->cfg.image_size || width != m->cfg.image_size) {
+    ds2_set_error("ds2_ingest_frames: only %dx%d frames are supported (identity resize; cv2.resize parity is unpinned), got %dx%d",
+                  m->cfg.image_size, m->cfg.image_size, height, width);
+    return DS2_ERR_UNSUPPORTED;
+  }
+  return launch_ingest_u8(rgb_u8, reinterpret_cast<const uint16_t*>(m->P("#ingest_lut")), frames_f16, n, m->cfg.image_size,
+                          (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ A4 + A5
+extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float* fpn0, float* fpn1, float* fpn2, void* stream) {
+  DS2_REQUIRE(m && m->finalized && frame_f16 && fpn0 && fpn1 && fpn2, "ds2_image_encoder: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int C0 = m->cfg.embed_dim;
+  // workspace bound: every block output kept (sum <= depth * 65536*C0 floats is a loose bound) + temporaries
+  size_t need = (size_t)65536 * 148 * 4;
+  {
+    int side = 256;
+    size_t outs = 0, tmp_max = 0;
+    for (const BlockCfg& b : m->blocks) {
+      const size_t hw = (size_t)side * side, hwq = b.q_stride ? hw / 4 : hw;
+      outs += hwq * b.dim_out * 4 + 256;
+      const size_t tmp = (hw * b.dim + hw * b.dim_out * 2 + hw * 3 * b.dim_out + hwq * b.dim_out * 3 + hwq * 4 * b.dim_out) * 4 + 4096;
+      if (tmp > tmp_max) tmp_max = tmp;
+      if (b.q_stride) side /= 2;
+    }
+    need += outs + tmp_max + (size_t)(65536 + 16384 + 4096 * 2 + 1024) * 256 * 4 + (1u << 20);
+  }
+  TRY(m->require(need, st));
+
+  // PatchEmbed (backbones/utils.py:93-96) + pos embed (hieradet.py:273-281), fused as GEMM epilogue
+  ALLOC(col, (size_t)65536 * 148);
+  TRY(launch_im2col_patch(frame_f16, col, 1024, st));
+  ALLOC(x0, (size_t)65536 * C0);
+  TRY(gemm(st, 65536, C0, 148, col, 148, m->P("@patch_w"), 148, m->P("image_encoder.trunk.patch_embed.proj.bias"), x0, C0,
+           DS2_ACT_NONE, m->P("#pos_embed"), C0));
+  const float* x = x0;
+  int side = 256;
+  const float* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_dim[4] = {0, 0, 0, 0}, stage_side[4] = {0, 0, 0, 0};
+  int n_stage = 0;
+  for (size_t i = 0; i < m->blocks.size(); ++i) {
+    const BlockCfg& b = m->blocks[i];
+    const std::string p = "image_encoder.trunk.blocks." + std::to_string(i);
+    const int hw = side * side;
+    const int side_q = b.q_stride ? side / 2 : side, hwq = side_q * side_q;
+    ALLOC(xn, (size_t)hwq * b.dim_out);           // block output survives the temporaries below
+    const size_t mark = m->ws_top;
+    ALLOC(t, (size_t)hw * b.dim);
+    TRY(layernorm(m, st, p + ".norm1", x, t, hw, b.dim, 1e-6f));
+    const float* sc = x;
+    if (b.dim != b.dim_out) {                      // hieradet.py:141-142
+      ALLOC(scf, (size_t)hw * b.dim_out);
+      TRY(linear(m, st, p + ".proj", hw, b.dim_out, b.dim, t, b.dim, scf, b.dim_out));
+      if (b.q_stride) {
+        ALLOC(scp, (size_t)hwq * b.dim_out);
+        TRY(launch_maxpool2x2(scf, b.dim_out, scp, b.dim_out, side, side, b.dim_out, st));
+        sc = scp;
+      } else {
+        sc = scf;
+      }
+    }
+    ALLOC(qkv, (size_t)hw * 3 * b.dim_out);
+    TRY(linear(m, st, p + ".attn.qkv", hw, 3 * b.dim_out, b.dim, t, b.dim, qkv, 3 * b.dim_out));
+    const float* q = qkv;
+    int ldq = 3 * b.dim_out;
+    if (b.q_stride) {                              // q pooling (hieradet.py:65-68); even windows => plain 2x2 pooling
+      ALLOC(qp, (size_t)hwq * b.dim_out);
+      TRY(launch_maxpool2x2(qkv, 3 * b.dim_out, qp, b.dim_out, side, side, b.dim_out, st));
+      q = qp;
+      ldq = b.dim_out;
+    }
+    ALLOC(a, (size_t)hwq * b.dim_out);
+    AttnArgs aa{};
+    aa.q = q; aa.k = qkv + b.dim_out; aa.v = qkv + 2 * b.dim_out; aa.o = a;
+    aa.ldq = ldq; aa.ldk = aa.ldv = 3 * b.dim_out; aa.ldo = b.dim_out;
+    aa.heads = b.heads; aa.D = aa.DV = b.dim_out / b.heads;
+    aa.scale = 1.0f / sqrtf((float)aa.D);
+    if (b.window == 0) {
+      aa.batch = 1; aa.Lq = hwq; aa.Lk = hw; aa.win_q = aa.win_k = 0;
+    } else {
+      const int nw = cdiv(side, b.window);
+      aa.win_k = b.window; aa.win_q = b.q_stride ? b.window / 2 : b.window;
+      aa.batch = nw * nw; aa.nwx = nw;
+      aa.Lq = aa.win_q * aa.win_q; aa.Lk = aa.win_k * aa.win_k;
+      aa.Hq = aa.Wq = side_q; aa.Hk = aa.Wk = side;
+      const float* qb = m->P(p + ".attn.qkv.bias");
+      aa.k_pad = qb ? qb + b.dim_out : nullptr;
+      aa.v_pad = qb ? qb + 2 * b.dim_out : nullptr;
+    }
+    TRY(launch_attention(aa, st));
+    TRY(linear(m, st, p + ".attn.proj", hwq, b.dim_out, b.dim_out, a, b.dim_out, xn, b.dim_out, DS2_ACT_NONE, sc, b.dim_out));
+    ALLOC(t2, (size_t)hwq * b.dim_out);
+    TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f));
+    ALLOC(h, (size_t)hwq * 4 * b.dim_out);
+    TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU));
+    TRY(linear(m, st, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, h, 4 * b.dim_out, xn, b.dim_out, DS2_ACT_NONE, xn, b.dim_out));
+    m->ws_top = mark;
+    x = xn;
+    side = side_q;
+    for (int s = 0; s < 4; ++s)
+      if (m->stage_ends[s] == (int)i) { stage_out[n_stage] = xn; stage_dim[n_stage] = b.dim_out; stage_side[n_stage] = side; ++n_stage; }
+  }
+  DS2_REQUIRE(n_stage == 4, "image encoder: expected 4 stage outputs, got %d", n_stage);
+  // FpnNeck (image_encoder.py:101-134): convs[n-i] on xs[i]; top-down nearest only into level 2; scalp=1
+  ALLOC(lat3, (size_t)1024 * 256);
+  ALLOC(lat2, (size_t)4096 * 256);
+  ALLOC(lat1, (size_t)16384 * 256);
+  ALLOC(lat0, (size_t)65536 * 256);
+  TRY(linear(m, st, "image_encoder.neck.convs.0.conv", 1024, 256, stage_dim[3], stage_out[3], stage_dim[3], lat3, 256));
+  TRY(linear(m, st, "image_encoder.neck.convs.1.conv", 4096, 256, stage_dim[2], stage_out[2], stage_dim[2], lat2, 256));
+  TRY(linear(m, st, "image_encoder.neck.convs.2.conv", 16384, 256, stage_dim[1], stage_out[1], stage_dim[1], lat1, 256));
+  TRY(linear(m, st, "image_encoder.neck.convs.3.conv", 65536, 256, stage_dim[0], stage_out[0], stage_dim[0], lat0, 256));
+  TRY(launch_up2_add(lat2, lat3, fpn2, 64, 64, 256, st));
+  // conv_s0 / conv_s1 (sam2_base.py:455-460)
+  TRY(linear(m, st, "sam_mask_decoder.conv_s1", 16384, 64, 256, lat1, 256, fpn1, 64));
+  TRY(linear(m, st, "sam_mask_decoder.conv_s0", 65536, 32, 256, lat0, 256, fpn0, 32));
+  CHECK_PARAMS();
+  (void)stage_side;
+  return DS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A11
+extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const void* const* feats, const int32_t* tpos_row,
+                                 int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
+                                 float* memory_pos, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && memory && memory_pos, "ds2_bank_assemble: bad argument");
+  DS2_REQUIRE(n_mem >= 0 && n_mem <= DS2_MAX_MEM_ENTRIES && n_ptr >= 0 && n_ptr <= DS2_MAX_PTR_ENTRIES,
+              "ds2_bank_assemble: at most %d memory frames and %d pointers (got %d, %d)", DS2_MAX_MEM_ENTRIES,
+              DS2_MAX_PTR_ENTRIES, n_mem, n_ptr);
+  hipStream_t st = (hipStream_t)stream;
+  BankArgs a{};
+  a.B = B; a.n_mem = n_mem; a.n_ptr = n_ptr; a.tokens = TOK;
+  for (int e = 0; e < n_mem; ++e) {
+    DS2_REQUIRE(tpos_row[e] >= 0 && tpos_row[e] < m->cfg.num_maskmem, "ds2_bank_assemble: bad tpos_row");
+    a.feats[e] = reinterpret_cast<const uint16_t*>(feats[e]);
+    a.tpos_row[e] = tpos_row[e];
+  }
+  for (int i = 0; i < n_ptr; ++i) { a.ptrs[i] = ptrs[i]; a.ptr_pos[i] = ptr_pos[i]; }
+  a.maskmem_pos = m->P("#maskmem_pos");
+  a.tpos_enc = m->P("maskmem_tpos_enc");
+  a.tpos_w = m->P("obj_ptr_tpos_proj.weight");
+  a.tpos_b = m->P("obj_ptr_tpos_proj.bias");
+  a.mem = memory; a.mem_pos = memory_pos;
+  CHECK_PARAMS();
+  TRY(launch_bank_assemble(a, st));
+  TRY(launch_bank_ptr(a, m->P("#ptr_dim_t"), st));
+  return DS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A12
+extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, const float* memory, const float* memory_pos,
+                                    int32_t Nk, int32_t n_ptr_tok, float* out, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && curr && memory && memory_pos && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
+              "ds2_memory_attention: bad argument");
+  DS2_REQUIRE((Nk - n_ptr_tok) % TOK == 0, "ds2_memory_attention: Nk - num_obj_ptr_tokens must be a multiple of 4096");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + (4u << 20);
+  TRY(m->require(need, st));
+  const float* cis = m->P("#rope_cis");
+  ALLOC(x, (size_t)rows * 256);
+  ALLOC(x1, (size_t)TOK * 256);
+  ALLOC(t, (size_t)rows * 256);
+  ALLOC(qkv, (size_t)rows * 768);
+  ALLOC(a, (size_t)rows * 256);
+  ALLOC(q, (size_t)rows * 256);
+  ALLOC(a64, (size_t)rows * 64);
+  ALLOC(kin, (size_t)B * Nk * 64);
+  ALLOC(K, (size_t)B * Nk * 256);
+  ALLOC(h, (size_t)rows * F);
+  // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
+  TRY(launch_add_bcast(curr, 256, m->P("#vision_pos"), 256, 0, 0.1f, x1, 256, TOK, 256, st));
+  // k input of the cross attention: memory + memory_pos (pos_enc_at_cross_attn_keys, memory_attention.py:79)
+  TRY(launch_add_bcast(memory, 64, memory_pos, 64, 0, 1.0f, kin, 64, B * Nk, 64, st));
+  const float sc = 1.0f / 16.0f;  // 1/sqrt(256)
+  for (int l = 0; l < m->cfg.mem_attn_layers; ++l) {
+    const std::string p = "memory_attention.layers." + std::to_string(l);
+    const std::string ls = std::to_string(l);
+    // -- self attention (RoPE on q,k).  Layer 0 sees the same input for all B objects: computed once.
+    const int Bs = (l == 0) ? 1 : B;
+    const float* xin = (l == 0) ? x1 : x;
+    TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f));
+    TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768));
+    TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
+    TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
+    AttnArgs sa{};
+    sa.q = qkv; sa.k = qkv + 256; sa.v = qkv + 512; sa.o = a;
+    sa.ldq = sa.ldk = sa.ldv = 768; sa.ldo = 256;
+    sa.batch = Bs; sa.heads = 1; sa.D = 256; sa.DV = 256; sa.Lq = sa.Lk = TOK; sa.scale = sc;
+    TRY(launch_attention(sa, st));
+    if (l == 0) {
+      TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
+      for (int b = 0; b < B; ++b)
+        DS2_CHECK_HIP(hipMemcpyAsync(x + (size_t)b * TOK * 256, x1, (size_t)TOK * 256 * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+      TRY(linear(m, st, p + ".self_attn.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
+    }
+    // -- cross attention to the memory bank.  V = v_proj(memory) is never materialised:
+    //    softmax(QK^T) (M Wv^T + bv) = (softmax(QK^T) M) Wv^T + bv, so P.V runs in the 64-d memory space.
+    TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f));
+    TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
+    TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
+    TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
+    TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
+    AttnArgs ca{};
+    ca.q = q; ca.k = K; ca.v = memory; ca.o = a64;
+    ca.ldq = 256; ca.ldk = 256; ca.ldv = 64; ca.ldo = 64;
+    ca.batch = B; ca.heads = 1; ca.D = 256; ca.DV = 64; ca.Lq = TOK; ca.Lk = Nk; ca.scale = sc;
+    TRY(launch_attention(ca, st));
+    TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256));
+    TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
+    // -- FFN
+    TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f));
+    TRY(linear(m, st, p + ".linear1", rows, F, 256, t, 256, h, F, DS2_ACT_RELU));
+    TRY(linear(m, st, p + ".linear2", rows, 256, F, h, F, x, 256, DS2_ACT_NONE, x, 256));
+  }
+  TRY(layernorm(m, st, "memory_attention.norm", x, out, rows, 256, 1e-5f));
+  CHECK_PARAMS();
+  return DS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A7 + A8
+namespace {
+// Attention module of the two-way transformer (transformer.py:239-284): projections + SDPA + out_proj.
+// q_in [B*Lq,256], k_in/v_in [B*Lk,256]; result (+ optional residual R) -> out [B*Lq,256].
+int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int Lq, int Lk, int internal,
+                  const float* q_in, const float* k_in, const float* v_in, float* out, const float* R) {
+  const size_t mark = m->ws_top;
+  ALLOC(q, (size_t)B * Lq * internal);
+  ALLOC(k, (size_t)B * Lk * internal);
+  ALLOC(v, (size_t)B * Lk * internal);
+  ALLOC(o, (size_t)B * Lq * internal);
+  TRY(linear(m, st, p + ".q_proj", B * Lq, internal, 256, q_in, 256, q, internal));
+  TRY(linear(m, st, p + ".k_proj", B * Lk, internal, 256, k_in, 256, k, internal));
+  TRY(linear(m, st, p + ".v_proj", B * Lk, internal, 256, v_in, 256, v, internal));
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = o;
+  a.ldq = a.ldk = a.ldv = a.ldo = internal;
+  a.batch = B; a.heads = 8; a.D = a.DV = internal / 8; a.Lq = Lq; a.Lk = Lk;
+  a.scale = 1.0f / sqrtf((float)a.D);
+  TRY(launch_attention(a, st));
+  TRY(linear(m, st, p + ".out_proj", B * Lq, 256, internal, o, internal, out, 256, DS2_ACT_NONE, R, 256));
+  m->ws_top = mark;
+  return DS2_OK;
+}
+int mlp3(ds2_model* m, hipStream_t st, const std::string& p, int M, const float* A, int lda, int hidden, int n_out, float* out,
+         int ldc, int last_act) {
+  const size_t mark = m->ws_top;
+  ALLOC(h1, (size_t)M * hidden);
+  ALLOC(h2, (size_t)M * hidden);
+  TRY(linear(m, st, p + ".layers.0", M, hidden, 256, A, lda, h1, hidden, DS2_ACT_RELU));
+  TRY(linear(m, st, p + ".layers.1", M, hidden, hidden, h1, hidden, h2, hidden, DS2_ACT_RELU));
+  TRY(linear(m, st, p + ".layers.2", M, n_out, hidden, h2, hidden, out, ldc, last_act));
+  m->ws_top = mark;
+  return DS2_OK;
+}
+}  // namespace
+
+extern "C" int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
+                             const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
+                             int32_t P, int32_t multimask, float* low_res, float* obj_ptr, float* obj_logits, float* ious,
+                             void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && pix_feat && fpn0 && fpn1 && low_res && obj_ptr && obj_logits,
+              "ds2_sam_heads: bad argument");
+  DS2_REQUIRE(P >= 0 && P <= 8 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * TOK;
+  const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * 16 * 2048 * 4) * 4 + (8u << 20);
+  TRY(m->require(need, st));
+  const std::string md = "sam_mask_decoder", tr = md + ".transformer";
+  // no prompt => the reference feeds one dummy point labelled -1 (sam2_base.py:298-301)
+  int Pe = P;
+  const float* coords = point_coords;
+  const int* labels = point_labels;
+  if (P == 0) {
+    Pe = 1;
+    float* zc = m->alloc((size_t)B * 2);
+    int* ml = reinterpret_cast<int*>(m->alloc_bytes((size_t)B * 4));
+    if (!zc || !ml) { ds2_set_error("ds2_sam_heads: workspace exhausted"); return DS2_ERR_STATE; }
+    DS2_CHECK_HIP(hipMemsetAsync(zc, 0, (size_t)B * 8, st));
+    DS2_CHECK_HIP(hipMemsetAsync(ml, 0xFF, (size_t)B * 4, st));
+    coords = zc;
+    labels = ml;
+  }
+  const int T = 6 + Pe + 1;
+  ALLOC(tokens, (size_t)B * T * 256);
+  TRY(launch_prompt_tokens(m->P("@out_tokens6"), m->P("sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"),
+                           m->P("@point_emb4"), m->P("sam_prompt_encoder.not_a_point_embed.weight"), coords, labels, B, Pe,
+                           1024.f, tokens, st));
+  // src = image_embeddings + dense_prompt (no_mask_embed broadcast)  (mask_decoder.py:203)
+  ALLOC(keys, (size_t)rows * 256);
+  if (pix_bcast) {
+    const float* src = pix_feat;
+    if (add_no_mem_embed) {   // directly_add_no_mem_embed (sam2_base.py:651-657)
+      ALLOC(pm, (size_t)TOK * 256);
+      TRY(launch_add_rowvec(pix_feat, 256, m->P("no_mem_embed"), pm, 256, TOK, 256, st));
+      src = pm;
+    }
+    for (int b = 0; b < B; ++b)
+      TRY(launch_add_rowvec(src, 256, m->P("@dense_vec"), keys + (size_t)b * TOK * 256, 256, TOK, 256, st));
+  } else {
+    DS2_REQUIRE(!add_no_mem_embed, "ds2_sam_heads: add_no_mem_embed requires pix_bcast");
+    TRY(launch_add_rowvec(pix_feat, 256, m->P("@dense_vec"), keys, 256, rows, 256, st));
+  }
+  ALLOC(queries, (size_t)B * T * 256);
+  ALLOC(qpe, (size_t)B * T * 256);     // queries + query_pe
+  ALLOC(kpe, (size_t)rows * 256);      // keys + key_pe
+  ALLOC(tmpq, (size_t)B * T * 256);
+  ALLOC(tmpk, (size_t)rows * 256);
+  ALLOC(hid, (size_t)B * T * 2048);
+  const float* dense_pe = m->P("#dense_pe");
+  const int BT = B * T;
+  // TwoWayTransformer (transformer.py:91-131) with TwoWayAttentionBlock (:182-215)
+  for (int l = 0; l < 2; ++l) {
+    const std::string p = tr + ".layers." + std::to_string(l);
+    const float* qsrc = (l == 0) ? tokens : queries;
+    if (l == 0) {   // skip_first_layer_pe: queries = self_attn(q=k=v=queries), no residual
+      TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qsrc, qsrc, qsrc, tmpq, nullptr));
+    } else {
+      TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+      TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qpe, qpe, queries, tmpq, queries));
+    }
+    TRY(layernorm(m, st, p + ".norm1", tmpq, queries, BT, 256, 1e-5f));
+    // tokens -> image
+    TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+    TRY(launch_add_bcast(keys, 256, dense_pe, 256, TOK, 1.f, kpe, 256, rows, 256, st));
+    TRY(sam_attention(m, st, p + ".cross_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
+    TRY(layernorm(m, st, p + ".norm2", tmpq, queries, BT, 256, 1e-5f));
+    // MLP
+    TRY(linear(m, st, p + ".mlp.layers.0", BT, 2048, 256, queries, 256, hid, 2048, DS2_ACT_RELU));
+    TRY(linear(m, st, p + ".mlp.layers.1", BT, 256, 2048, hid, 2048, tmpq, 256, DS2_ACT_NONE, queries, 256));
+    TRY(layernorm(m, st, p + ".norm3", tmpq, queries, BT, 256, 1e-5f));
+    // image -> tokens
+    TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+    TRY(sam_attention(m, st, p + ".cross_attn_image_to_token", B, TOK, T, 128, kpe, qpe, queries, tmpk, keys));
+    TRY(layernorm(m, st, p + ".norm4", tmpk, keys, rows, 256, 1e-5f));
+  }
+  TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+  TRY(launch_add_bcast(keys, 256, dense_pe, 256, TOK, 1.f, kpe, 256, rows, 256, st));
+  TRY(sam_attention(m, st, tr + ".final_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
+  float* hs = queries;
+  TRY(layernorm(m, st, tr + ".norm_final_attn", tmpq, hs, BT, 256, 1e-5f));
+  // upscaling + hypernetworks (mask_decoder.py:216-235)
+  float* g1 = tmpk;  // [rows,256]
+  TRY(gemm(st, rows, 256, 256, keys, 256, m->P("@up1_w"), 256, m->P("@up1_b"), g1, 256));
+  ALLOC(u1, (size_t)B * 16384 * 64);
+  TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st));
+  ALLOC(g2, (size_t)B * 16384 * 128);
+  TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128));
+  ALLOC(hyper, (size_t)B * 128);
+  for (int i = 0; i < 4; ++i)
+    TRY(mlp3(m, st, md + ".output_hypernetworks_mlps." + std::to_string(i), B, hs + (2 + i) * 256, T * 256, 256, 32,
+             hyper + i * 32, 128, DS2_ACT_NONE));
+  ALLOC(masks4, (size_t)B * 4 * 65536);
+  TRY(launch_upscale2_masks(g2, fpn0, hyper, masks4, B, st));
+  ALLOC(iou4, (size_t)B * 4);
+  TRY(mlp3(m, st, md + ".iou_prediction_head", B, hs + 256, T * 256, 256, 4, iou4, 4, DS2_ACT_SIGMOID));
+  TRY(mlp3(m, st, md + ".pred_obj_score_head", B, hs, T * 256, 256, 1, obj_logits, 1, DS2_ACT_NONE));
+  ALLOC(sel_tok, (size_t)B * 256);
+  TRY(launch_select_masks(masks4, iou4, obj_logits, hs, T * 256, multimask, m->cfg.dynamic_multimask_stability_delta,
+                          m->cfg.dynamic_multimask_stability_thresh, low_res, sel_tok, ious, B, st));
+  // object pointer (sam2_base.py:373-387)
+  TRY(mlp3(m, st, "obj_ptr_proj", B, sel_tok, 256, 256, 256, obj_ptr, 256, DS2_ACT_NONE));
+  TRY(launch_ptr_gate(obj_ptr, obj_logits, m->P("no_obj_ptr"), B, 256, st));
+  CHECK_PARAMS();
+  return DS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A13
+extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, const float* low_res, const float* obj_logits,
+                                  int32_t binarize, uint16_t* maskmem_bf16, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && fpn2 && low_res && obj_logits && maskmem_bf16, "ds2_memory_encoder: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = B * TOK;
+  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (8u << 20);
+  TRY(m->require(need, st));
+  const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
+  ALLOC(high, (size_t)B * 1048576);
+  TRY(launch_mask_upsample_transform(low_res, high, B, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc,
+                                     m->cfg.sigmoid_bias_for_mem_enc, st));
+  ALLOC(c1, (size_t)B * 262144 * 4);
+  TRY(launch_conv3x3s2_small(high, m->P(ds + "0.weight"), m->P(ds + "0.bias"), m->P(ds + "1.weight"), m->P(ds + "1.bias"), c1,
+                             B, 1024, 1, 4, st));
+  ALLOC(c2, (size_t)B * 65536 * 16);
+  TRY(launch_conv3x3s2_small(c1, m->P(ds + "3.weight"), m->P(ds + "3.bias"), m->P(ds + "4.weight"), m->P(ds + "4.bias"), c2, B,
+                             512, 4, 16, st));
+  ALLOC(col3, (size_t)B * 16384 * 144);
+  TRY(launch_im2col3x3s2(c2, col3, B, 256, 16, st));
+  ALLOC(g3, (size_t)B * 16384 * 64);
+  TRY(gemm(st, B * 16384, 64, 144, col3, 144, m->P("@mds6_w"), 144, m->P(ds + "6.bias"), g3, 64));
+  ALLOC(c3, (size_t)B * 16384 * 64);
+  TRY(layernorm(m, st, ds + "7", g3, c3, B * 16384, 64, 1e-6f, DS2_ACT_GELU));
+  ALLOC(col4, (size_t)rows * 576);
+  TRY(launch_im2col3x3s2(c3, col4, B, 128, 64, st));
+  ALLOC(g4, (size_t)rows * 256);
+  TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256));
+  ALLOC(c4, (size_t)rows * 256);
+  TRY(layernorm(m, st, ds + "10", g4, c4, rows, 256, 1e-6f, DS2_ACT_GELU));
+  // x = pix_feat_proj(pix_feat) + mask_downsampler(masks)   (memory_encoder.py:172-175); pix_feat is shared by all objects
+  ALLOC(pf, (size_t)TOK * 256);
+  TRY(linear(m, st, me + ".pix_feat_proj", TOK, 256, 256, fpn2, 256, pf, 256));
+  ALLOC(x, (size_t)rows * 256);
+  TRY(linear(m, st, ds + "12", rows, 256, 256, c4, 256, x, 256, DS2_ACT_NONE, pf, 256, TOK));
+  // Fuser: 2 x CXBlock (memory_encoder.py:104-117)
+  ALLOC(d, (size_t)rows * 256);
+  ALLOC(t, (size_t)rows * 256);
+  ALLOC(h, (size_t)rows * 1024);
+  for (int l = 0; l < 2; ++l) {
+    const std::string p = me + ".fuser.layers." + std::to_string(l);
+    TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
+    TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f));
+    TRY(linear(m, st, p + ".pwconv1", rows, 1024, 256, t, 256, h, 1024, DS2_ACT_GELU));
+    TRY(linear(m, st, p + ".pwconv2", rows, 256, 1024, h, 1024, x, 256, DS2_ACT_NONE, x, 256, 0, m->P(p + ".gamma")));
+  }
+  ALLOC(o, (size_t)rows * 64);
+  TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, o, 64));
+  TRY(launch_memfeat_finish(o, obj_logits, m->P("no_obj_embed_spatial"), maskmem_bf16, B, TOK, 64, st));
+  CHECK_PARAMS();
+  return DS2_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ A15
+extern "C" int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
+                               uint8_t* packed, void* stream) {
+  DS2_REQUIRE(m && low_res && B > 0 && Hv > 0 && Wv > 0 && (logits || packed), "ds2_mask_output: bad argument");
+  return launch_mask_output(low_res, B, 256, Hv, Wv, logits, packed, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ primitives
+extern "C" int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
+                           const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
+                           int32_t ldr, int32_t r_mod, void* stream) {
+  return gemm((hipStream_t)stream, M, N, K, A, lda, W, ldw, bias, C, ldc, act, R, ldr, r_mod, gamma);
+}
+extern "C" int ds2_op_layernorm(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t C, float eps,
+                                int32_t act, void* stream) {
+  return launch_layernorm(x, C, w, b, y, C, rows, C, eps, act, (hipStream_t)stream);
+}
+extern "C" int ds2_op_attention(const float* q, const float* k, const float* v, float* o, int32_t ldq, int32_t ldk, int32_t ldv,
+                                int32_t ldo, int32_t batch, int32_t heads, int32_t D, int32_t DV, int32_t Lq, int32_t Lk,
+                                float scale, int32_t win_q, int32_t win_k, int32_t Hq, int32_t Wq, int32_t Hk, int32_t Wk,
+                                int32_t nwx, const float* k_pad, const float* v_pad, void* stream) {
+  AttnArgs a{};
+  a.q = q; a.k = k; a.v = v; a.o = o;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+  a.batch = batch; a.heads = heads; a.D = D; a.DV = DV; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+  a.win_q = win_q; a.win_k = win_k; a.Hq = Hq; a.Wq = Wq; a.Hk = Hk; a.Wk = Wk; a.nwx = nwx;
+  a.k_pad = k_pad; a.v_pad = v_pad;
+  return launch_attention(a, (hipStream_t)stream);
+}

@@ -1,0 +1,187 @@
+"""SAM 2.1 stages on MI355X: thin host wrapper over the C-ABI (include/detsam2_hip.h).
+
+PyTorch is used here only as plumbing: device allocations (torch tensors) and the current HIP
+stream.  Every number is produced by the kernels in csrc/; nothing falls back to torch ops.
+
+Token-major layout: what the reference holds as [B,C,H,W] is [B,H*W,C] here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .config import ModelCfg, resolve_config
+from .constants import model_constants
+from .weights import check_state_dict
+
+TOK = 4096
+
+
+def _p(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipOps:
+    """Library handle + stream/allocation plumbing + the primitive ops (no model needed)."""
+
+    def __init__(self, device="cuda:0"):
+        self.lib = _capi.load()                     # raises if the HIP library is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("det-sam2_amd needs a ROCm GPU: there is no CPU execution path")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ primitives (tests)
+    def op_gemm(self, A, W, bias=None, act=0, gamma=None, R=None, r_mod=0):
+        M, K = A.shape
+        N = W.shape[0]
+        out = self._empty(M, N)
+        _capi.check(self.lib.ds2_op_gemm(M, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), N, act, _p(gamma),
+                                         _p(R), 0 if R is None else R.stride(0), r_mod, self._stream()), "ds2_op_gemm")
+        return out
+
+    def op_layernorm(self, x, w, b, eps, act=0):
+        out = torch.empty_like(x)
+        _capi.check(self.lib.ds2_op_layernorm(_p(x), _p(w), _p(b), _p(out), x.shape[0], x.shape[1], eps, act, self._stream()),
+                    "ds2_op_layernorm")
+        return out
+
+    def op_attention(self, q, k, v, heads, scale, win_q=0, win_k=0, hq=0, wq=0, hk=0, wk=0, nwx=0, k_pad=None, v_pad=None,
+                     batch=None, lq=None, lk=None, dv=None):
+        """Plain mode: q [B,Lq,H*D], k [B,Lk,H*D], v [B,Lk,H*DV]. Windowed: q [Hq*Wq,H*D], k/v [Hk*Wk,...]."""
+        D = q.shape[-1] // heads
+        DV = dv if dv is not None else v.shape[-1] // heads
+        if win_k == 0:
+            batch, lq, lk = q.shape[0], q.shape[1], k.shape[1]
+            o = self._empty(batch, lq, heads * DV)
+        else:
+            o = torch.zeros(q.shape[0], heads * DV, device=self.device)
+        _capi.check(self.lib.ds2_op_attention(_p(q), _p(k), _p(v), _p(o), q.stride(-2), k.stride(-2), v.stride(-2), heads * DV,
+                                              batch, heads, D, DV, lq, lk, scale, win_q, win_k, hq, wq, hk, wk, nwx, _p(k_pad),
+                                              _p(v_pad), self._stream()), "ds2_op_attention")
+        return o
+
+
+class HipSam2(HipOps):
+    """Owns one ``ds2_model`` (weights + workspace) on one GPU."""
+
+    def __init__(self, cfg, state_dict, device="cuda:0", max_batch: int = 16):
+        super().__init__(device)
+        self.cfg: ModelCfg = resolve_config(cfg)
+        check_state_dict(self.cfg, state_dict)      # strict, like build_sam.py:166-177
+        t = self.cfg.trunk
+        c = _capi.Ds2Config()
+        c.image_size, c.embed_dim, c.num_heads = self.cfg.image_size, t.embed_dim, t.num_heads
+        for i in range(4):
+            c.stages[i] = t.stages[i]
+            c.window_spec[i] = t.window_spec[i]
+            c.global_att_blocks[i] = t.global_att_blocks[i] if i < len(t.global_att_blocks) else -1
+        c.n_global_att_blocks = len(t.global_att_blocks)
+        c.d_model, c.mem_dim, c.num_maskmem = self.cfg.d_model, self.cfg.mem_dim, self.cfg.num_maskmem
+        c.mem_attn_layers, c.mem_attn_ffn, c.max_batch = self.cfg.mem_attn_layers, self.cfg.mem_attn_ffn, max_batch
+        c.sigmoid_scale_for_mem_enc, c.sigmoid_bias_for_mem_enc = (self.cfg.sigmoid_scale_for_mem_enc,
+                                                                   self.cfg.sigmoid_bias_for_mem_enc)
+        c.dynamic_multimask_stability_delta = self.cfg.dynamic_multimask_stability_delta
+        c.dynamic_multimask_stability_thresh = self.cfg.dynamic_multimask_stability_thresh
+        h = C.c_void_p()
+        _capi.check(self.lib.ds2_model_create(C.byref(c), C.byref(h)), "ds2_model_create")
+        self.h = h
+        sd_np = {}
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            sd_np[k] = np.ascontiguousarray(a, dtype=np.float32)
+        consts = model_constants(self.cfg, sd_np)
+        for k, a in list(sd_np.items()) + list(consts.items()):
+            a = np.ascontiguousarray(a)
+            _capi.check(self.lib.ds2_model_set_param(self.h, k.encode(), a.ctypes.data_as(C.c_void_p), a.nbytes),
+                        f"set_param({k})")
+        _capi.check(self.lib.ds2_model_finalize(self.h, self._stream()), "ds2_model_finalize")
+        self.no_obj_ptr = torch.from_numpy(sd_np["no_obj_ptr"]).to(self.device)           # [1,256]
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ds2_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ stages
+    def ingest(self, frames_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [n,S,S,3] (device) -> fp16 [n,3,S,S] normalised frames (A3)."""
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
+        n, hh, ww, _ = frames_u8.shape
+        out = self._empty(n, 3, self.cfg.image_size, self.cfg.image_size, dtype=torch.float16)
+        _capi.check(self.lib.ds2_ingest_frames(self.h, _p(frames_u8), n, hh, ww, _p(out), self._stream()), "ds2_ingest_frames")
+        return out
+
+    def image_encoder(self, frame_f16: torch.Tensor):
+        """fp16 [3,S,S] -> (fpn0 [65536,32], fpn1 [16384,64], fpn2 [4096,256]) (A4+A5)."""
+        assert frame_f16.dtype == torch.float16 and frame_f16.is_cuda and frame_f16.is_contiguous()
+        f0, f1, f2 = self._empty(65536, 32), self._empty(16384, 64), self._empty(TOK, 256)
+        _capi.check(self.lib.ds2_image_encoder(self.h, _p(frame_f16), _p(f0), _p(f1), _p(f2), self._stream()), "ds2_image_encoder")
+        return f0, f1, f2
+
+    def bank_assemble(self, B, mem_entries, ptr_entries):
+        """mem_entries: [(bf16 [B,4096,64], tpos_row)], ptr_entries: [(fp32 [B,256], pos/t_diff_max)] (A11)."""
+        n_mem, n_ptr = len(mem_entries), len(ptr_entries)
+        nk = n_mem * TOK + 4 * n_ptr
+        memory, memory_pos = self._empty(B, nk, 64), self._empty(B, nk, 64)
+        feats = (C.c_void_p * max(n_mem, 1))(*[t.data_ptr() for t, _ in mem_entries])
+        rows = (C.c_int32 * max(n_mem, 1))(*[int(r) for _, r in mem_entries])
+        ptrs = (C.c_void_p * max(n_ptr, 1))(*[t.data_ptr() for t, _ in ptr_entries])
+        pos = (C.c_float * max(n_ptr, 1))(*[float(p) for _, p in ptr_entries])
+        for t, _ in mem_entries:
+            assert t.dtype == torch.bfloat16 and tuple(t.shape) == (B, TOK, 64) and t.is_contiguous()
+        for t, _ in ptr_entries:
+            assert t.dtype == torch.float32 and tuple(t.shape) == (B, 256) and t.is_contiguous()
+        _capi.check(self.lib.ds2_bank_assemble(self.h, B, n_mem, feats, rows, n_ptr, ptrs, pos, _p(memory), _p(memory_pos),
+                                               self._stream()), "ds2_bank_assemble")
+        return memory, memory_pos
+
+    def memory_attention(self, B, curr, memory, memory_pos, num_obj_ptr_tokens):
+        """curr [4096,256] shared; memory/memory_pos [B,Nk,64] -> [B,4096,256] (A12)."""
+        nk = memory.shape[1]
+        out = self._empty(B, TOK, 256)
+        _capi.check(self.lib.ds2_memory_attention(self.h, B, _p(curr), _p(memory), _p(memory_pos), nk, num_obj_ptr_tokens,
+                                                  _p(out), self._stream()), "ds2_memory_attention")
+        return out
+
+    def sam_heads(self, B, pix_feat, fpn0, fpn1, point_coords=None, point_labels=None, multimask=False,
+                  pix_bcast=False, add_no_mem_embed=False):
+        """-> low_res [B,256,256], obj_ptr [B,256], obj_logits [B], ious [B] (A7+A8)."""
+        P = 0 if point_coords is None else point_coords.shape[1]
+        low, ptr = self._empty(B, 256, 256), self._empty(B, 256)
+        obj, iou = self._empty(B), self._empty(B)
+        if P:
+            assert point_coords.dtype == torch.float32 and point_labels.dtype == torch.int32
+            point_coords, point_labels = point_coords.contiguous(), point_labels.contiguous()
+        _capi.check(self.lib.ds2_sam_heads(self.h, B, _p(pix_feat), int(pix_bcast), int(add_no_mem_embed), _p(fpn0), _p(fpn1),
+                                           _p(point_coords), _p(point_labels), P, int(multimask), _p(low), _p(ptr), _p(obj),
+                                           _p(iou), self._stream()), "ds2_sam_heads")
+        return low, ptr, obj, iou
+
+    def memory_encoder(self, B, fpn2, low_res, obj_logits, binarize):
+        """-> maskmem bf16 [B,4096,64] (A13)."""
+        out = self._empty(B, TOK, 64, dtype=torch.bfloat16)
+        _capi.check(self.lib.ds2_memory_encoder(self.h, B, _p(fpn2), _p(low_res), _p(obj_logits), int(binarize), _p(out),
+                                                self._stream()), "ds2_memory_encoder")
+        return out
+
+    def mask_output(self, low_res, hv, wv, want_logits=True, want_packed=True):
+        """low_res [B,256,256] -> (logits fp32 [B,1,hv,wv] | None, packed uint8 [B,hv,wv/8] | None) (A15)."""
+        B = low_res.shape[0]
+        logits = self._empty(B, 1, hv, wv) if want_logits else None
+        packed = self._empty(B, hv, wv // 8, dtype=torch.uint8) if want_packed else None
+        _capi.check(self.lib.ds2_mask_output(self.h, _p(low_res), B, hv, wv, _p(logits), _p(packed), self._stream()),
+                    "ds2_mask_output")
+        return logits, packed

@@ -1,0 +1,131 @@
+/* detsam2_hip.h - C-ABI of libdetsam2_hip.so: the MI355X (gfx950) implementation of the Det-SAM2
+ * per-frame hot path (SAM 2.1 video predictor).  Plain pointers and sizes only; every pointer is a
+ * DEVICE pointer unless stated otherwise; `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  All entry points are asynchronous on `stream` and return 0 on success; on failure they
+ * return a non-zero code and ds2_last_error() describes it.
+ *
+ * The reference has no FFI of its own for this path (its only native symbol is the CUDA
+ * connected-components op, sam2/csrc/connected_components.cu:284-289); its plugin seam is the
+ * Hydra `_target_` module tree (sam2/configs/sam2.1/sam2.1_hiera_l.yaml:5-80).  Each stage below
+ * therefore replaces one nn.Module.forward / SAM2Base method of that tree, cited per function;
+ * file:line are relative to the reference repository.  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Layout conventions: activations are fp32 and TOKEN-MAJOR ("NHWC"): a feature map
+ * that the reference holds as [B,C,H,W] is [B, H*W, C] here; memory-bank features are bf16
+ * [B, 4096, 64] (the reference stores bf16 [B,64,64,64], sam2_video_predictor.py:1337).
+ */
+#ifndef DETSAM2_HIP_H
+#define DETSAM2_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS2_ABI_VERSION 1
+
+typedef struct ds2_model ds2_model;
+
+/* Hyper-parameters (sam2/configs/sam2.1/sam2.1_hiera_*.yaml + build_sam.py:126-135). */
+typedef struct ds2_config {
+  int32_t image_size;             /* 1024 */
+  int32_t embed_dim, num_heads;   /* Hiera trunk (hieradet.py:172-196) */
+  int32_t stages[4];
+  int32_t global_att_blocks[4];
+  int32_t n_global_att_blocks;
+  int32_t window_spec[4];
+  int32_t d_model, mem_dim;       /* 256, 64 */
+  int32_t num_maskmem;            /* 7 */
+  int32_t mem_attn_layers;        /* 4 */
+  int32_t mem_attn_ffn;           /* 2048 */
+  int32_t max_batch;              /* workspace is sized for this many objects (it grows on demand) */
+  float sigmoid_scale_for_mem_enc, sigmoid_bias_for_mem_enc;            /* 20, -10 */
+  float dynamic_multimask_stability_delta, dynamic_multimask_stability_thresh; /* 0.05, 0.98 */
+} ds2_config;
+
+const char* ds2_last_error(void);   /* thread-local, valid until the next failing call on this thread */
+int ds2_abi_version(void);
+
+/* ---- model lifetime ------------------------------------------------------------------------
+ * Replaces build_sam2_video_predictor + _load_checkpoint (sam2/build_sam.py:111-178): parameters are
+ * registered under their state_dict key (fp32, host or device pointer; the library copies them), then
+ * ds2_model_finalize checks the set is complete (strict, like load_state_dict) and packs derived
+ * weights.  Names starting with '#' are host-precomputed constants of the model (see
+ * det-sam2_amd/constants.py): "#pos_embed" [65536,embed_dim], "#rope_cis" [4096,128,2],
+ * "#vision_pos" [4096,256], "#maskmem_pos" [4096,64], "#dense_pe" [4096,256], "#ptr_dim_t" [128],
+ * "#ingest_lut" uint16[768]. */
+int ds2_model_create(const ds2_config* cfg, ds2_model** out);
+void ds2_model_destroy(ds2_model* m);
+int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_t nbytes);
+int ds2_model_finalize(ds2_model* m, void* stream);
+
+/* ---- A3: frame ingest.  load_video_frames, list-of-ndarray branch (sam2/utils/misc.py:280-284,
+ * 328-342, 358-359) for frames that are already image_size x image_size (identity resize):
+ * rgb_u8 [n,S,S,3] -> frames_f16 [n,3,S,S] = fp16((fp16(x/255) - mean) / std), fp16 roundings as the
+ * reference.  Other resolutions return DS2 error 4 (cv2.resize parity is unpinned). */
+int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t height, int32_t width,
+                      uint16_t* frames_f16, void* stream);
+
+/* ---- A4+A5: SAM2Base.forward_image (sam2/modeling/sam2_base.py:450-461) = ImageEncoder.forward
+ * (backbones/image_encoder.py:30-43): Hiera trunk (hieradet.py:283-299) + FpnNeck (:101-134, scalp=1)
+ * + conv_s0/conv_s1 (mask_decoder.py:73-78).  frame_f16 [3,S,S] ->
+ * fpn0 [65536,32], fpn1 [16384,64], fpn2 [4096,256]. */
+int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float* fpn0, float* fpn1, float* fpn2, void* stream);
+
+/* ---- A11: memory-bank assembly, the tensor part of _prepare_memory_conditioned_features
+ * (sam2_base.py:565-648).  feats[e]: bf16 [B,4096,64] of memory frame e, tpos_row[e] = index into
+ * maskmem_tpos_enc (= num_maskmem - t_pos - 1); ptrs[i]: fp32 [B,256] object pointers with temporal
+ * position ptr_pos[i] (already divided by max_obj_ptrs-1).  HOST arrays of device pointers.
+ * memory / memory_pos: [B, Nk, 64], Nk = n_mem*4096 + 4*n_ptr. */
+int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const void* const* feats, const int32_t* tpos_row,
+                      int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
+                      float* memory_pos, void* stream);
+
+/* ---- A12: MemoryAttention.forward (sam2/modeling/memory_attention.py:119-176) with RoPEAttention
+ * (sam/transformer.py:312-363).  curr [4096,256] is the level-2 feature of the frame, shared by the B
+ * objects (the reference .expand()s it, sam2_video_predictor.py:1193-1206); curr_pos is the model
+ * constant "#vision_pos".  out [B,4096,256]. */
+int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, const float* memory, const float* memory_pos,
+                         int32_t Nk, int32_t num_obj_ptr_tokens, float* out, void* stream);
+
+/* ---- A7+A8: SAM2Base._forward_sam_heads (sam2_base.py:254-397) = PromptEncoder.forward
+ * (sam/prompt_encoder.py:134-171) + MaskDecoder.forward (sam/mask_decoder.py:105-161) + mask selection,
+ * objectness gate, object pointer.  pix_feat: [B,4096,256], or [4096,256] shared when pix_bcast != 0
+ * (init-cond frames; add_no_mem_embed != 0 adds no_mem_embed, sam2_base.py:651-657).  point_coords
+ * [B,P,2] (1024-grid pixels) / point_labels [B,P] may be NULL (P=0: the reference's dummy point).
+ * Outputs: low_res [B,256,256] logits of the selected mask, obj_ptr [B,256], obj_logits [B],
+ * ious [B] (may be NULL). */
+int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
+                  const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
+                  int32_t P, int32_t multimask_output, float* low_res, float* obj_ptr, float* obj_logits,
+                  float* ious, void* stream);
+
+/* ---- A13: SAM2Base._encode_new_memory (sam2_base.py:692-743) = 256->1024 bilinear upsample
+ * (:355-360) + sigmoid|binarize, *20-10 + MemoryEncoder.forward (memory_encoder.py:158-181) +
+ * no_obj_embed_spatial + bf16 storage.  fpn2 [4096,256] raw level-2 feature, low_res [B,256,256],
+ * obj_logits [B] -> maskmem bf16 [B,4096,64]. */
+int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, const float* low_res, const float* obj_logits,
+                       int32_t binarize, uint16_t* maskmem_bf16, void* stream);
+
+/* ---- A15: _get_orig_video_res_output (sam2_video_predictor.py:618-642) + `> 0` (det_sam2_RT.py:396-399):
+ * low_res [B,256,256] -> logits fp32 [B,Hv,Wv] (may be NULL) and/or masks packed 8 px/byte, MSB first
+ * (numpy.packbits order) [B,Hv,Wv/8] (may be NULL). */
+int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
+                    uint8_t* packed, void* stream);
+
+/* ---- primitive ops (exported for unit tests and for integrators who want a single op) */
+int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
+                const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
+                int32_t ldr, int32_t r_mod, void* stream);
+int ds2_op_layernorm(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t C, float eps,
+                     int32_t act, void* stream);
+int ds2_op_attention(const float* q, const float* k, const float* v, float* o, int32_t ldq, int32_t ldk, int32_t ldv,
+                     int32_t ldo, int32_t batch, int32_t heads, int32_t D, int32_t DV, int32_t Lq, int32_t Lk,
+                     float scale, int32_t win_q, int32_t win_k, int32_t Hq, int32_t Wq, int32_t Hk, int32_t Wk,
+                     int32_t nwx, const float* k_pad, const float* v_pad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETSAM2_HIP_H */

@@ -1,0 +1,147 @@
+"""GPU parity of the primitive HIP ops (through the C-ABI) against fp64 PyTorch-CPU formulas."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from _util import record, rel_err
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from det_sam2_amd.hip_model import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.mark.parametrize("M,N,K,act,use_r,r_mod,use_g", [
+    (128, 128, 64, 0, False, 0, False),
+    (200, 96, 148, 0, True, 0, False),
+    (1000, 432, 144, 2, False, 0, False),
+    (513, 4, 256, 3, False, 0, False),
+    (16, 1, 256, 0, False, 0, False),
+    (300, 256, 576, 1, True, 100, True),
+    (4096, 768, 256, 0, False, 0, False),
+])
+def test_gemm(ops, M, N, K, act, use_r, r_mod, use_g):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    R = torch.randn(r_mod if r_mod else M, N, generator=g) if use_r else None
+    gam = torch.randn(N, generator=g) if use_g else None
+    ref = A.double() @ W.double().T + b.double()
+    ref = [lambda x: x, F.relu, F.gelu, torch.sigmoid][act](ref)
+    if use_g:
+        ref = ref * gam.double()
+    if use_r:
+        ref = ref + (R.double()[torch.arange(M) % r_mod] if r_mod else R.double())
+    d = ops.device
+    got = ops.op_gemm(A.to(d), W.to(d), b.to(d), act, None if gam is None else gam.to(d), None if R is None else R.to(d), r_mod)
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    record("gemm", M=M, N=N, K=K, act=act, err=e)
+    assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("rows,C,act", [(37, 96, 0), (1000, 256, 2), (5, 1152, 0), (64, 4, 2)])
+def test_layernorm(ops, rows, C, act):
+    g = torch.Generator().manual_seed(rows)
+    x, w, b = torch.randn(rows, C, generator=g) * 3 + 1, torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)
+    if act == 2:
+        ref = F.gelu(ref)
+    got = ops.op_layernorm(x.to(ops.device), w.to(ops.device), b.to(ops.device), 1e-6, act)
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    record("layernorm", rows=rows, C=C, err=e)
+    assert e < 1e-5, e
+
+
+@pytest.mark.parametrize("B,H,D,DV,Lq,Lk", [
+    (2, 1, 256, 256, 200, 300),
+    (2, 1, 256, 64, 130, 1000),
+    (3, 8, 16, 16, 9, 500),
+    (3, 8, 16, 16, 500, 9),
+    (2, 8, 32, 32, 9, 9),
+    (1, 2, 72, 72, 256, 256),
+    (1, 2, 96, 96, 64, 64),
+    (2, 4, 56, 56, 100, 196),
+])
+def test_attention_plain(ops, B, H, D, DV, Lq, Lk):
+    g = torch.Generator().manual_seed(D * 31 + Lq)
+    q, k, v = torch.randn(B, Lq, H * D, generator=g), torch.randn(B, Lk, H * D, generator=g), torch.randn(B, Lk, H * DV, generator=g)
+    sc = 1.0 / math.sqrt(D)
+
+    def heads(x, d):
+        return x.double().reshape(B, -1, H, d).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(heads(q, D), heads(k, D), heads(v, DV), scale=sc).transpose(1, 2).reshape(B, Lq, H * DV)
+    d = ops.device
+    got = ops.op_attention(q.to(d), k.to(d), v.to(d), H, sc)
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    record("attention_plain", D=D, DV=DV, Lq=Lq, Lk=Lk, err=e)
+    assert e < 2e-5, e
+
+
+def _window_ref(q_nat, k_nat, v_nat, kb, vb, side_q, side_k, win_q, win_k, heads):
+    """Reference windowed attention with zero-pad semantics (pad keys = bias rows)."""
+    def part(x, side, ws, pad_row):
+        C = x.shape[-1]
+        x = x.reshape(side, side, C)
+        p = (ws - side % ws) % ws
+        if p:
+            full = pad_row.reshape(1, 1, C).expand(side + p, side + p, C).clone()
+            full[:side, :side] = x
+            x = full
+        sp = side + p
+        x = x.reshape(sp // ws, ws, sp // ws, ws, C).permute(0, 2, 1, 3, 4).reshape(-1, ws * ws, C)
+        return x, sp
+
+    qw, spq = part(q_nat, side_q, win_q, torch.zeros(q_nat.shape[-1], dtype=q_nat.dtype))
+    kw, _ = part(k_nat, side_k, win_k, kb)
+    vw, _ = part(v_nat, side_k, win_k, vb)
+    nW = qw.shape[0]
+    D = q_nat.shape[-1] // heads
+
+    def hd(x):
+        return x.reshape(nW, -1, heads, D).transpose(1, 2)
+
+    o = F.scaled_dot_product_attention(hd(qw), hd(kw), hd(vw)).transpose(1, 2).reshape(nW, win_q * win_q, -1)
+    n = spq // win_q
+    o = o.reshape(n, n, win_q, win_q, -1).permute(0, 2, 1, 3, 4).reshape(spq, spq, -1)
+    return o[:side_q, :side_q].reshape(side_q * side_q, -1)
+
+
+@pytest.mark.parametrize("side,win,heads,D,pool", [
+    (64, 8, 1, 96, False), (64, 8, 2, 72, True), (64, 14, 4, 96, False), (64, 14, 2, 56, True), (32, 7, 2, 96, False),
+    (64, 16, 8, 72, False),
+])
+def test_attention_windowed(ops, side, win, heads, D, pool):
+    g = torch.Generator().manual_seed(side + win)
+    dim = heads * D
+    qkv = torch.randn(side * side, 3 * dim, generator=g)
+    bias = torch.randn(3 * dim, generator=g)
+    k_nat, v_nat = qkv[:, dim:2 * dim], qkv[:, 2 * dim:]
+    if pool:
+        q_nat = F.max_pool2d(qkv[:, :dim].reshape(side, side, dim).permute(2, 0, 1)[None], 2, 2)[0].permute(1, 2, 0).reshape(-1, dim).contiguous()
+        side_q, win_q = side // 2, win // 2
+    else:
+        q_nat, side_q, win_q = qkv[:, :dim], side, win
+    ref = _window_ref(q_nat.double(), k_nat.double(), v_nat.double(), bias[dim:2 * dim].double(), bias[2 * dim:].double(),
+                      side_q, side, win_q, win, heads)
+    d = ops.device
+    qkv_d, bias_d = qkv.to(d), bias.to(d)
+    qd = q_nat.to(d).contiguous() if pool else qkv_d[:, :dim]
+    nw = -(-side // win)
+    got = ops.op_attention(qd, qkv_d[:, dim:2 * dim], qkv_d[:, 2 * dim:], heads, 1.0 / math.sqrt(D), win_q=win_q, win_k=win,
+                           hq=side_q, wq=side_q, hk=side, wk=side, nwx=nw, k_pad=bias_d[dim:2 * dim], v_pad=bias_d[2 * dim:],
+                           batch=nw * nw, lq=win_q * win_q, lk=win * win, dv=D)
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    record("attention_windowed", side=side, win=win, heads=heads, D=D, pool=pool, err=e)
+    assert e < 2e-5, e

@@ -1,0 +1,152 @@
+"""GPU parity of each hot-path stage (C-ABI, HIP kernels) against the CPU oracle on the same seeded
+inputs and the same synthetic checkpoint.  Tolerances are for fp32 arithmetic with a different
+summation order (MFMA tiles vs ATen CPU kernels)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from det_sam2_amd.config import resolve_config
+from det_sam2_amd.synth import synthetic_frame
+from det_sam2_amd.weights import synthetic_state_dict
+from oracle import modeling as M
+from oracle.predictor import OraclePredictor, load_frames
+from _util import record, rel_err
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def model(name):
+    if name not in _CACHE:
+        from det_sam2_amd.hip_model import HipSam2
+        cfg = resolve_config(name)
+        sd = synthetic_state_dict(cfg, 0)
+        _CACHE[name] = (cfg, sd, HipSam2(cfg, sd, "cuda:0", max_batch=4))
+    return _CACHE[name]
+
+
+def nhwc(x):  # [B,C,H,W] -> [B,H*W,C]
+    return x.flatten(2).transpose(1, 2).contiguous()
+
+
+def test_ingest_bit_exact():
+    cfg, sd, hm = model("sam2.1_hiera_t")
+    frames = [synthetic_frame(t) for t in range(2)]
+    ref, _, _ = load_frames(frames)
+    got = hm.ingest(torch.from_numpy(np.stack(frames)).to(hm.device))
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("name", ["sam2.1_hiera_t", "sam2.1_hiera_b+", "sam2.1_hiera_l"])
+def test_image_encoder(name):
+    cfg, sd, hm = model(name)
+    imgs, _, _ = load_frames([synthetic_frame(5)])
+    with torch.inference_mode():
+        fpn, _ = M.forward_image(sd, cfg, imgs[0].float().unsqueeze(0))
+    f0, f1, f2 = hm.image_encoder(imgs[0].to(hm.device))
+    torch.cuda.synchronize()
+    errs = [rel_err(g, nhwc(r)[0]) for g, r in zip((f0, f1, f2), fpn)]
+    record("image_encoder", model=name, e0=errs[0], e1=errs[1], e2=errs[2])
+    assert max(errs) < 2e-4, errs
+
+
+def test_memory_attention_and_bank():
+    cfg, sd, hm = model("sam2.1_hiera_t")
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    curr = torch.randn(4096, 256, generator=g)
+    feats = [torch.randn(B, 64, 64, 64, generator=g).to(torch.bfloat16) for _ in range(2)]
+    ptrs = [torch.randn(B, 256, generator=g) for _ in range(3)]
+    tpos_rows, ptr_pos = [6, 2], [0.0, 1.0, -4.0]
+    # oracle formulation of the bank tensors (sam2_base.py:565-648)
+    pos2 = M.sine_pos_2d(64, 64, 64)
+    mems, poss = [], []
+    for f, r in zip(feats, tpos_rows):
+        mems.append(f.float().flatten(2).permute(2, 0, 1))
+        poss.append(pos2[None].expand(B, -1, -1, -1).flatten(2).permute(2, 0, 1) + sd["maskmem_tpos_enc"][r])
+    op = M.linear(sd, "obj_ptr_tpos_proj", M.sine_pe_1d(torch.tensor(ptr_pos) / 15.0, 256))
+    op = op.unsqueeze(1).expand(-1, B, 64).repeat_interleave(4, dim=0)
+    pt = torch.stack(ptrs, 0).reshape(-1, B, 4, 64).permute(0, 2, 1, 3).flatten(0, 1)
+    memory, memory_pos = torch.cat(mems + [pt], 0), torch.cat(poss + [op], 0)
+    vis_pos = M.sine_pos_2d(256, 64, 64).flatten(1).T
+    with torch.inference_mode():
+        ref = M.memory_attention(sd, cfg, curr[:, None].expand(-1, B, -1), vis_pos[:, None].expand(-1, B, -1), memory,
+                                 memory_pos, 12)
+    d = hm.device
+    mem_d, pos_d = hm.bank_assemble(B, [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)],
+                                    [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)])
+    torch.cuda.synchronize()
+    e_mem, e_pos = rel_err(mem_d, memory.transpose(0, 1)), rel_err(pos_d, memory_pos.transpose(0, 1))
+    out = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 12)
+    torch.cuda.synchronize()
+    e = rel_err(out, ref.transpose(0, 1))
+    record("memory_attention", e_mem=e_mem, e_pos=e_pos, err=e)
+    assert e_mem == 0.0 and e_pos < 1e-5 and e < 2e-4, (e_mem, e_pos, e)
+
+
+@pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True)])
+def test_sam_heads(prompt, multimask):
+    cfg, sd, hm = model("sam2.1_hiera_t")
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    feats = torch.randn(B, 256, 64, 64, generator=g)
+    hr0, hr1 = torch.randn(1, 32, 256, 256, generator=g), torch.randn(1, 64, 128, 128, generator=g)
+    pin = None
+    if prompt == "box":
+        pin = {"point_coords": torch.rand(B, 2, 2, generator=g) * 1024, "point_labels": torch.tensor([[2, 3]] * B, dtype=torch.int32)}
+    with torch.inference_mode():
+        ref = OraclePredictor(sd, cfg).forward_sam_heads(feats, pin, None, [hr0.expand(B, -1, -1, -1), hr1.expand(B, -1, -1, -1)], multimask)
+    d = hm.device
+    low, ptr, obj, iou = hm.sam_heads(B, nhwc(feats).to(d), nhwc(hr0)[0].to(d), nhwc(hr1)[0].to(d),
+                                      None if pin is None else pin["point_coords"].to(d),
+                                      None if pin is None else pin["point_labels"].to(d), multimask)
+    torch.cuda.synchronize()
+    e_low, e_ptr, e_obj = rel_err(low, ref[3][:, 0]), rel_err(ptr, ref[5]), rel_err(obj, ref[6][:, 0])
+    record("sam_heads", prompt=prompt, e_low=e_low, e_ptr=e_ptr, e_obj=e_obj)
+    assert e_low < 2e-4 and e_ptr < 2e-4 and e_obj < 2e-4, (e_low, e_ptr, e_obj)
+
+
+@pytest.mark.parametrize("binarize", [False, True])
+def test_memory_encoder(binarize):
+    cfg, sd, hm = model("sam2.1_hiera_t")
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    pix = torch.randn(1, 256, 64, 64, generator=g)
+    low = torch.randn(B, 1, 256, 256, generator=g) * 3
+    obj = torch.tensor([[1.5], [-0.5]])
+    op = OraclePredictor(sd, cfg)
+    with torch.inference_mode():
+        high = F.interpolate(low, size=(1024, 1024), mode="bilinear", align_corners=False)
+        f, _ = op.encode_new_memory(pix.expand(B, -1, -1, -1).flatten(2).permute(2, 0, 1), high, obj, binarize)
+    ref = f.to(torch.bfloat16)
+    d = hm.device
+    got = hm.memory_encoder(B, nhwc(pix)[0].to(d), low[:, 0].contiguous().to(d), obj[:, 0].contiguous().to(d), binarize)
+    torch.cuda.synchronize()
+    # bf16 storage: allow 1 bf16 ulp on a few elements from rounding-boundary flips
+    diff = (got.float().cpu() - nhwc(ref.float())).abs()
+    tol = nhwc(ref.float()).abs() * 2 ** -7 + 1e-3
+    frac_bad = float((diff > tol).float().mean())
+    e = rel_err(got.float(), nhwc(ref.float()))
+    record("memory_encoder", binarize=binarize, err=e, frac_bad=frac_bad)
+    assert frac_bad == 0.0 and e < 1e-2, (e, frac_bad)
+
+
+def test_mask_output():
+    cfg, sd, hm = model("sam2.1_hiera_t")
+    g = torch.Generator().manual_seed(3)
+    low = torch.randn(3, 1, 256, 256, generator=g)
+    for hv, wv in ((1024, 1024), (720, 1280), (256, 256)):
+        ref = low if (hv, wv) == (256, 256) else F.interpolate(low, size=(hv, wv), mode="bilinear", align_corners=False)
+        logits, packed = hm.mask_output(low[:, 0].contiguous().to(hm.device), hv, wv)
+        torch.cuda.synchronize()
+        e = float((logits.cpu() - ref).abs().max())
+        bits = np.unpackbits(packed.cpu().numpy(), axis=-1).astype(bool)
+        mism = float((bits != (logits.cpu().numpy()[:, 0] > 0)).mean())
+        record("mask_output", hv=hv, wv=wv, err=e, mism=mism)
+        assert e < 1e-5 and mism == 0.0, (e, mism)

@@ -99,3 +99,36 @@ def test_e2e_config1_matches_reference_golden(tiny, golden_dir):
         ref_mask = np.unpackbits(g["bits"][i]).reshape(1, 1, 1024, 1024).astype(bool)
         ours = vp.video_segments[int(t)][0]
         assert 1.0 - _iou(ours, ref_mask[0]) <= 1e-3
+
+
+def test_e2e_stream2_matches_reference_golden(tiny, golden_dir):
+    """Two passes, release_old_frames, and the online new-object path (A17)."""
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_stream2.npz"))
+    vp = OracleVideoProcessor(sd, cfg, SyntheticDetector(3, appear={2: 4}), skip_classes=set(), frame_buffer_size=4,
+                              detect_interval=4, max_frame_num_to_track=8, max_inference_state_frames=6)
+    lows = []
+    orig = vp.predictor.propagate_in_video
+
+    def capture(st, **kw):
+        for t, ids, logits in orig(st, **kw):
+            od = st["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            lows.append((t, len(ids), od[key][t]["pred_masks"].clone().numpy(), (logits > 0).numpy()))
+            yield t, ids, logits
+
+    vp.predictor.propagate_in_video = capture
+    with torch.inference_mode():
+        for t in range(8):
+            vp.process_frame(t, synthetic_frame(t))
+    assert [l[0] for l in lows] == list(g["frames"])
+    assert [l[1] for l in lows] == list(g["nobj"])
+    assert sorted(vp.inference_state["output_dict"]["cond_frame_outputs"]) == list(g["final_cond"])
+    assert sorted(vp.inference_state["output_dict"]["non_cond_frame_outputs"]) == list(g["final_noncond"])
+    assert vp.inference_state["images_idx"] == list(g["images_idx"])
+    for i, (t, nobj, low, mask) in enumerate(lows):
+        ref_low_bits = np.unpackbits(g[f"lowbits{i}"])[: low.size].reshape(low.shape).astype(bool)
+        assert 1.0 - _iou(low > 0, ref_low_bits) <= 1e-3
+        assert np.abs(low - g[f"low{i}"].astype(np.float32)).max() <= 2e-2 + 1e-3 * np.abs(low).max()
+        ref_bits = np.unpackbits(g[f"bits{i}"])[: mask[:, :, ::2, ::2].size].reshape(mask[:, :, ::2, ::2].shape).astype(bool)
+        assert 1.0 - _iou(mask[:, :, ::2, ::2], ref_bits) <= 1e-3
