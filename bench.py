@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py - frames/sec/GPU of propagate_in_video on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): sam2.1_hiera_large, 16 objects, 1024x1024 synthetic frames, 7-frame memory
+bank (1 conditioning + 6 non-conditioning frames, 16 object pointers => Nk = 28736), synthetic
+deterministic checkpoint (no SAM 2.1 weights exist offline).  A "step" = one tracked frame of
+propagate_in_video: image encoder on a NEW frame (no feature-cache hit), bank gather, 4-layer memory
+attention, SAM heads (multimask), memory encoder, 256->1024 upsample + threshold + bit-pack, and the packed
+masks copied to the host.  Frames are resident in HBM (as in the reference, where init_state loads them
+before propagate).  N>1: passes shard over ranks (weak scaling), with the RCCL all-gather of the cond-frame
+bank entry inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PREFILL = 15  # tracked frames needed before the 7-frame bank + 16 pointers are in steady state
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
+    """Algorithmic FLOPs of ONE cross-attention launch (one layer, all B objects): QK^T over 256-d keys plus
+    P.V in the 64-d memory space (DESIGN.md section 'Kernels')."""
+    return 2.0 * B * tokens * Nk * (d + dv)
+
+
+def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
+    """Oracle (CPU restatement, oracle/) timed on the host cores on a bounded sample of the same workload:
+    one tracked frame with ONE object (encoder + bank of 7 frames/16 pointers + memory attention + SAM heads +
+    memory encoder), then scaled to 16 objects: t_frame(16) = t_encoder + 16 * t_per_object."""
+    from det_sam2_amd.config import resolve_config
+    from det_sam2_amd.synth import synthetic_frame
+    from det_sam2_amd.weights import synthetic_state_dict
+    from oracle import modeling as M
+    from oracle.predictor import OraclePredictor, load_frames
+
+    cfg = resolve_config(model_name)
+    sd = synthetic_state_dict(cfg, 0)
+    op = OraclePredictor(sd, cfg)
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    imgs, _, _ = load_frames([synthetic_frame(0)])
+    with torch.inference_mode():
+        t0 = time.time()
+        fpn, pos = M.forward_image(sd, cfg, imgs[0].float().unsqueeze(0))
+        t_enc = time.time() - t0
+        feats = [f.flatten(2).permute(2, 0, 1) for f in fpn]
+        poss = [p.flatten(2).permute(2, 0, 1) for p in pos]
+        mk = lambda: {"maskmem_features": torch.randn(1, 64, 64, 64, generator=g).to(torch.bfloat16),  # noqa: E731
+                      "maskmem_pos_enc": [M.sine_pos_2d(64, 64, 64)[None]], "obj_ptr": torch.randn(1, 256, generator=g)}
+        od = {"cond_frame_outputs": {0: mk()}, "non_cond_frame_outputs": {t: mk() for t in range(1, 16)}}
+        t0 = time.time()
+        op.track_step(16, False, feats, poss, None, None, od, 64, False, True)
+        t_obj = time.time() - t0
+    fps16 = 1.0 / (t_enc + 16.0 * t_obj)
+    return {"value": fps16, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (fp32 PyTorch-CPU restatement) on 1 tracked frame, 1 object, {model_name}, Nk=28736: "
+                      f"encoder {t_enc:.1f}s + per-object {t_obj:.1f}s; value = 1/(t_enc+16*t_obj)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="sam2.1_hiera_l")
+    ap.add_argument("--objects", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = f"cuda:{local}"
+
+    from det_sam2_amd.config import resolve_config
+    from det_sam2_amd.parallel import allgather_cond_entries
+    from det_sam2_amd.sam2_video_predictor import SAM2VideoPredictor
+    from det_sam2_amd.synth import synthetic_box, synthetic_frame
+    from det_sam2_amd.weights import synthetic_state_dict
+
+    cfg = resolve_config(a.model)
+    B, K, W = a.objects, a.steps, a.warmup
+    pred = SAM2VideoPredictor(cfg, synthetic_state_dict(cfg, 0), dev, max_batch=B)
+    n_frames = 1 + PREFILL + W + K
+    seed = 1000 * rank   # every rank (= its own pass shard) sees different frames
+    frames = torch.from_numpy(np.stack([synthetic_frame(t, seed) for t in range(n_frames)])).to(dev)
+    st = pred.init_state(frames)
+    del frames
+    for o in range(B):
+        pred.add_new_points_or_box(st, 0, o, box=synthetic_box(o % 16, 0, seed))
+    gen = pred.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=n_frames, reverse=False, output="packed")
+    hv, wv = st["video_height"], st["video_width"]
+    host = torch.empty((K, B, hv, wv // 8), dtype=torch.uint8).pin_memory()
+    next(gen)                                   # frame 0: conditioning frame (no tracking)
+    for _ in range(PREFILL + W):                # fill the bank to steady state + warmup
+        next(gen)
+    torch.cuda.synchronize()
+    nk = 4096 * 7 + 4 * 16
+    assert pred.trace is None
+    pred.trace = []
+    pred.hip.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if world > 1:   # the one data-path exchange of the pass-sharded design: this pass' cond-frame bank entry
+        allgather_cond_entries(st["output_dict"]["cond_frame_outputs"][0])
+    for i in range(K):
+        _, _, bits = next(gen)
+        host[i].copy_(bits, non_blocking=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    pred.hip.profile_enable(False)
+    assert all(tr["nk"] == nk for tr in pred.trace), [tr["nk"] for tr in pred.trace]
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    ca_ms, ca_n = pred.hip.profile_read("kernel.cross_attention")
+    stage_ms = {}
+    for tag in ("stage.image_encoder", "stage.memory_attention", "stage.sam_heads", "stage.memory_encoder", "kernel.self_attention"):
+        ms, n = pred.hip.profile_read(tag)
+        stage_ms[tag] = round(ms / max(K, 1), 3)
+    if rank == 0:
+        achieved = cross_attention_flops(B, nk) / (ca_ms / max(ca_n, 1) * 1e-3) / 1e12 if ca_n else None
+        out = {
+            "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
+            "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} propagate_in_video, {B} objects, 1024x1024 uniform-noise frames, "
+                                   f"7-frame memory bank + 16 object pointers (Nk={nk}), synthetic checkpoint seed 0, "
+                                   f"encoder run on every tracked frame, packed masks copied to host",
+                       "objects": B, "Nk": nk, "frames_per_rank": K, "parallelism": f"pass-sharded dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_attention<256,64> (memory cross-attention, 1 launch/layer)",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n},
+            "ms_per_step_by_stage": stage_ms,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.model)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

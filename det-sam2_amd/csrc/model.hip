@@ -23,6 +23,44 @@ void ds2_set_error(const char* fmt, ...) {
 extern "C" const char* ds2_last_error(void) { return g_err; }
 extern "C" int ds2_abi_version(void) { return DS2_ABI_VERSION; }
 
+// ------------------------------------------------------------------------------------------------ profiling
+// HIP-event brackets on the caller's stream around named launch sites; read back by bench.py for the
+// live roofline numbers (ds2_profile_read synchronises the recorded events, never the hot path).
+namespace {
+struct ProfRec { hipEvent_t a, b; };
+bool g_prof = false;
+std::unordered_map<std::string, std::vector<ProfRec>> g_recs;
+struct ProfScope {
+  hipStream_t st; const char* tag; ProfRec r; bool on;
+  ProfScope(const char* t, hipStream_t s) : st(s), tag(t), on(g_prof) {
+    if (!on) return;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, st);
+    g_recs[tag].push_back(r);
+  }
+};
+}  // namespace
+extern "C" int ds2_profile_enable(int32_t on) { g_prof = on != 0; return DS2_OK; }
+extern "C" int ds2_profile_read(const char* tag, double* total_ms, int64_t* launches) {
+  DS2_REQUIRE(tag && total_ms && launches, "ds2_profile_read: null argument");
+  *total_ms = 0.0; *launches = 0;
+  auto it = g_recs.find(tag);
+  if (it == g_recs.end()) return DS2_OK;
+  for (ProfRec& r : it->second) {
+    float ms = 0.f;
+    DS2_CHECK_HIP(hipEventSynchronize(r.b));
+    DS2_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    *total_ms += ms; *launches += 1;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  it->second.clear();
+  return DS2_OK;
+}
+
 #define TRY(x)              \
   do {                      \
     int _r = (x);           \
@@ -297,6 +335,7 @@ extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n,
 extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float* fpn0, float* fpn1, float* fpn2, void* stream) {
   DS2_REQUIRE(m && m->finalized && frame_f16 && fpn0 && fpn1 && fpn2, "ds2_image_encoder: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope _ps("stage.image_encoder", st);
   const int C0 = m->cfg.embed_dim;
   // workspace bound: every block output kept (sum <= depth * 65536*C0 floats is a loose bound) + temporaries
   size_t need = (size_t)65536 * 148 * 4;
@@ -441,6 +480,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
               "ds2_memory_attention: bad argument");
   DS2_REQUIRE((Nk - n_ptr_tok) % TOK == 0, "ds2_memory_attention: Nk - num_obj_ptr_tokens must be a multiple of 4096");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope _ps("stage.memory_attention", st);
   const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
   const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + (4u << 20);
   TRY(m->require(need, st));
@@ -474,7 +514,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     sa.q = qkv; sa.k = qkv + 256; sa.v = qkv + 512; sa.o = a;
     sa.ldq = sa.ldk = sa.ldv = 768; sa.ldo = 256;
     sa.batch = Bs; sa.heads = 1; sa.D = 256; sa.DV = 256; sa.Lq = sa.Lk = TOK; sa.scale = sc;
-    TRY(launch_attention(sa, st));
+    { ProfScope _p("kernel.self_attention", st); TRY(launch_attention(sa, st)); }
     if (l == 0) {
       TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
       for (int b = 0; b < B; ++b)
@@ -493,7 +533,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     ca.q = q; ca.k = K; ca.v = memory; ca.o = a64;
     ca.ldq = 256; ca.ldk = 256; ca.ldv = 64; ca.ldo = 64;
     ca.batch = B; ca.heads = 1; ca.D = 256; ca.DV = 64; ca.Lq = TOK; ca.Lk = Nk; ca.scale = sc;
-    TRY(launch_attention(ca, st));
+    { ProfScope _p("kernel.cross_attention", st); TRY(launch_attention(ca, st)); }
     TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256));
     TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     // -- FFN
@@ -551,6 +591,7 @@ extern "C" int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int
               "ds2_sam_heads: bad argument");
   DS2_REQUIRE(P >= 0 && P <= 8 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope _ps("stage.sam_heads", st);
   const int rows = B * TOK;
   const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * 16 * 2048 * 4) * 4 + (8u << 20);
   TRY(m->require(need, st));
@@ -658,6 +699,7 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
                                   int32_t binarize, uint16_t* maskmem_bf16, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && fpn2 && low_res && obj_logits && maskmem_bf16, "ds2_memory_encoder: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  ProfScope _ps("stage.memory_encoder", st);
   const int rows = B * TOK;
   const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (8u << 20);
   TRY(m->require(need, st));

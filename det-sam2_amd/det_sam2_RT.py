@@ -1,0 +1,196 @@
+"""VideoProcessor: the Det-SAM2 streaming driver (det_sam2_inference/det_sam2_RT.py:25-651) on MI355X.
+
+Same constructor arguments and public methods (``run``, ``process_frame``,
+``Detect_and_SAM2_inference``, ``clear``, ``save/load_inference_state``).  Differences, all outside the
+arithmetic: YOLO is injected (``detector``: any callable at the YOLO output contract
+det_sam2_RT.py:228-244, or a path handled by ultralytics if it is installed); thresholded masks leave the
+GPU bit-packed, once per pass, instead of one blocking ``.cpu()`` per object per frame (:396-399);
+visualisation/rendering (:628-651) is not part of the hot path.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .build_sam import build_sam2_video_predictor
+
+
+class VideoProcessor:
+    def __init__(self, output_dir=None, sam2_checkpoint=None, model_cfg="configs/sam2.1/sam2.1_hiera_l.yaml",
+                 detect_model_weights=None, detect_confidence=0.85, skip_classes={11, 14, 15, 19}, vis_frame_stride=-1,
+                 visualize_prompt=False, frame_buffer_size=30, detect_interval=30, max_frame_num_to_track=60,
+                 max_inference_state_frames=60, load_inference_state_path=None, save_inference_state_path=None,
+                 detector=None, device="cuda", predictor=None):
+        self.output_dir = output_dir
+        self.sam2_checkpoint, self.model_cfg = sam2_checkpoint, model_cfg
+        self.detect_model_weights, self.detect_confidence = detect_model_weights, detect_confidence
+        self.skip_classes = set(skip_classes)
+        self.vis_frame_stride, self.visualize_prompt = vis_frame_stride, visualize_prompt
+        self.frame_buffer_size, self.detect_interval = frame_buffer_size, detect_interval
+        self.frame_buffer = []
+        self.max_frame_num_to_track = max_frame_num_to_track
+        self.max_inference_state_frames = max_inference_state_frames
+        self.load_inference_state_path = load_inference_state_path
+        self.save_inference_state_path = save_inference_state_path
+        self.pre_frames = 0
+        if save_inference_state_path is not None:
+            assert max_inference_state_frames == -1, \
+                "saving a preload memory bank requires max_inference_state_frames == -1 (det_sam2_RT.py:67-68)"
+        if vis_frame_stride != -1 or visualize_prompt:
+            raise NotImplementedError("rendering / prompt visualisation is outside the hot path")
+        self.special_classes = 11
+        self.special_classes_detection, self.special_classes_count = [], 0
+        self.predictor = predictor or build_sam2_video_predictor(model_cfg, sam2_checkpoint, device=device)
+        if detector is None:
+            if detect_model_weights is None:
+                raise ValueError("pass `detector` (callable frame_idx, frame_rgb -> detections) or YOLO weights")
+            from ultralytics import YOLO  # third-party, out of scope; only used if installed
+
+            yolo = YOLO(detect_model_weights)
+
+            def detector(frame_idx, frame_rgb, _yolo=yolo):
+                res = next(iter(_yolo([frame_rgb[..., ::-1]], stream=True, conf=self.detect_confidence, iou=0.1, verbose=False)))
+                return [{"coordinates": b.xyxy[0].cpu().numpy(), "class": b.cls.cpu().numpy(), "confidence": b.conf.cpu().numpy()}
+                        for b in (res.boxes or [])]
+        self.detector = detector
+        self.video_segments = {}
+        self.inference_state = None
+        self.pass_log = []
+        if output_dir:
+            os.makedirs(output_dir, exist_ok=True)
+
+    def clear(self):
+        """det_sam2_RT.py:189-198."""
+        self.frame_buffer, self.pre_frames = [], 0
+        self.special_classes_detection, self.video_segments, self.inference_state = [], {}, None
+
+    # ------------------------------------------------------------------ A2
+    def detect_predict(self, images, past_num_frames):
+        """det_sam2_RT.py:201-265."""
+        res = {}
+        if self.detect_interval == -1:
+            return res
+        for i, image in enumerate(images):
+            t = past_num_frames + i
+            if t % self.detect_interval != 0:
+                continue
+            dets = list(self.detector(t, image))
+            if not self.special_classes_detection:
+                self.special_classes_count = 0
+            cls = [int(np.asarray(d["class"]).reshape(-1)[0]) for d in dets]
+            n_special = sum(1 for c in cls if c == self.special_classes)
+            if n_special > self.special_classes_count:
+                self.special_classes_detection = [d["coordinates"] for d, c in zip(dets, cls) if c == self.special_classes]
+                self.special_classes_count = n_special
+            res[f"frame_{t}"] = dets
+        return res
+
+    def Detect_2_SAM2_Prompt(self, detection_results_json):
+        """det_sam2_RT.py:267-316."""
+        for key, dets in (detection_results_json or {}).items():
+            t = int(key.replace("frame_", ""))
+            for d in dets:
+                c = int(np.asarray(d["class"]).reshape(-1)[0])
+                if c in self.skip_classes:
+                    continue
+                self.predictor.add_new_points_or_box(inference_state=self.inference_state, frame_idx=t, obj_id=c,
+                                                     box=np.array(d["coordinates"], dtype=np.float32))
+        return self.inference_state
+
+    # ------------------------------------------------------------------ A1
+    def Detect_and_SAM2_inference(self, frame_idx):
+        """det_sam2_RT.py:342-411."""
+        past = self.inference_state["num_frames"] if self.inference_state else 0
+        dets = self.detect_predict(self.frame_buffer, past)
+        if self.inference_state is None:
+            self.inference_state = self.predictor.init_state(video_path=self.frame_buffer)
+        else:
+            self.inference_state = self.predictor.update_state(video_path=self.frame_buffer, inference_state=self.inference_state)
+        self.inference_state = self.Detect_2_SAM2_Prompt(dets)
+        yielded, packed = [], []
+        for t, obj_ids, bits in self.predictor.propagate_in_video(
+                self.inference_state, start_frame_idx=frame_idx, max_frame_num_to_track=self.max_frame_num_to_track,
+                reverse=True, output="packed"):
+            yielded.append(t)
+            if t >= self.pre_frames:
+                packed.append((t, list(obj_ids), bits))
+        # one device->host transfer per pass, then unpack to the reference's {obj_id: bool[1,Hv,Wv]} format
+        hv, wv = self.inference_state["video_height"], self.inference_state["video_width"]
+        if packed:
+            host = torch.stack([b for _, _, b in packed]).cpu().numpy()
+            for (t, ids, _), pb in zip(packed, host):
+                m = np.unpackbits(pb, axis=-1).reshape(len(ids), 1, hv, wv).astype(bool)
+                self.video_segments[t] = {oid: m[i] for i, oid in enumerate(ids)}
+        if self.max_inference_state_frames != -1:
+            self.predictor.release_old_frames(self.inference_state, frame_idx, self.max_inference_state_frames,
+                                              self.pre_frames, release_images=(self.vis_frame_stride == -1))
+        od = self.inference_state["output_dict"]
+        self.pass_log.append((frame_idx, yielded, sorted(od["cond_frame_outputs"]), sorted(od["non_cond_frame_outputs"])))
+
+    def process_frame(self, frame_idx, frame):
+        """det_sam2_RT.py:421-435."""
+        self.frame_buffer.append(frame)
+        if len(self.frame_buffer) >= self.frame_buffer_size:
+            self.Detect_and_SAM2_inference(frame_idx)
+            self.frame_buffer.clear()
+        return self.inference_state
+
+    # ------------------------------------------------------------------ A18 (preload bank)
+    def save_inference_state(self, save_path):
+        """det_sam2_RT.py:489-497 (pickle of the whole state; tensors are moved to host first)."""
+        os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+
+        def to_host(x):
+            if isinstance(x, torch.Tensor):
+                return x.cpu()
+            if isinstance(x, dict):
+                return type(x)((k, to_host(v)) for k, v in x.items())
+            if isinstance(x, (list, tuple)):
+                return type(x)(to_host(v) for v in x)
+            if isinstance(x, torch.device):
+                return str(x)
+            return x
+
+        st = {k: v for k, v in self.inference_state.items() if k != "cached_features"}
+        st["cached_features"] = {}
+        with open(save_path, "wb") as f:
+            pickle.dump(to_host(st), f)
+
+    def load_inference_state(self, load_path):
+        """det_sam2_RT.py:499-503."""
+        with open(load_path, "rb") as f:
+            return pickle.load(f)
+
+    def run(self, video_path=None, frame_dir=None, output_video_segments_pkl_path=None,
+            output_special_classes_detection_pkl_path=None, frames=None):
+        """det_sam2_RT.py:526-626 for an in-memory iterable of RGB frames (``frames``).  Video files / frame
+        folders need cv2 (not part of the hot path): decode them upstream and pass the frames."""
+        if frames is None:
+            raise NotImplementedError("pass frames=<iterable of HxWx3 uint8 RGB arrays>; cv2 decoding is out of scope")
+        if self.load_inference_state_path is not None:
+            self.inference_state = self.load_inference_state(self.load_inference_state_path)
+            od = self.inference_state["output_dict"]
+            self.inference_state["preloading_memory_cond_frame_idx"] = list(od["cond_frame_outputs"].keys())
+            self.inference_state["preloading_memory_non_cond_frames_idx"] = list(od["non_cond_frame_outputs"].keys())
+            self.pre_frames = self.inference_state["num_frames"]
+            self.predictor.init_preloading_state(self.inference_state)
+        idx = 0
+        for fr in frames:
+            self.inference_state = self.process_frame(self.pre_frames + idx, fr)
+            idx += 1
+        if self.frame_buffer:
+            self.Detect_and_SAM2_inference(frame_idx=self.pre_frames + idx - 1)
+            self.frame_buffer.clear()
+        self.video_segments = {t - self.pre_frames: s for t, s in self.video_segments.items() if t >= self.pre_frames}
+        if output_video_segments_pkl_path:
+            with open(output_video_segments_pkl_path, "wb") as f:
+                pickle.dump(self.video_segments, f)
+        if output_special_classes_detection_pkl_path and self.special_classes_detection is not None:
+            with open(output_special_classes_detection_pkl_path, "wb") as f:
+                pickle.dump(self.special_classes_detection, f)
+        if self.save_inference_state_path is not None:
+            self.save_inference_state(self.save_inference_state_path)
+        return self.video_segments

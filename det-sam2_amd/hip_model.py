@@ -40,6 +40,16 @@ class HipOps:
     def _empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, on=True):
+        _capi.check(self.lib.ds2_profile_enable(int(on)), "ds2_profile_enable")
+
+    def profile_read(self, tag):
+        """-> (total_ms, launches) of the HIP-event brackets recorded under ``tag`` since the last read."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        _capi.check(self.lib.ds2_profile_read(tag.encode(), C.byref(ms), C.byref(n)), "ds2_profile_read")
+        return ms.value, n.value
+
     # ------------------------------------------------------------------ primitives (tests)
     def op_gemm(self, A, W, bias=None, act=0, gamma=None, R=None, r_mod=0):
         M, K = A.shape

@@ -1,0 +1,455 @@
+"""SAM2VideoPredictor for MI355X: the reference's predictor API and inference-state schema
+(sam2/sam2_video_predictor.py) over the HIP stages of ``HipSam2``.
+
+Same public methods, argument meaning and error behaviour as the reference so that
+``VideoProcessor`` / ``DetSAM2Pipeline`` callers stay drop-in:
+``init_state, update_state, init_preloading_state, add_new_points_or_box, propagate_in_video
+(generator), release_old_frames, reset_state``.
+
+What is re-designed (results unchanged):
+* everything stays in HBM: frames (fp16), per-frame pyramid features, the memory bank (bf16) - no
+  host offload, no per-object ``.cpu()``, no ``empty_cache()``;
+* image features are cached for every retained frame, so the second visit of a frame in the next
+  pass (README.md:161 of the reference) does not re-run the encoder;
+* the memory bank is indexed, not concatenated on the host: one gather kernel per tracked frame;
+* tensors are token-major: ``pred_masks`` [B,1,256,256] as in the reference, ``maskmem_features`` bf16
+  [B,4096,64] (reference: [B,64,64,64]); ``maskmem_pos_enc`` is a model constant and is stored as None.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .config import resolve_config
+from .hip_model import HipSam2
+
+NO_OBJ_SCORE = -1024.0  # sam2_base.py:21
+
+
+class SAM2VideoPredictor:
+    def __init__(self, cfg, state_dict, device="cuda:0", max_batch=16):
+        self.cfg = resolve_config(cfg)
+        self.hip = HipSam2(self.cfg, state_dict, device, max_batch)
+        self.device = self.hip.device
+        self.image_size = self.cfg.image_size
+        self.hidden_dim, self.mem_dim, self.num_maskmem = self.cfg.d_model, self.cfg.mem_dim, self.cfg.num_maskmem
+        self.trace = None          # optional list of bank-selection traces (tests)
+        self.stats = {"encoder_runs": 0, "tracked_frames": 0}
+
+    # ------------------------------------------------------------------ frame ingest (A3)
+    def _load_frames(self, video_path):
+        if isinstance(video_path, np.ndarray) and video_path.ndim == 3:
+            video_path = [video_path]
+        if isinstance(video_path, torch.Tensor):       # already-resident uint8 [n,H,W,3] frames
+            u8 = video_path
+        elif isinstance(video_path, (list, tuple)) and all(isinstance(p, np.ndarray) for p in video_path):
+            u8 = torch.from_numpy(np.ascontiguousarray(np.stack(video_path)))
+        elif isinstance(video_path, np.ndarray) and video_path.ndim == 4:
+            u8 = torch.from_numpy(np.ascontiguousarray(video_path))
+        else:
+            raise NotImplementedError(
+                "only in-memory RGB uint8 frames (ndarray / list of ndarray / uint8 tensor) are supported; "
+                "JPEG folders and video files are outside the hot path (misc.py:292-303)")
+        h, w = int(u8.shape[1]), int(u8.shape[2])
+        images = self.hip.ingest(u8.to(self.device, non_blocking=True).contiguous())
+        return images, h, w
+
+    @torch.inference_mode()
+    def init_state(self, video_path, offload_video_to_cpu=True, offload_state_to_cpu=False, async_loading_frames=False):
+        """init_state (sam2_video_predictor.py:44-120).  The offload flags are accepted for signature
+        compatibility; state always lives in HBM here."""
+        images, vh, vw = self._load_frames(video_path)
+        st = {}
+        st["images"] = images
+        st["num_frames"] = len(images)
+        st["images_idx"] = list(range(len(images)))
+        st["offload_video_to_cpu"] = False
+        st["offload_state_to_cpu"] = False
+        st["video_height"], st["video_width"] = vh, vw
+        st["device"] = self.device
+        st["storage_device"] = self.device
+        st["point_inputs_per_obj"] = {}
+        st["mask_inputs_per_obj"] = {}
+        st["cached_features"] = {}
+        st["constants"] = {}
+        st["obj_id_to_idx"] = OrderedDict()
+        st["obj_idx_to_id"] = OrderedDict()
+        st["obj_ids"] = []
+        st["output_dict"] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        st["output_dict_per_obj"] = {}
+        st["temp_output_dict_per_obj"] = {}
+        st["consolidated_frame_inds"] = {"cond_frame_outputs": set(), "non_cond_frame_outputs": set()}
+        st["tracking_has_started"] = False
+        st["frames_already_tracked"] = {}
+        st["preloading_memory_cond_frame_idx"] = None
+        st["preloading_memory_non_cond_frames_idx"] = None
+        st["max_update_length_for_new_obj_id"] = 100
+        self._get_image_feature(st, 0)
+        return st
+
+    @torch.inference_mode()
+    def update_state(self, video_path, inference_state, async_loading_frames=False):
+        """update_state (sam2_video_predictor.py:160-204)."""
+        st = inference_state
+        new, vh, vw = self._load_frames(video_path)
+        assert vh == st["video_height"] and vw == st["video_width"], "new frames must match the video size"
+        last = st["images_idx"][-1]
+        st["images_idx"].extend(range(last + 1, last + 1 + len(new)))
+        st["images"] = torch.cat((st["images"], new), dim=0)
+        st["num_frames"] += len(new)
+        return st
+
+    def init_preloading_state(self, inference_state, offload_video_to_cpu=True, offload_state_to_cpu=True):
+        """init_preloading_state (sam2_video_predictor.py:123-156): in the reference this moves the preload
+        bank to the storage device; here the bank is already resident - just make sure it is on this GPU."""
+        st = inference_state
+        st["storage_device"] = st["device"] = self.device
+        st["images"] = st["images"].to(self.device)
+        for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+            for out in st["output_dict"][key].values():
+                for k in ("maskmem_features", "pred_masks", "obj_ptr", "object_score_logits"):
+                    if out.get(k) is not None:
+                        out[k] = out[k].to(self.device)
+        for t, out in st["output_dict"]["cond_frame_outputs"].items():
+            self._add_output_per_object(st, t, out, "cond_frame_outputs")
+        st["cached_features"] = {}
+
+    # ------------------------------------------------------------------ features (A4/A5)
+    def _get_image_feature(self, st, frame_idx):
+        """_get_image_feature (sam2_video_predictor.py:1174-1212) with a whole-window cache."""
+        f = st["cached_features"].get(frame_idx)
+        if f is None:
+            img = st["images"][st["images_idx"].index(frame_idx)]
+            f = self.hip.image_encoder(img)
+            st["cached_features"][frame_idx] = f
+            self.stats["encoder_runs"] += 1
+        return f
+
+    # ------------------------------------------------------------------ object table (A17)
+    def _new_slot(self, st, obj_id):
+        idx = len(st["obj_id_to_idx"])
+        st["obj_id_to_idx"][obj_id] = idx
+        st["obj_idx_to_id"][idx] = obj_id
+        st["obj_ids"] = list(st["obj_id_to_idx"])
+        st["point_inputs_per_obj"][idx] = {}
+        st["mask_inputs_per_obj"][idx] = {}
+        st["output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        st["temp_output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        return idx
+
+    def _obj_id_to_idx(self, st, obj_id):
+        """_obj_id_to_idx incl. the online new-object path (sam2_video_predictor.py:219-333)."""
+        idx = st["obj_id_to_idx"].get(obj_id)
+        if idx is not None:
+            return idx
+        idx = self._new_slot(st, obj_id)
+        if st["tracking_has_started"]:
+            od = st["output_dict"]
+            inds = sorted(od["cond_frame_outputs"].keys())
+            mx = st["max_update_length_for_new_obj_id"]
+            if mx > 0:
+                inds = inds[-mx:]
+            for t in st["preloading_memory_cond_frame_idx"] or []:
+                if t not in inds:
+                    inds.append(t)
+            for t in inds:
+                cons = self._consolidate(st, t, True, True)
+                od["cond_frame_outputs"][t] = cons
+                self._add_output_per_object(st, t, cons, "cond_frame_outputs")
+        return idx
+
+    def _get_obj_num(self, st):
+        return len(st["obj_idx_to_id"])
+
+    # ------------------------------------------------------------------ prompts (A6)
+    @torch.inference_mode()
+    def add_new_points_or_box(self, inference_state, frame_idx, obj_id, points=None, labels=None, clear_old_points=True,
+                              normalize_coords=True, box=None):
+        """add_new_points_or_box (sam2_video_predictor.py:344-520)."""
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        if (points is not None) != (labels is not None):
+            raise ValueError("points and labels must be provided together")
+        if points is None and box is None:
+            raise ValueError("at least one of points or box must be provided as input")
+        points = torch.zeros(0, 2, dtype=torch.float32) if points is None else torch.as_tensor(points, dtype=torch.float32)
+        labels = torch.zeros(0, dtype=torch.int32) if labels is None else torch.as_tensor(labels, dtype=torch.int32)
+        if points.dim() == 2:
+            points = points.unsqueeze(0)
+        if labels.dim() == 1:
+            labels = labels.unsqueeze(0)
+        if box is not None:
+            if not clear_old_points:
+                raise ValueError("cannot add box without clearing old points, since box prompt must be provided "
+                                 "before any point prompt (please use clear_old_points=True instead)")
+            box = torch.as_tensor(box, dtype=torch.float32)
+            points = torch.cat([box.reshape(1, 2, 2), points], dim=1)
+            labels = torch.cat([torch.tensor([[2, 3]], dtype=torch.int32), labels], dim=1)
+        if normalize_coords:
+            points = points / torch.tensor([st["video_width"], st["video_height"]], dtype=torch.float32)
+        points = points * self.image_size
+        pin = {"point_coords": points.to(self.device), "point_labels": labels.to(self.device)}
+        if not clear_old_points and frame_idx in st["point_inputs_per_obj"][obj_idx]:
+            old = st["point_inputs_per_obj"][obj_idx][frame_idx]
+            pin = {"point_coords": torch.cat([old["point_coords"], pin["point_coords"]], dim=1),
+                   "point_labels": torch.cat([old["point_labels"], pin["point_labels"]], dim=1)}
+        st["point_inputs_per_obj"][obj_idx][frame_idx] = pin
+        st["mask_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        is_init_cond_frame = frame_idx not in st["frames_already_tracked"]
+        if not is_init_cond_frame:
+            raise NotImplementedError("correction prompts on already-tracked frames are outside the Det-SAM2 hot path "
+                                      "(Det-SAM2 only prompts frames of the newest buffer, det_sam2_RT.py:217-222)")
+        obj_tmp, obj_out = st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]
+        prev = obj_tmp["cond_frame_outputs"].get(frame_idx) or obj_out["cond_frame_outputs"].get(frame_idx) \
+            or obj_out["non_cond_frame_outputs"].get(frame_idx)
+        if prev is not None and prev["pred_masks"] is not None:
+            raise NotImplementedError("a second prompt for the same object on the same frame needs the mask-prompt path "
+                                      "(prev_sam_mask_logits, sam2_video_predictor.py:470-483): next row F3")
+        # single-object SAM pass without memory (is_init_cond_frame): pix = feat + no_mem_embed (sam2_base.py:651-657)
+        f0, f1, f2 = self._get_image_feature(st, frame_idx)
+        npts = pin["point_labels"].shape[1]
+        multimask = self.cfg.multimask_min_pt_num <= npts <= self.cfg.multimask_max_pt_num   # _use_multimask :922-932
+        low, ptr, obj, _ = self.hip.sam_heads(1, f2, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
+                                              pix_bcast=True, add_no_mem_embed=True)
+        obj_tmp["cond_frame_outputs"][frame_idx] = {
+            "maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1),
+            "obj_ptr": ptr, "object_score_logits": obj.unsqueeze(1)}
+        cons = self._consolidate(st, frame_idx, True, False)
+        return frame_idx, st["obj_ids"], self._video_res(st, cons["pred_masks"])
+
+    def add_new_points(self, *a, **k):
+        return self.add_new_points_or_box(*a, **k)
+
+    def add_new_mask(self, *a, **k):
+        raise NotImplementedError("add_new_mask (mask prompts) is next-row F3 of the scope table, not built yet")
+
+    def _video_res(self, st, low, packed=False):
+        """_get_orig_video_res_output (sam2_video_predictor.py:618-642)."""
+        logits, bits = self.hip.mask_output(low[:, 0].contiguous(), st["video_height"], st["video_width"],
+                                            want_logits=not packed, want_packed=packed)
+        return bits if packed else logits
+
+    # ------------------------------------------------------------------ consolidation (A9)
+    def _consolidate(self, st, frame_idx, is_cond, run_mem_encoder):
+        """_consolidate_temp_output_across_obj (sam2_video_predictor.py:644-767) at low resolution."""
+        B = self._get_obj_num(st)
+        key = "cond_frame_outputs" if is_cond else "non_cond_frame_outputs"
+        d = self.device
+        cons = {"maskmem_features": None, "maskmem_pos_enc": None,
+                "pred_masks": torch.full((B, 1, 256, 256), NO_OBJ_SCORE, dtype=torch.float32, device=d),
+                "obj_ptr": torch.full((B, self.hidden_dim), NO_OBJ_SCORE, dtype=torch.float32, device=d),
+                "object_score_logits": torch.full((B, 1), 10.0, dtype=torch.float32, device=d)}
+        for i in range(B):
+            tmp, od = st["temp_output_dict_per_obj"][i], st["output_dict_per_obj"][i]
+            out = tmp[key].get(frame_idx) or od["cond_frame_outputs"].get(frame_idx) \
+                or od["non_cond_frame_outputs"].get(frame_idx)
+            if out is None:
+                if run_mem_encoder:
+                    # _get_empty_mask_ptr (:769-804): the reference runs the SAM heads on an all-zero mask and
+                    # then multiplies the pointer by is_obj_appearing = 0 (sam2_base.py:436-444) => no_obj_ptr.
+                    cons["obj_ptr"][i:i + 1] = self.hip.no_obj_ptr
+                continue
+            cons["pred_masks"][i:i + 1] = out["pred_masks"]
+            cons["obj_ptr"][i:i + 1] = out["obj_ptr"]
+            cons["object_score_logits"][i:i + 1] = out["object_score_logits"]
+        if run_mem_encoder:
+            _, _, f2 = self._get_image_feature(st, frame_idx)
+            cons["maskmem_features"] = self.hip.memory_encoder(
+                B, f2, cons["pred_masks"][:, 0].contiguous(), cons["object_score_logits"][:, 0].contiguous(),
+                binarize=self.cfg.binarize_mask_from_pts_for_mem_enc)
+        return cons
+
+    def _add_output_per_object(self, st, frame_idx, out, key):
+        """_add_output_per_object (sam2_video_predictor.py:1027-1058): per-object views."""
+        for i, od in st["output_dict_per_obj"].items():
+            s = slice(i, i + 1)
+            if out["pred_masks"].shape[0] <= i:
+                continue
+            od[key][frame_idx] = {
+                "maskmem_features": None if out["maskmem_features"] is None else out["maskmem_features"][s],
+                "maskmem_pos_enc": None, "pred_masks": out["pred_masks"][s], "obj_ptr": out["obj_ptr"][s],
+                "object_score_logits": out["object_score_logits"][s]}
+
+    # ------------------------------------------------------------------ propagate (A9, A10, A11)
+    @torch.inference_mode()
+    def propagate_in_video_preflight(self, inference_state):
+        """propagate_in_video_preflight (sam2_video_predictor.py:807-893)."""
+        st = inference_state
+        st["tracking_has_started"] = True
+        od, cfi = st["output_dict"], st["consolidated_frame_inds"]
+        for is_cond in (False, True):
+            key = "cond_frame_outputs" if is_cond else "non_cond_frame_outputs"
+            inds = set()
+            for tmp in st["temp_output_dict_per_obj"].values():
+                inds.update(tmp[key].keys())
+            cfi[key].update(inds)
+            for t in inds:
+                cons = self._consolidate(st, t, is_cond, True)
+                od[key][t] = cons
+                self._add_output_per_object(st, t, cons, key)
+            for tmp in st["temp_output_dict_per_obj"].values():
+                tmp[key].clear()
+        for t in od["cond_frame_outputs"]:
+            od["non_cond_frame_outputs"].pop(t, None)
+        for o in st["output_dict_per_obj"].values():
+            for t in o["cond_frame_outputs"]:
+                o["non_cond_frame_outputs"].pop(t, None)
+        for t in cfi["cond_frame_outputs"]:
+            assert t in od["cond_frame_outputs"]
+            cfi["non_cond_frame_outputs"].discard(t)
+
+    def _select_cond(self, frame_idx, cond, preload_idx):
+        """select_closest_cond_frames (sam2_utils.py:19-66), Det-SAM2 variant."""
+        mx = self.cfg.max_cond_frames_in_attn
+        if mx == -1 or len(cond) <= mx:
+            return cond, {}
+        sel = {}
+        before = max((t for t in cond if t < frame_idx), default=None)
+        if before is not None:
+            sel[before] = cond[before]
+        after = min((t for t in cond if t >= frame_idx), default=None)
+        if after is not None:
+            sel[after] = cond[after]
+        rest = sorted((t for t in cond if t not in sel), key=lambda x: abs(x - frame_idx))[: mx - len(sel)]
+        sel.update((t, cond[t]) for t in rest)
+        for t in preload_idx or []:
+            if t not in sel:
+                sel[t] = cond[t]
+        return sel, {t: v for t, v in cond.items() if t not in sel}
+
+    def _bank_for_frame(self, st, frame_idx, B, reverse):
+        """Index logic of _prepare_memory_conditioned_features (sam2_base.py:500-648): which stored entries
+        enter the bank, their temporal slots and the pointer list.  Returns (mem_entries, ptr_entries)."""
+        od = st["output_dict"]
+        sign = -1 if reverse else 1
+        sel, unsel = self._select_cond(frame_idx, od["cond_frame_outputs"], st["preloading_memory_cond_frame_idx"])
+        slots = [(0, t, out) for t, out in sel.items()]
+        for t_pos in range(1, self.num_maskmem):
+            t_rel = self.num_maskmem - t_pos
+            prev = frame_idx + t_rel if reverse else frame_idx - t_rel
+            out = od["non_cond_frame_outputs"].get(prev)
+            if out is None:
+                out = unsel.get(prev)
+            slots.append((t_pos, prev, out))
+        mem_entries, tr = [], {"frame": frame_idx, "mem": [], "ptr": []}
+        for t_pos, t, out in slots:
+            if out is None:
+                continue
+            f = out["maskmem_features"]
+            if f.shape[0] != B:
+                raise RuntimeError(f"memory entry of frame {t} has batch {f.shape[0]}, expected {B}")
+            mem_entries.append((f, self.num_maskmem - t_pos - 1))
+            tr["mem"].append((t_pos, t))
+        max_ptrs = min(st["num_frames"], self.cfg.max_obj_ptrs_in_encoder)
+        ptr_cond = {t: o for t, o in sel.items() if (t >= frame_idx if reverse else t <= frame_idx)}
+        pos_ptrs = [((frame_idx - t) * sign, o["obj_ptr"]) for t, o in ptr_cond.items()]
+        for t_diff in range(1, max_ptrs):
+            t = frame_idx + t_diff if reverse else frame_idx - t_diff
+            if t < 0 or t >= st["num_frames"]:
+                break
+            o = od["non_cond_frame_outputs"].get(t, unsel.get(t))
+            if o is not None:
+                pos_ptrs.append((t_diff, o["obj_ptr"]))
+        tdm = np.float32(max_ptrs - 1)
+        ptr_entries = [(p, float(np.float32(pos) / tdm)) for pos, p in pos_ptrs]
+        tr["ptr"] = [p for p, _ in pos_ptrs]
+        tr["nk"], tr["n_ptr_tok"] = 4096 * len(mem_entries) + 4 * len(ptr_entries), 4 * len(ptr_entries)
+        if self.trace is not None:
+            self.trace.append(tr)
+        return mem_entries, ptr_entries
+
+    def _track_frame(self, st, frame_idx, B, reverse):
+        """_run_single_frame_inference + track_step for a non-conditioning frame (is_init_cond_frame=False,
+        no prompts, run_mem_encoder=True)  (sam2_video_predictor.py:1280-1365; sam2_base.py:857-919)."""
+        f0, f1, f2 = self._get_image_feature(st, frame_idx)
+        mem_entries, ptr_entries = self._bank_for_frame(st, frame_idx, B, reverse)
+        memory, memory_pos = self.hip.bank_assemble(B, mem_entries, ptr_entries)
+        pix = self.hip.memory_attention(B, f2, memory, memory_pos, 4 * len(ptr_entries))
+        low, ptr, obj, _ = self.hip.sam_heads(B, pix, f0, f1, None, None, multimask=True)   # num_pts=0 => multimask
+        mem = self.hip.memory_encoder(B, f2, low, obj, binarize=False)
+        # NOTE fill_holes_in_mask_scores (misc.py:365-393) is a silent no-op in the CPU reference => not applied
+        self.stats["tracked_frames"] += 1
+        return {"maskmem_features": mem, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1), "obj_ptr": ptr,
+                "object_score_logits": obj.unsqueeze(1)}
+
+    @torch.inference_mode()
+    def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False,
+                           output="logits"):
+        """propagate_in_video (sam2_video_predictor.py:911-1025).  Generator of
+        (frame_idx, obj_ids, video_res_masks fp32 [B,1,Hv,Wv]); with output='packed' the third item is the
+        thresholded mask packed 8 px/byte [B,Hv,Wv/8] (the det_sam2_RT.py:396-399 consumer only needs bits)."""
+        st = inference_state
+        self.propagate_in_video_preflight(st)
+        od, cfi = st["output_dict"], st["consolidated_frame_inds"]
+        obj_ids, n, B = st["obj_ids"], st["num_frames"], self._get_obj_num(st)
+        if len(od["cond_frame_outputs"]) == 0:
+            raise RuntimeError("No points are provided; please add points first")
+        if start_frame_idx is None:
+            start_frame_idx = min(od["cond_frame_outputs"])
+        if max_frame_num_to_track is None:
+            max_frame_num_to_track = n
+        if reverse:
+            end = max(start_frame_idx - max_frame_num_to_track + 1, 0)
+            order = range(start_frame_idx, end - 1, -1) if start_frame_idx > 0 else []
+        else:
+            end = min(start_frame_idx + max_frame_num_to_track, n - 1)
+            order = range(start_frame_idx, end + 1)
+        for t in order:
+            if t in cfi["cond_frame_outputs"]:
+                key = "cond_frame_outputs"
+                cur = od[key][t]
+            elif t in cfi["non_cond_frame_outputs"]:
+                key = "non_cond_frame_outputs"
+                cur = od[key][t]
+            else:
+                key = "non_cond_frame_outputs"
+                cur = self._track_frame(st, t, B, reverse)
+                od[key][t] = cur
+            self._add_output_per_object(st, t, cur, key)
+            st["frames_already_tracked"][t] = {"reverse": reverse}
+            yield t, obj_ids, self._video_res(st, cur["pred_masks"], packed=(output == "packed"))
+
+    # ------------------------------------------------------------------ eviction / reset (A16)
+    def release_old_frames(self, inference_state, frame_idx, max_inference_state_frames, pre_frames, release_images=False):
+        """release_old_frames (sam2_video_predictor.py:1215-1273); also drops the cached features of released frames."""
+        st = inference_state
+        oldest = frame_idx - max_inference_state_frames
+        od = st["output_dict"]
+        old_c = [t for t in od["cond_frame_outputs"] if pre_frames - 1 < t <= oldest]
+        old_n = [t for t in od["non_cond_frame_outputs"] if pre_frames - 1 < t <= oldest]
+        for t in old_n:
+            od["non_cond_frame_outputs"].pop(t, None)
+            for o in st["output_dict_per_obj"].values():
+                o["non_cond_frame_outputs"].pop(t, None)
+        for t in old_c:
+            od["cond_frame_outputs"].pop(t, None)
+            st["consolidated_frame_inds"]["cond_frame_outputs"].discard(t)
+            for o in st["output_dict_per_obj"].values():
+                o["cond_frame_outputs"].pop(t, None)
+        for t in [t for t in st["cached_features"] if pre_frames - 1 < t <= oldest]:
+            st["cached_features"].pop(t, None)
+        if release_images:
+            old = [t for t in st["images_idx"] if pre_frames - 1 < t <= oldest]
+            rm = {st["images_idx"].index(t) for t in old}
+            keep = torch.tensor([i for i in range(st["images"].size(0)) if i not in rm], device=st["images"].device)
+            st["images"] = torch.index_select(st["images"], 0, keep)
+            st["images_idx"] = [t for t in st["images_idx"] if t not in old]
+            assert len(st["images"]) == len(st["images_idx"])
+
+    @torch.inference_mode()
+    def reset_state(self, inference_state):
+        """reset_state (sam2_video_predictor.py:1134-1172)."""
+        st = inference_state
+        for k in ("point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj", "temp_output_dict_per_obj"):
+            st[k].clear()
+        st["obj_id_to_idx"].clear()
+        st["obj_idx_to_id"].clear()
+        st["obj_ids"].clear()
+        st["output_dict"]["cond_frame_outputs"].clear()
+        st["output_dict"]["non_cond_frame_outputs"].clear()
+        st["consolidated_frame_inds"]["cond_frame_outputs"].clear()
+        st["consolidated_frame_inds"]["non_cond_frame_outputs"].clear()
+        st["tracking_has_started"] = False
+        st["frames_already_tracked"].clear()

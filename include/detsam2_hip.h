@@ -114,6 +114,13 @@ int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, const float* 
 int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
                     uint8_t* packed, void* stream);
 
+/* ---- measurement: HIP-event brackets (on the caller's stream) around named launch sites.  Tags:
+ * "kernel.cross_attention", "kernel.self_attention", "stage.image_encoder", "stage.memory_attention",
+ * "stage.sam_heads", "stage.memory_encoder".  ds2_profile_read waits for the recorded events, returns the
+ * summed duration and launch count since the last read, and clears them. */
+int ds2_profile_enable(int32_t on);
+int ds2_profile_read(const char* tag, double* total_ms, int64_t* launches);
+
 /* ---- primitive ops (exported for unit tests and for integrators who want a single op) */
 int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
                 const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,

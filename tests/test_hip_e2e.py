@@ -1,0 +1,91 @@
+"""End-to-end GPU parity: the MI355X VideoProcessor/SAM2VideoPredictor (HIP stages through the C-ABI)
+against golden vectors produced by the REFERENCE itself (tests/golden, oracle/make_goldens.py).
+Bar (BASELINE.json): 1 - IoU <= 1e-3 per (frame, object) on identical frames; logits within fp32 noise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import record
+from det_sam2_amd.config import resolve_config
+from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
+from det_sam2_amd.weights import synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+TINY = "sam2.1_hiera_t"
+
+
+def _iou(a, b):
+    inter, union = np.logical_and(a, b).sum(), np.logical_or(a, b).sum()
+    return 1.0 if union == 0 else inter / union
+
+
+def _vp(detector, **kw):
+    from det_sam2_amd.det_sam2_RT import VideoProcessor
+    from det_sam2_amd.sam2_video_predictor import SAM2VideoPredictor
+    cfg = resolve_config(TINY)
+    pred = SAM2VideoPredictor(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=4)
+    return VideoProcessor(model_cfg=TINY, detector=detector, skip_classes=set(), predictor=pred, **kw)
+
+
+def test_config1_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "e2e_cfg1.npz"))
+    vp = _vp(SyntheticDetector(1), frame_buffer_size=8, detect_interval=8, max_frame_num_to_track=8, max_inference_state_frames=-1)
+    for t in range(8):
+        vp.process_frame(t, synthetic_frame(t))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    worst_iou, worst_logit = 0.0, 0.0
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].cpu().numpy()
+        worst_logit = max(worst_logit, float(np.abs(low - g["low"][i]).max()))
+        ref = np.unpackbits(g["bits"][i]).reshape(1, 1024, 1024).astype(bool)
+        worst_iou = max(worst_iou, 1.0 - _iou(vp.video_segments[int(t)][0], ref))
+    record("e2e_cfg1", one_minus_iou=worst_iou, max_abs_dlogit=worst_logit, logit_absmax=float(np.abs(g["low"]).max()))
+    assert worst_iou <= 1e-3 and worst_logit <= 5e-3, (worst_iou, worst_logit)
+    assert vp.predictor.stats["encoder_runs"] == 8
+
+
+def test_stream2_matches_reference(golden_dir):
+    """Two passes, release_old_frames with image release, online new object (A17)."""
+    g = np.load(os.path.join(golden_dir, "e2e_stream2.npz"))
+    vp = _vp(SyntheticDetector(3, appear={2: 4}), frame_buffer_size=4, detect_interval=4, max_frame_num_to_track=8,
+             max_inference_state_frames=6)
+    lows = []
+    orig = vp.predictor.propagate_in_video
+
+    def capture(st, **kw):
+        for t, ids, bits in orig(st, **kw):
+            od = st["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            lows.append((t, len(ids), od[key][t]["pred_masks"].clone()))
+            yield t, ids, bits
+
+    vp.predictor.propagate_in_video = capture
+    for t in range(8):
+        vp.process_frame(t, synthetic_frame(t))
+    assert [l[0] for l in lows] == list(g["frames"])
+    assert [l[1] for l in lows] == list(g["nobj"])
+    st = vp.inference_state
+    assert sorted(st["output_dict"]["cond_frame_outputs"]) == list(g["final_cond"])
+    assert sorted(st["output_dict"]["non_cond_frame_outputs"]) == list(g["final_noncond"])
+    assert st["images_idx"] == list(g["images_idx"])
+    worst = 0.0
+    for i, (t, nobj, low) in enumerate(lows):
+        low = low.cpu().numpy()
+        ref_bits = np.unpackbits(g[f"lowbits{i}"])[: low.size].reshape(low.shape).astype(bool)
+        for o in range(nobj):
+            worst = max(worst, 1.0 - _iou(low[o] > 0, ref_bits[o]))
+        assert np.abs(low - g[f"low{i}"].astype(np.float32)).max() <= 2e-2 + 1e-3 * np.abs(low).max()
+    # final masks of the second pass at video resolution (2x decimated in the fixture)
+    n_first = int((g["pass_id"] == 0).sum())
+    for i in range(n_first, len(lows)):
+        t, nobj, _ = lows[i]
+        seg = np.stack([vp.video_segments[t][oid] for oid in sorted(vp.video_segments[t])])[:, :, ::2, ::2]
+        ref = np.unpackbits(g[f"bits{i}"])[: seg.size].reshape(seg.shape).astype(bool)
+        for o in range(nobj):
+            worst = max(worst, 1.0 - _iou(seg[o], ref[o]))
+    record("e2e_stream2", one_minus_iou=worst)
+    assert worst <= 1e-3, worst
