@@ -23,6 +23,14 @@ void ds2_set_error(const char* fmt, ...) {
 extern "C" const char* ds2_last_error(void) { return g_err; }
 extern "C" int ds2_abi_version(void) { return DS2_ABI_VERSION; }
 
+int g_ds2_precision = DS2_PREC_BF16X3;
+extern "C" int ds2_set_precision(int32_t mode) {
+  DS2_REQUIRE(mode == DS2_PREC_FP32 || mode == DS2_PREC_BF16X3, "ds2_set_precision: mode must be 0 (fp32) or 1 (bf16x3)");
+  g_ds2_precision = mode;
+  return DS2_OK;
+}
+extern "C" int ds2_get_precision(void) { return g_ds2_precision; }
+
 // ------------------------------------------------------------------------------------------------ profiling
 // HIP-event brackets on the caller's stream around named launch sites; read back by bench.py for the
 // live roofline numbers (ds2_profile_read synchronises the recorded events, never the hot path).
@@ -153,7 +161,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     return DS2_ERR_STATE;
   }
   GemmArgs g{M, N, K, A, lda, W, ldw, bias, C, ldc, act, gamma, R, ldr, r_mod};
-  return launch_gemm(g, st);
+  return g_ds2_precision == DS2_PREC_BF16X3 ? launch_gemm_bf16x3(g, st) : launch_gemm(g, st);
 }
 // Linear layer by state_dict prefix: y = act(x W^T + b) (+ R)
 static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int N, int K, const float* A, int lda,

@@ -40,6 +40,13 @@ class HipOps:
     def _empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
+    def set_precision(self, mode: str):
+        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, default)."""
+        _capi.check(self.lib.ds2_set_precision({"fp32": 0, "bf16x3": 1}[mode]), "ds2_set_precision")
+
+    def get_precision(self) -> str:
+        return ["fp32", "bf16x3"][self.lib.ds2_get_precision()]
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on=True):
         _capi.check(self.lib.ds2_profile_enable(int(on)), "ds2_profile_enable")

@@ -114,6 +114,13 @@ int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, const float* 
 int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
                     uint8_t* packed, void* stream);
 
+/* ---- arithmetic mode of the matrix-core kernels (process-wide): 0 = exact fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), 1 = split-precision bf16x3 (x = x0 + x1 in bf16, a0b0 + a0b1 + a1b0 with fp32
+ * accumulation, ~2^-16 relative error per product; default).  Softmax, LayerNorm, residuals and all
+ * storage stay fp32 in both modes. */
+int ds2_set_precision(int32_t mode);
+int ds2_get_precision(void);
+
 /* ---- measurement: HIP-event brackets (on the caller's stream) around named launch sites.  Tags:
  * "kernel.cross_attention", "kernel.self_attention", "stage.image_encoder", "stage.memory_attention",
  * "stage.sam_heads", "stage.memory_encoder".  ds2_profile_read waits for the recorded events, returns the
