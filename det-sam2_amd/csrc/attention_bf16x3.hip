@@ -1,0 +1,302 @@
+// Split-precision ("bf16x3") flash attention on the CDNA4 bf16 matrix cores, same structure as
+// attention.hip (transposed scores S^T = K Q^T so a lane owns one query column; P^T feeds the second
+// product straight from the accumulator registers), with every fp32 operand split into two bf16 planes
+//     x = x0 + x1,   product = a0*b0 + a0*b1 + a1*b0   (fp32 accumulate, ~2^-16 relative error),
+// i.e. three v_mfma_f32_32x32x16_bf16 where attention.hip issues eight v_mfma_f32_32x32x2_f32 (5.3x less
+// matrix-pipe time).  Splits happen once per element: Q when it is loaded into registers (pre-multiplied by
+// scale*log2e), K and V when their 32-key tile is staged into LDS, P in registers after the softmax.
+//
+// LDS images (bf16):  K planes [32 keys][D] with a 16-byte row pad -> every lane's operand is ONE
+// ds_read_b128 and the 16-lane read groups are conflict-free; V is stored TRANSPOSED [DV][32 keys] with the
+// keys permuted into the accumulator's own row order (mfma32_row), so the V^T operand of O^T = V^T P^T is
+// also one ds_read_b128 and P needs no cross-lane movement.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BQ = 128, BKEYS = 32, VROWB = 80;   // V^T row: 32 keys * 2 B + 16 B pad
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// split 8 floats into two packed bf16x8 planes
+__device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1) {
+  uint4 h, l;
+  h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);
+  h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);
+  l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
+  l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
+  l.z = cvt_pk_bf16(v[4] - bf_lo(h.z), v[5] - bf_hi(h.z));
+  l.w = cvt_pk_bf16(v[6] - bf_lo(h.w), v[7] - bf_hi(h.w));
+  p0 = __builtin_bit_cast(bf16x8, h);
+  p1 = __builtin_bit_cast(bf16x8, l);
+}
+
+struct RowMap {
+  int win, H, W, nwx, L;
+  __device__ __forceinline__ long row(int b, int i) const {
+    if (win == 0) return (long)b * L + i;
+    const int wy = b / nwx, wx = b - wy * nwx;
+    const int ly = i / win, lx = i - ly * win;
+    const int y = wy * win + ly, x = wx * win + lx;
+    return (y < H && x < W) ? (long)y * W + x : -1;
+  }
+};
+
+// position of key (0..31) inside a V^T row so that the 8 k-slots of MFMA k-step s read by half-wave h
+// (keys mfma32_row(8s+j, h), j = 0..7) are contiguous: pos = 16s + 8h + j.
+__device__ __forceinline__ int vt_pos(int key) {
+  const int h = (key >> 2) & 1, r = (key & 3) + 4 * (key >> 3);
+  return 16 * (r >> 3) + 8 * h + (r & 7);
+}
+
+template <int D, int DV>
+__global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
+  static_assert(D % 16 == 0 && DV % 32 == 0, "pad head dims");
+  constexpr int KS = D / 16, NT = DV / 32;
+  constexpr int KROWB = D * 2 + 16;                    // bytes per K row per plane
+  constexpr int KPLANE = BKEYS * KROWB, VPLANE = DV * VROWB;
+  constexpr int NK4 = (8 * D + 255) / 256, NV4 = (8 * DV + 255) / 256;
+  static_assert(2 * KPLANE >= 32 * (D + 1) * 4, "Q staging must fit in one K buffer");
+  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0i = blockIdx.x * BQ;
+  const RowMap qm{a.win_q, a.Hq, a.Wq, a.nwx, a.Lq};
+  const RowMap km{a.win_k, a.Hk, a.Wk, a.nwx, a.Lk};
+  const float sc = a.scale * 1.44269504088896340736f;
+
+  // ---- Q: stage fp32 rows through LDS, scale, split into two bf16 planes held in registers (B operand)
+  bf16x8 q0[KS], q1[KS];
+  {
+    float* Qs = reinterpret_cast<float*>(&Kp[0][0][0]);   // [32][D+1] floats
+    for (int w = 0; w < 4; ++w) {
+      for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+        const int r = idx / (D / 4), c4 = idx - r * (D / 4);
+        const int qi = q0i + w * 32 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qi < a.Lq) {
+          const long row = qm.row(b, qi);
+          if (row >= 0) v = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * D + c4 * 4);
+        }
+        float* dst = Qs + r * (D + 1) + c4 * 4;
+        dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
+      }
+      __syncthreads();
+      if (wave == w) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = Qs[l31 * (D + 1) + ks * 16 + half * 8 + j];
+          split8(v, q0[ks], q1[ks]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const bool wave_active = (q0i + wave * 32) < a.Lq;
+
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  float4 rk[NK4], rv[NV4];
+  auto load_k = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NK4; ++i) {
+      const int idx = tid + 256 * i;
+      rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < 8 * D) {
+        const int r = idx / (D / 4), c4 = idx - r * (D / 4);
+        const int ki = kt * BKEYS + r;
+        if (ki < a.Lk) {
+          const long row = km.row(b, ki);
+          const float* p = row >= 0 ? a.k + row * a.ldk + h * D : (a.k_pad ? a.k_pad + h * D : nullptr);
+          if (p) rk[i] = *reinterpret_cast<const float4*>(p + c4 * 4);
+        }
+      }
+    }
+  };
+  auto load_v = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const int idx = tid + 256 * i;
+      rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < 8 * DV) {
+        const int r = idx / (DV / 4), c4 = idx - r * (DV / 4);
+        const int ki = kt * BKEYS + r;
+        if (ki < a.Lk) {
+          const long row = km.row(b, ki);
+          const float* p = row >= 0 ? a.v + row * a.ldv + h * DV : (a.v_pad ? a.v_pad + h * DV : nullptr);
+          if (p) rv[i] = *reinterpret_cast<const float4*>(p + c4 * 4);
+        }
+      }
+    }
+  };
+  auto store_k = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NK4; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 8 * D) {
+        const int r = idx / (D / 4), c4 = idx - r * (D / 4);
+        uint2 hi, lo;
+        hi.x = cvt_pk_bf16(rk[i].x, rk[i].y);
+        hi.y = cvt_pk_bf16(rk[i].z, rk[i].w);
+        lo.x = cvt_pk_bf16(rk[i].x - bf_lo(hi.x), rk[i].y - bf_hi(hi.x));
+        lo.y = cvt_pk_bf16(rk[i].z - bf_lo(hi.y), rk[i].w - bf_hi(hi.y));
+        const int off = r * KROWB + c4 * 8;
+        *reinterpret_cast<uint2*>(&Kp[buf][0][off]) = hi;
+        *reinterpret_cast<uint2*>(&Kp[buf][1][off]) = lo;
+      }
+    }
+  };
+  auto store_v = [&](int buf) {   // transposed + key-permuted
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 8 * DV) {
+        const int r = idx / (DV / 4), c4 = idx - r * (DV / 4);
+        const int pos = vt_pos(r) * 2;
+        const float v[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned hi = cvt_pk_bf16(v[j], 0.f);
+          const unsigned lo = cvt_pk_bf16(v[j] - bf_lo(hi), 0.f);
+          const int off = (c4 * 4 + j) * VROWB + pos;
+          *reinterpret_cast<unsigned short*>(&Vp[buf][0][off]) = (unsigned short)(hi & 0xffffu);
+          *reinterpret_cast<unsigned short*>(&Vp[buf][1][off]) = (unsigned short)(lo & 0xffffu);
+        }
+      }
+    }
+  };
+
+  const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
+  load_k(0);
+  store_k(0);
+  load_v(0);
+  store_v(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) load_k(kt + 1);
+    f32x16 acc;
+    bf16x8 pb0[2], pb1[2];
+    float alpha = 1.f;
+    if (wave_active) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      const unsigned char* k0p = &Kp[cur][0][l31 * KROWB + half * 16];
+      const unsigned char* k1p = &Kp[cur][1][l31 * KROWB + half * 16];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(k0p + ks * 32);
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(k1p + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0[ks], acc, 0, 0, 0);
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt * BKEYS + mfma32_row(e, half);
+        acc[e] = key < a.Lk ? acc[e] : -INFINITY;    // scores already carry scale*log2e (folded into Q)
+        tmax = fmaxf(tmax, acc[e]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+      float p[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        p[e] = exp2f(acc[e] - m_new);
+        psum += p[e];
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      split8(p, pb0[0], pb1[0]);
+      split8(p + 8, pb0[1], pb1[1]);
+    }
+    if (kt + 1 < nkt) {
+      store_k(cur ^ 1);
+      load_v(kt + 1);
+    }
+    if (wave_active) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+        const unsigned char* v0p = &Vp[cur][0][(t * 32 + l31) * VROWB + half * 16];
+        const unsigned char* v1p = &Vp[cur][1][(t * 32 + l31) * VROWB + half * 16];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(v0p + s * 32);
+          const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(v1p + s * 32);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb0[s], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb1[s], o[t], 0, 0, 0);
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0[s], o[t], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nkt) store_v(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (!wave_active) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qi = q0i + wave * 32 + l31;
+  if (qi >= a.Lq) return;
+  const long orow = qm.row(b, qi);
+  if (orow < 0) return;
+  float* op = a.o + orow * a.ldo + h * DV;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) op[t * 32 + mfma32_row(e, half)] = o[t][e] * inv;
+}
+
+template <int D, int DV>
+int launch_t(const AttnArgs& a, hipStream_t st) {
+  dim3 grid(cdiv(a.Lq, BQ), a.heads, a.batch);
+  hipLaunchKernelGGL((k_attention_bf16x3<D, DV>), grid, dim3(256), 0, st, a);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
+}  // namespace
+
+// Returns DS2_ERR_UNSUPPORTED (without setting an error) for head dims that have no bf16x3 kernel yet;
+// the caller then uses the exact-fp32 kernel.
+int launch_attention_bf16x3(const AttnArgs& a, hipStream_t st) {
+  DS2_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
+  if (a.D == 256 && a.DV == 64 && a.heads == 1) return launch_t<256, 64>(a, st);
+  if (a.D == 256 && a.DV == 256 && a.heads == 1) {
+    // DV = 256 does not fit the register file next to the 128 Q registers: four DV=64 column passes
+    // (scores recomputed per pass; self-attention is 1/7 of the cross-attention work).
+    for (int c = 0; c < 4; ++c) {
+      AttnArgs p = a;
+      p.DV = 64;
+      p.v = a.v + c * 64;
+      p.o = a.o + c * 64;
+      int rc = launch_t<256, 64>(p, st);
+      if (rc != DS2_OK) return rc;
+    }
+    return DS2_OK;
+  }
+  return DS2_ERR_UNSUPPORTED;
+}

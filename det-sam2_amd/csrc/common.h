@@ -85,4 +85,5 @@ struct AttnArgs {
   int Hq, Wq, Hk, Wk, nwx;
   const float *k_pad, *v_pad;   // row used for padded key positions (the qkv bias), may be null
 };
-int launch_attention(const AttnArgs& a, hipStream_t st);
+int launch_attention(const AttnArgs& a, hipStream_t st);         // dispatches on g_ds2_precision
+int launch_attention_bf16x3(const AttnArgs& a, hipStream_t st);  // DS2_ERR_UNSUPPORTED if no kernel for (D,DV)

@@ -59,3 +59,10 @@ int launch_bank_ptr(const BankArgs& a, const float* dim_t /*[128]*/, hipStream_t
 // outputs
 int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits /*nullable*/,
                        uint8_t* packed /*nullable*/, hipStream_t st);
+
+// pre-split bf16x3 attention fast path (attention_split.hip)
+int launch_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
+                      void* hi, void* lo, hipStream_t st);   // rows [batch*L] x 256 cols -> bf16 planes [batch*L][256]
+int launch_vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st);  // 64 cols -> [B][tile][2][64][32]
+int launch_attention_split(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
+                           int batch, int Lq, int Lk, float scale, hipStream_t st);

@@ -490,7 +490,11 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_attention", st);
   const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + (4u << 20);
+  const bool split = g_ds2_precision == DS2_PREC_BF16X3;
+  const int nt_c = (Nk + 31) / 32, nt_s = TOK / 32;
+  const size_t split_bytes = split ? ((size_t)B * Nk * 256 * 4 + (size_t)B * nt_c * 8192 + (size_t)rows * 256 * 4 +
+                                      (size_t)4 * B * nt_s * 8192 + (1u << 20)) : 0;
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + (4u << 20);
   TRY(m->require(need, st));
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
@@ -503,6 +507,16 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
   ALLOC(kin, (size_t)B * Nk * 64);
   ALLOC(K, (size_t)B * Nk * 256);
   ALLOC(h, (size_t)rows * F);
+  // bf16x3 mode: attention operands are split into bf16 planes once by their producers (attention_split.hip)
+  void *khi = nullptr, *klo = nullptr, *vt_c = nullptr, *khi_s = nullptr, *klo_s = nullptr, *vt_s = nullptr;
+  if (split) {
+    khi = m->alloc_bytes((size_t)B * Nk * 512); klo = m->alloc_bytes((size_t)B * Nk * 512);
+    vt_c = m->alloc_bytes((size_t)B * nt_c * 8192);
+    khi_s = m->alloc_bytes((size_t)rows * 512); klo_s = m->alloc_bytes((size_t)rows * 512);
+    vt_s = m->alloc_bytes((size_t)4 * B * nt_s * 8192);
+    if (!khi || !klo || !vt_c || !khi_s || !klo_s || !vt_s) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
+    TRY(launch_vt_split(memory, 64, B, Nk, vt_c, st));   // V = raw memory (64-d), shared by the 4 layers
+  }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
   TRY(launch_add_bcast(curr, 256, m->P("#vision_pos"), 256, 0, 0.1f, x1, 256, TOK, 256, st));
   // k input of the cross attention: memory + memory_pos (pos_enc_at_cross_attn_keys, memory_attention.py:79)
@@ -517,12 +531,23 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f));
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768));
     TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
-    TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
-    AttnArgs sa{};
-    sa.q = qkv; sa.k = qkv + 256; sa.v = qkv + 512; sa.o = a;
-    sa.ldq = sa.ldk = sa.ldv = 768; sa.ldo = 256;
-    sa.batch = Bs; sa.heads = 1; sa.D = 256; sa.DV = 256; sa.Lq = sa.Lk = TOK; sa.scale = sc;
-    { ProfScope _p("kernel.self_attention", st); TRY(launch_attention(sa, st)); }
+    if (split) {
+      TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_s, st));
+      for (int c = 0; c < 4; ++c)
+        TRY(launch_vt_split(qkv + 512 + c * 64, 768, Bs, TOK, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, st));
+      ProfScope _p("kernel.self_attention", st);
+      for (int c = 0; c < 4; ++c)   // DV=256 as four 64-column passes (scores recomputed; 1/7 of the cross-attention work)
+        TRY(launch_attention_split(qkv, 768, khi_s, klo_s, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, a + c * 64, 256, Bs, TOK,
+                                   TOK, sc, st));
+    } else {
+      TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
+      AttnArgs sa{};
+      sa.q = qkv; sa.k = qkv + 256; sa.v = qkv + 512; sa.o = a;
+      sa.ldq = sa.ldk = sa.ldv = 768; sa.ldo = 256;
+      sa.batch = Bs; sa.heads = 1; sa.D = 256; sa.DV = 256; sa.Lq = sa.Lk = TOK; sa.scale = sc;
+      ProfScope _p("kernel.self_attention", st);
+      TRY(launch_attention(sa, st));
+    }
     if (l == 0) {
       TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
       for (int b = 0; b < B; ++b)
@@ -536,12 +561,19 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
     TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
-    TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
-    AttnArgs ca{};
-    ca.q = q; ca.k = K; ca.v = memory; ca.o = a64;
-    ca.ldq = 256; ca.ldk = 256; ca.ldv = 64; ca.ldo = 64;
-    ca.batch = B; ca.heads = 1; ca.D = 256; ca.DV = 64; ca.Lq = TOK; ca.Lk = Nk; ca.scale = sc;
-    { ProfScope _p("kernel.cross_attention", st); TRY(launch_attention(ca, st)); }
+    if (split) {
+      TRY(launch_rope_split(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, khi, klo, st));
+      ProfScope _p("kernel.cross_attention", st);
+      TRY(launch_attention_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
+    } else {
+      TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
+      AttnArgs ca{};
+      ca.q = q; ca.k = K; ca.v = memory; ca.o = a64;
+      ca.ldq = 256; ca.ldk = 256; ca.ldv = 64; ca.ldo = 64;
+      ca.batch = B; ca.heads = 1; ca.D = 256; ca.DV = 64; ca.Lq = TOK; ca.Lk = Nk; ca.scale = sc;
+      ProfScope _p("kernel.cross_attention", st);
+      TRY(launch_attention(ca, st));
+    }
     TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256));
     TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     // -- FFN
