@@ -1,0 +1,199 @@
+// bf16x3 GEMM over PRE-SPLIT operands:  C[M,N] = epi( (A0+A1)[M,K] * (W0+W1)[N,K]^T )
+//
+// Same arithmetic as gemm_bf16x3.hip (a0*w0 + a0*w1 + a1*w0, fp32 accumulate) but the fp32 -> (hi,lo) bf16
+// split is NOT done in the tile loop: weights are split once per model (cached), activations once per tensor
+// (k_split_rows, or directly by the producing kernel).  The tile loop is then 8 unconditional 16-byte global
+// loads, 8 ds_write_b128, 16 ds_read_b128 and 24 v_mfma_f32_32x32x16_bf16 per wave - no conversion VALU.
+// The epilogue can emit fp32 and/or the split planes of the result (for a consumer GEMM).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BM = 128, BN = 128, BK = 32, ROWB = 80, PLANE = BM * ROWB;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// fp32 [rows, cols] (row stride ldx) -> bf16 planes [rows, ldp] (cols..ldp zero padded); one thread / 4 cols
+__global__ void k_split_rows(const float* x, int ldx, int rows, int cols, uint2* hi, uint2* lo, int ldp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = ldp / 4;
+  if (i >= (size_t)rows * q) return;
+  const int c4 = (int)(i % q);
+  const size_t r = i / q;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < cols) v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
+  uint2 h, l;
+  h.x = cvt_pk_bf16(v.x, v.y);
+  h.y = cvt_pk_bf16(v.z, v.w);
+  l.x = cvt_pk_bf16(v.x - bf_lo(h.x), v.y - bf_hi(h.x));
+  l.y = cvt_pk_bf16(v.z - bf_lo(h.y), v.w - bf_hi(h.y));
+  hi[i] = h;
+  lo[i] = l;
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, int nt) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][2][PLANE];   // [buf][A/B][hi/lo]
+
+  const int nwg = mt * nt;
+  const int orig = blockIdx.x;
+  const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  const int tile_m = wg / nt, tile_n = wg % nt;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // staging geometry: a plane tile is 128 rows x 4 uint4 (32 bf16); thread -> (row = tid>>2 (+64), part = tid&3)
+  const int srow = tid >> 2, spart = tid & 3;
+  int ma0 = m0 + srow, ma1 = m0 + srow + 64, nb0 = n0 + srow, nb1 = n0 + srow + 64;
+  ma0 = ma0 < g.M ? ma0 : g.M - 1;   // clamp: rows beyond M/N are computed but never stored
+  ma1 = ma1 < g.M ? ma1 : g.M - 1;
+  nb0 = nb0 < g.N ? nb0 : g.N - 1;
+  nb1 = nb1 < g.N ? nb1 : g.N - 1;
+  const uint4* pa0h = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma0 * g.lda) + spart;
+  const uint4* pa0l = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma0 * g.lda) + spart;
+  const uint4* pa1h = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma1 * g.lda) + spart;
+  const uint4* pa1l = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma1 * g.lda) + spart;
+  const uint4* pb0h = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb0 * g.ldw) + spart;
+  const uint4* pb0l = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb0 * g.ldw) + spart;
+  const uint4* pb1h = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb1 * g.ldw) + spart;
+  const uint4* pb1l = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb1 * g.ldw) + spart;
+  const int so0 = srow * ROWB + spart * 16, so1 = (srow + 64) * ROWB + spart * 16;
+
+  const int nk = g.Kp / BK;   // Kp (padded K) is a multiple of 32; pad columns are zero in both operands
+  // Two named staging register sets => global loads run TWO K-tiles ahead of the MFMAs (the loop is latency-,
+  // not bandwidth-bound with a single tile in flight).
+  uint4 xa0h, xa0l, xa1h, xa1l, xb0h, xb0l, xb1h, xb1l;
+  uint4 ya0h, ya0l, ya1h, ya1l, yb0h, yb0l, yb1h, yb1l;
+#define G_LOAD(P, kt)                                                                     \
+  {                                                                                       \
+    const int ko = (kt) * 4;                                                              \
+    P##a0h = pa0h[ko]; P##a0l = pa0l[ko]; P##a1h = pa1h[ko]; P##a1l = pa1l[ko];           \
+    P##b0h = pb0h[ko]; P##b0l = pb0l[ko]; P##b1h = pb1h[ko]; P##b1l = pb1l[ko];           \
+  }
+#define G_STORE(P, buf)                                                                   \
+  {                                                                                       \
+    *reinterpret_cast<uint4*>(&lds[buf][0][0][so0]) = P##a0h;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][0][1][so0]) = P##a0l;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][0][0][so1]) = P##a1h;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][0][1][so1]) = P##a1l;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][1][0][so0]) = P##b0h;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][1][1][so0]) = P##b0l;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][1][0][so1]) = P##b1h;                             \
+    *reinterpret_cast<uint4*>(&lds[buf][1][1][so1]) = P##b1l;                             \
+  }
+#define G_COMPUTE(cur)                                                                    \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                         \
+    const int koff = s * 32 + half * 16;                                                  \
+    bf16x8 fa0[2], fa1[2], fb0[2], fb1[2];                                                \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                       \
+      const int ar = (wm * 64 + t * 32 + l31) * ROWB + koff;                              \
+      const int br = (wn * 64 + t * 32 + l31) * ROWB + koff;                              \
+      fa0[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][0][ar]);                     \
+      fa1[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][1][ar]);                     \
+      fb0[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][0][br]);                     \
+      fb1[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][1][br]);                     \
+    }                                                                                     \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
+      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                  \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[tm], fb0[tn], acc[tm][tn], 0, 0, 0); \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb1[tn], acc[tm][tn], 0, 0, 0); \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb0[tn], acc[tm][tn], 0, 0, 0); \
+      }                                                                                   \
+  }
+
+  // prologue: tile 0 -> LDS[0]; tile 1 -> set x.  All loads/stores in the steady state are UNCONDITIONAL (tile
+  // index clamped to nk-1): a branch around a load makes the compiler's s_waitcnt placement conservative
+  // (vmcnt(0) before the first ds_write), which serialises the two-deep prefetch.
+  const int last = nk - 1;
+  G_LOAD(x, 0)
+  G_STORE(x, 0)
+  G_LOAD(x, (1 < last ? 1 : last))
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {   // LDS[0] holds tile kt, set x holds tile kt+1
+    G_LOAD(y, (kt + 2 < last ? kt + 2 : last))
+    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch issue ABOVE the MFMAs (the scheduler sinks it otherwise)
+    G_COMPUTE(0)
+    G_STORE(x, 1)
+    __syncthreads();
+    G_LOAD(x, (kt + 3 < last ? kt + 3 : last))
+    __builtin_amdgcn_sched_barrier(0);
+    G_COMPUTE(1)
+    G_STORE(y, 0)
+    __syncthreads();
+  }
+  if (kt < nk) G_COMPUTE(0)   // odd tail: tile nk-1 sits in LDS[0]
+
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = n0 + wn * 64 + tn * 32 + l31;
+    const bool n_ok = n < g.N;
+    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+    const float gam = (g.gamma && n_ok) ? g.gamma[n] : 1.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + tm * 32 + mfma32_row(e, half);
+        float v = ds2_act(acc[tm][tn][e] + bias, g.act) * gam;
+        if (g.R && n_ok && m < g.M) {
+          const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
+          v += g.R[(size_t)rm * g.ldr + n];
+        }
+        if (g.C && n_ok && m < g.M) g.C[(size_t)m * g.ldc + n] = v;
+        if (g.C_hi) {   // split planes of the result: neighbouring lanes hold neighbouring columns -> pack pairs
+          const float vn = __shfl_down(v, 1);
+          if ((l31 & 1) == 0 && m < g.M && n < g.ldcp) {
+            const float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
+            const unsigned h = cvt_pk_bf16(x0, x1);
+            const unsigned l = cvt_pk_bf16(x0 - bf_lo(h), x1 - bf_hi(h));
+            *reinterpret_cast<unsigned*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
+            *reinterpret_cast<unsigned*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st) {
+  DS2_REQUIRE(ldp % 32 == 0 && ldx % 4 == 0 && cols % 4 == 0, "split_rows: ldp must be a multiple of 32, ldx/cols of 4");
+  const size_t n = (size_t)rows * (ldp / 4);
+  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, rows, cols,
+                     reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), ldp);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
+int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
+  DS2_REQUIRE(g.M > 0 && g.N > 0 && g.Kp > 0 && g.Kp % 32 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.lda >= g.Kp && g.ldw >= g.Kp,
+              "gemm_split: bad dims M=%d N=%d Kp=%d lda=%d ldw=%d", g.M, g.N, g.Kp, g.lda, g.ldw);
+  DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
+  DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
+  const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
+  hipLaunchKernelGGL(k_gemm_split, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}

@@ -66,3 +66,16 @@ int launch_rope_split(const float* x, int ldx, const float* cis, int batch, int 
 int launch_vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st);  // 64 cols -> [B][tile][2][64][32]
 int launch_attention_split(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                            int batch, int Lq, int Lk, float scale, hipStream_t st);
+
+// pre-split bf16x3 GEMM (gemm_split.hip)
+struct GemmSplitArgs {
+  int M, N, Kp;                                   // Kp = K rounded up to 32 (pad columns are zero)
+  const unsigned short *A_hi, *A_lo; int lda;     // bf16 planes [M, lda]   (lda in elements, multiple of 8)
+  const unsigned short *W_hi, *W_lo; int ldw;     // bf16 planes [N, ldw]
+  const float* bias;
+  float* C; int ldc;                              // fp32 result (may be null if only planes are wanted)
+  int act; const float* gamma; const float* R; int ldr; int r_mod;
+  unsigned short *C_hi, *C_lo; int ldcp;          // optional split planes of the result [M, ldcp] (pad cols zeroed)
+};
+int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
+int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);

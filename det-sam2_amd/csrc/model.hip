@@ -153,21 +153,74 @@ struct ds2_model {
     return DS2_ERR_STATE;                                                       \
   }
 
+// ---- bf16x3 operand planes: weights are split once and cached (model-owned pointers only); activations are
+// split per call into a process-wide scratch buffer (until their producers emit planes directly).
+namespace {
+struct Planes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
+std::unordered_map<const float*, Planes> g_wcache;
+char* g_scratch = nullptr;
+size_t g_scratch_cap = 0;
+int scratch_require(size_t bytes, hipStream_t st) {
+  if (bytes <= g_scratch_cap) return DS2_OK;
+  DS2_CHECK_HIP(hipStreamSynchronize(st));
+  if (g_scratch) DS2_CHECK_HIP(hipFree(g_scratch));
+  g_scratch = nullptr; g_scratch_cap = 0;
+  const size_t want = bytes + bytes / 4 + (16u << 20);
+  DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_scratch), want));
+  g_scratch_cap = want;
+  return DS2_OK;
+}
+inline int round32(int k) { return (k + 31) / 32 * 32; }
+}  // namespace
+
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
-                const float* gamma = nullptr) {
+                const float* gamma = nullptr, bool w_static = false) {
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
   }
-  GemmArgs g{M, N, K, A, lda, W, ldw, bias, C, ldc, act, gamma, R, ldr, r_mod};
-  return g_ds2_precision == DS2_PREC_BF16X3 ? launch_gemm_bf16x3(g, st) : launch_gemm(g, st);
+  if (g_ds2_precision != DS2_PREC_BF16X3) {
+    GemmArgs g{M, N, K, A, lda, W, ldw, bias, C, ldc, act, gamma, R, ldr, r_mod};
+    return launch_gemm(g, st);
+  }
+  DS2_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
+  const int Kp = round32(K);
+  const size_t a_bytes = (size_t)M * Kp * 2, w_bytes = (size_t)N * Kp * 2;
+  Planes wp;
+  auto it = w_static ? g_wcache.find(W) : g_wcache.end();
+  if (it != g_wcache.end()) {
+    wp = it->second;
+    TRY(scratch_require(2 * a_bytes + 512, st));
+  } else if (w_static) {
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.hi), w_bytes));
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), w_bytes));
+    wp.ld = Kp;
+    TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
+    g_wcache[W] = wp;
+    TRY(scratch_require(2 * a_bytes + 512, st));
+  } else {
+    TRY(scratch_require(2 * a_bytes + 2 * w_bytes + 1024, st));
+    wp.hi = reinterpret_cast<unsigned short*>(g_scratch + ((2 * a_bytes + 255) & ~(size_t)255));
+    wp.lo = wp.hi + (size_t)N * Kp;
+    wp.ld = Kp;
+    TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
+  }
+  unsigned short* ahi = reinterpret_cast<unsigned short*>(g_scratch);
+  unsigned short* alo = ahi + (size_t)M * Kp;
+  TRY(launch_split_rows(A, lda, M, K, ahi, alo, Kp, st));
+  GemmSplitArgs g{};
+  g.M = M; g.N = N; g.Kp = Kp;
+  g.A_hi = ahi; g.A_lo = alo; g.lda = Kp;
+  g.W_hi = wp.hi; g.W_lo = wp.lo; g.ldw = wp.ld;
+  g.bias = bias; g.C = C; g.ldc = ldc; g.act = act; g.gamma = gamma; g.R = R; g.ldr = ldr; g.r_mod = r_mod;
+  return launch_gemm_split(g, st);
 }
 // Linear layer by state_dict prefix: y = act(x W^T + b) (+ R)
 static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int N, int K, const float* A, int lda,
                   float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
                   const float* gamma = nullptr) {
-  return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma);
+  return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma, true);
 }
 static int layernorm(ds2_model* m, hipStream_t st, const std::string& p, const float* x, float* y, int rows, int C, float eps,
                      int act = DS2_ACT_NONE) {
@@ -206,8 +259,11 @@ extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
 
 extern "C" void ds2_model_destroy(ds2_model* m) {
   if (!m) return;
-  for (auto& kv : m->params)
+  for (auto& kv : m->params) {
+    auto it = g_wcache.find(reinterpret_cast<const float*>(kv.second.ptr));
+    if (it != g_wcache.end()) { (void)hipFree(it->second.hi); (void)hipFree(it->second.lo); g_wcache.erase(it); }
     if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  }
   if (m->ws) (void)hipFree(m->ws);
   delete m;
 }
@@ -366,7 +422,7 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
   TRY(launch_im2col_patch(frame_f16, col, 1024, st));
   ALLOC(x0, (size_t)65536 * C0);
   TRY(gemm(st, 65536, C0, 148, col, 148, m->P("@patch_w"), 148, m->P("image_encoder.trunk.patch_embed.proj.bias"), x0, C0,
-           DS2_ACT_NONE, m->P("#pos_embed"), C0));
+           DS2_ACT_NONE, m->P("#pos_embed"), C0, 0, nullptr, true));
   const float* x = x0;
   int side = 256;
   const float* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -529,7 +585,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     const int Bs = (l == 0) ? 1 : B;
     const float* xin = (l == 0) ? x1 : x;
     TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f));
-    TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768));
+    TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
     TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
     if (split) {
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_s, st));
@@ -710,11 +766,11 @@ extern "C" int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int
   TRY(layernorm(m, st, tr + ".norm_final_attn", tmpq, hs, BT, 256, 1e-5f));
   // upscaling + hypernetworks (mask_decoder.py:216-235)
   float* g1 = tmpk;  // [rows,256]
-  TRY(gemm(st, rows, 256, 256, keys, 256, m->P("@up1_w"), 256, m->P("@up1_b"), g1, 256));
+  TRY(gemm(st, rows, 256, 256, keys, 256, m->P("@up1_w"), 256, m->P("@up1_b"), g1, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
   ALLOC(u1, (size_t)B * 16384 * 64);
   TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st));
   ALLOC(g2, (size_t)B * 16384 * 128);
-  TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128));
+  TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
   ALLOC(hyper, (size_t)B * 128);
   for (int i = 0; i < 4; ++i)
     TRY(mlp3(m, st, md + ".output_hypernetworks_mlps." + std::to_string(i), B, hs + (2 + i) * 256, T * 256, 256, 32,
@@ -756,13 +812,13 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   ALLOC(col3, (size_t)B * 16384 * 144);
   TRY(launch_im2col3x3s2(c2, col3, B, 256, 16, st));
   ALLOC(g3, (size_t)B * 16384 * 64);
-  TRY(gemm(st, B * 16384, 64, 144, col3, 144, m->P("@mds6_w"), 144, m->P(ds + "6.bias"), g3, 64));
+  TRY(gemm(st, B * 16384, 64, 144, col3, 144, m->P("@mds6_w"), 144, m->P(ds + "6.bias"), g3, 64, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
   ALLOC(c3, (size_t)B * 16384 * 64);
   TRY(layernorm(m, st, ds + "7", g3, c3, B * 16384, 64, 1e-6f, DS2_ACT_GELU));
   ALLOC(col4, (size_t)rows * 576);
   TRY(launch_im2col3x3s2(c3, col4, B, 128, 64, st));
   ALLOC(g4, (size_t)rows * 256);
-  TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256));
+  TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
   ALLOC(c4, (size_t)rows * 256);
   TRY(layernorm(m, st, ds + "10", g4, c4, rows, 256, 1e-6f, DS2_ACT_GELU));
   // x = pix_feat_proj(pix_feat) + mask_downsampler(masks)   (memory_encoder.py:172-175); pix_feat is shared by all objects
