@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PREFILL = 15  # tracked frames needed before the 7-frame bank + 16 pointers are in steady state
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md dense MFMA peaks: fp32 (v_mfma_f32_32x32x2_f32) and bf16 (v_mfma_f32_*_bf16)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
 
 
 def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
@@ -81,6 +82,7 @@ def main():
     ap.add_argument("--model", default="sam2.1_hiera_l")
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"])
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -102,6 +104,7 @@ def main():
     cfg = resolve_config(a.model)
     B, K, W = a.objects, a.steps, a.warmup
     pred = SAM2VideoPredictor(cfg, synthetic_state_dict(cfg, 0), dev, max_batch=B)
+    pred.hip.set_precision(a.precision)
     n_frames = 1 + PREFILL + W + K
     seed = 1000 * rank   # every rank (= its own pass shard) sees different frames
     frames = torch.from_numpy(np.stack([synthetic_frame(t, seed) for t in range(n_frames)])).to(dev)
@@ -151,15 +154,19 @@ def main():
             "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == "fp32" else "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
+            "data": "synthetic",
             "config": {"workload": f"{cfg.name} propagate_in_video, {B} objects, 1024x1024 uniform-noise frames, "
                                    f"7-frame memory bank + 16 object pointers (Nk={nk}), synthetic checkpoint seed 0, "
                                    f"encoder run on every tracked frame, packed masks copied to host",
                        "objects": B, "Nk": nk, "frames_per_rank": K, "parallelism": f"pass-sharded dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "k_attention<256,64> (memory cross-attention, 1 launch/layer)",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n},
+            "roofline": {"bound": "mfma",
+                         "kernel": "memory cross-attention (k_attention_w8 in bf16x3 mode, k_attention<256,64> in fp32 mode), 1 launch/layer",
+                         "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                         "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision], "traffic": None,
+                         "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
+                         "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time; "
+                                 "bf16x3 executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3 by construction"},
             "ms_per_step_by_stage": stage_ms,
         }
         if world == 1 and not a.no_cpu_baseline:

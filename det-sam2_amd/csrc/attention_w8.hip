@@ -1,0 +1,229 @@
+// Memory-attention kernel, 8-wave variant: bf16x3 flash attention over pre-split operands on
+// v_mfma_f32_16x16x32_bf16.
+//
+// attention_split.hip keeps 32 queries per wave (128 VGPRs of Q planes): one wave per SIMD, no registers left
+// to prefetch LDS operands, softmax VALU and MFMA strictly alternate.  Here a wave owns 16 queries (64 VGPRs of
+// Q planes), a block is 8 waves = 128 queries, so every SIMD hosts TWO waves whose MFMA and VALU phases
+// overlap in hardware, and the compiler has ~100 free VGPRs to run LDS reads ahead of the MFMAs.
+//
+// Same dataflow otherwise: transposed scores S^T = K Q^T (lane = one query column, 4 keys per 16x16 block),
+// online softmax with per-lane statistics (two __shfl_xor to share the row max across the four lane groups),
+// P^T fed to O^T = V^T P^T straight from the accumulators, V^T stored key-permuted so its operand is one
+// ds_read_b128.  Operands arrive pre-split (k_rope_split, k_vt_split16).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int D = 256, DV = 64, BQ = 128, BKEYS = 32;
+constexpr int KROWB = D * 2 + 16, KPLANE = BKEYS * KROWB;
+constexpr int VROWB = 80, VPLANE = DV * VROWB;
+constexpr int KS = D / 32;   // 8 k-steps of 32
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                       bf16x8& p0, bf16x8& p1) {
+  uint4 h, l;
+  h.x = cvt_pk_bf16(v0, v1); h.y = cvt_pk_bf16(v2, v3);
+  h.z = cvt_pk_bf16(v4, v5); h.w = cvt_pk_bf16(v6, v7);
+  l.x = cvt_pk_bf16(v0 - bf_lo(h.x), v1 - bf_hi(h.x));
+  l.y = cvt_pk_bf16(v2 - bf_lo(h.y), v3 - bf_hi(h.y));
+  l.z = cvt_pk_bf16(v4 - bf_lo(h.z), v5 - bf_hi(h.z));
+  l.w = cvt_pk_bf16(v6 - bf_lo(h.w), v7 - bf_hi(h.w));
+  p0 = __builtin_bit_cast(bf16x8, h);
+  p1 = __builtin_bit_cast(bf16x8, l);
+}
+// key (0..31) -> position in a V^T row for the 16x16x32 P.V product: lane group g = (key>>2)&3 holds keys
+// {4g+r} of key-block 0 and {16+4g+r} of key-block 1 in its accumulators; its 8 k-slots are pos 8g..8g+7.
+__device__ __forceinline__ int vt_pos16(int key) { return 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4); }
+
+__global__ void k_vt_split16(const float* v, int ldv, int batch, int L, unsigned short* vt) {
+  const int ntile = (L + 31) / 32;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)batch * ntile * 2048) return;
+  const int dv = (int)(i & 63), key = (int)((i >> 6) & 31);
+  const size_t bt = i >> 11;
+  const int tile = (int)(bt % ntile), b = (int)(bt / ntile);
+  const int ki = tile * 32 + key;
+  const float x = ki < L ? v[((size_t)b * L + ki) * ldv + dv] : 0.f;
+  const unsigned h = cvt_pk_bf16(x, 0.f);
+  const unsigned l = cvt_pk_bf16(x - bf_lo(h), 0.f);
+  unsigned short* base = vt + bt * 2 * 2048;
+  const int off = dv * 32 + vt_pos16(key);
+  base[off] = (unsigned short)(h & 0xffffu);
+  base[2048 + off] = (unsigned short)(l & 0xffffu);
+}
+
+struct W8Args {
+  const float* q; int ldq;
+  const uint4* k_hi; const uint4* k_lo;
+  const uint4* vt;
+  float* o; int ldo;
+  int batch, Lq, Lk;
+  float scale;
+};
+
+__global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, grp = lane >> 4;
+  const int nqb = a.Lq / BQ, nblk = a.batch * nqb;
+  int bid = blockIdx.x;
+  if (nblk % 8 == 0) bid = (bid % 8) * (nblk / 8) + bid / 8;   // whole objects per XCD (shared K/V stay in one L2)
+  const int b = bid / nqb, q0i = (bid % nqb) * BQ;
+  const float sc = a.scale * 1.44269504088896340736f;
+
+  // ---- Q: 4 rounds of 32 rows through LDS (fp32, scaled); waves 2r, 2r+1 pick up their 16 rows in round r
+  bf16x8 q0[KS], q1[KS];
+  {
+    float* Qs = reinterpret_cast<float*>(&Kp[0][0][0]);   // [32][D+1]
+    for (int r4 = 0; r4 < 4; ++r4) {
+      for (int idx = tid; idx < 32 * (D / 4); idx += 512) {
+        const int r = idx / (D / 4), c4 = idx - r * (D / 4);
+        const float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
+        float* dst = Qs + r * (D + 1) + c4 * 4;
+        dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
+      }
+      __syncthreads();
+      if ((wave >> 1) == r4) {
+        const float* qrow = Qs + ((wave & 1) * 16 + l15) * (D + 1) + grp * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float* qr = qrow + ks * 32;
+          split8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7], q0[ks], q1[ks]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  f32x4 o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
+  // staging: K planes = 2 x (32 rows x 32 uint4); thread handles uint4 #(tid + 512 i), i = 0..3; V^T planes =
+  // 2 x (64 rows x 4 uint4), one uint4 per thread
+  const int kpart = tid & 31, krow = (tid >> 5) & 15;         // rows krow and krow+16 of each plane
+  const int vplane = tid >> 8, vrow = (tid & 255) >> 2, vpart = tid & 3;
+  const size_t kbase = (size_t)b * a.Lk;
+  const uint4* vbase = a.vt + (size_t)b * nkt * 512;
+  const int kso0 = krow * KROWB + kpart * 16, kso1 = (krow + 16) * KROWB + kpart * 16;
+  const int vso = vrow * VROWB + vpart * 16;
+
+  uint4 rk0, rk1, rk2, rk3, rv;
+#define W8_LOAD(KT)                                                           \
+  {                                                                           \
+    const int kt_ = (KT);                                                     \
+    int k0_ = kt_ * BKEYS + krow, k1_ = k0_ + 16;                             \
+    k0_ = k0_ < a.Lk ? k0_ : a.Lk - 1;                                        \
+    k1_ = k1_ < a.Lk ? k1_ : a.Lk - 1;                                        \
+    rk0 = a.k_hi[(kbase + k0_) * 32 + kpart];                                 \
+    rk1 = a.k_hi[(kbase + k1_) * 32 + kpart];                                 \
+    rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                                 \
+    rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                                 \
+    rv = vbase[(size_t)kt_ * 512 + tid];                                      \
+  }
+#define W8_STORE(BUF)                                                         \
+  {                                                                           \
+    *reinterpret_cast<uint4*>(&Kp[BUF][0][kso0]) = rk0;                       \
+    *reinterpret_cast<uint4*>(&Kp[BUF][0][kso1]) = rk1;                       \
+    *reinterpret_cast<uint4*>(&Kp[BUF][1][kso0]) = rk2;                       \
+    *reinterpret_cast<uint4*>(&Kp[BUF][1][kso1]) = rk3;                       \
+    *reinterpret_cast<uint4*>(&Vp[BUF][vplane][vso]) = rv;                    \
+  }
+
+  W8_LOAD(0)
+  W8_STORE(0)
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    W8_LOAD(kt + 1 < nkt ? kt + 1 : kt)
+    // ---- S^T = K Q^T for the two 16-key blocks of the tile
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* kp0 = &Kp[cur][0][l15 * KROWB + grp * 16];
+    const unsigned char* kp1 = &Kp[cur][1][l15 * KROWB + grp * 16];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + ks * 64);
+      const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + ks * 64);
+      const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + ks * 64);
+      const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[ks], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q1[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[ks], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q0[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q0[ks], s1, 0, 0, 0);
+    }
+    if (kt == nkt - 1) {   // keys >= Lk only exist in the last tile; lane holds keys 4*grp + r (+16)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (kt * BKEYS + 4 * grp + r >= a.Lk) s0[r] = -INFINITY;
+        if (kt * BKEYS + 16 + 4 * grp + r >= a.Lk) s1[r] = -INFINITY;
+      }
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = exp2f(m_run - m_new);
+    const float p0 = exp2f(s0[0] - m_new), p1 = exp2f(s0[1] - m_new), p2 = exp2f(s0[2] - m_new), p3 = exp2f(s0[3] - m_new);
+    const float p4 = exp2f(s1[0] - m_new), p5 = exp2f(s1[1] - m_new), p6 = exp2f(s1[2] - m_new), p7 = exp2f(s1[3] - m_new);
+    l_run = l_run * alpha + (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)));
+    m_run = m_new;
+    bf16x8 pb0, pb1;
+    split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0, pb1);
+    // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      o[t] *= alpha;
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0, o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1, o[t], 0, 0, 0);
+      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0, o[t], 0, 0, 0);
+    }
+    W8_STORE(cur ^ 1)
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float l_tot = l_run + __shfl_xor(l_run, 16);
+  l_tot += __shfl_xor(l_tot, 32);
+  const float inv = 1.f / l_tot;
+  float* op = a.o + ((size_t)b * a.Lq + q0i + wave * 16 + l15) * a.ldo + 4 * grp;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+}
+
+}  // namespace
+
+int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
+  const size_t n = (size_t)batch * ((L + 31) / 32) * 2048;
+  hipLaunchKernelGGL(k_vt_split16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
+                     reinterpret_cast<unsigned short*>(vt));
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
+int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
+                        int batch, int Lq, int Lk, float scale, hipStream_t st) {
+  DS2_REQUIRE(Lq % BQ == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0, "attention_w8: Lq must be a multiple of 128");
+  W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
+           reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale};
+  hipLaunchKernelGGL(k_attention_w8, dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}

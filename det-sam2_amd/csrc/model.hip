@@ -3,6 +3,7 @@
 // (gemm.hip, attention.hip, kernels.hip) into the reference's stages.  Host code only launches
 // kernels on the caller's stream - no host<->device synchronisation on the hot path.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -156,6 +157,20 @@ struct ds2_model {
 // ---- bf16x3 operand planes: weights are split once and cached (model-owned pointers only); activations are
 // split per call into a process-wide scratch buffer (until their producers emit planes directly).
 namespace {
+// memory-attention kernel selection (A/B switch for experiments): DS2_ATTN_KERNEL=split selects the 4-wave
+// 32x32x16 kernel, anything else the 8-wave 16x16x32 kernel.
+bool use_w8() {
+  static const bool v = [] { const char* e = getenv("DS2_ATTN_KERNEL"); return !(e && strcmp(e, "split") == 0); }();
+  return v;
+}
+int vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
+  return use_w8() ? launch_vt_split16(v, ldv, batch, L, vt, st) : launch_vt_split(v, ldv, batch, L, vt, st);
+}
+int attn_split(const float* q, int ldq, const void* khi, const void* klo, const void* vt, float* o, int ldo, int batch,
+               int Lq, int Lk, float scale, hipStream_t st) {
+  return use_w8() ? launch_attention_w8(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, st)
+                  : launch_attention_split(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, st);
+}
 struct Planes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
 std::unordered_map<const float*, Planes> g_wcache;
 char* g_scratch = nullptr;
@@ -571,7 +586,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     khi_s = m->alloc_bytes((size_t)rows * 512); klo_s = m->alloc_bytes((size_t)rows * 512);
     vt_s = m->alloc_bytes((size_t)4 * B * nt_s * 8192);
     if (!khi || !klo || !vt_c || !khi_s || !klo_s || !vt_s) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
-    TRY(launch_vt_split(memory, 64, B, Nk, vt_c, st));   // V = raw memory (64-d), shared by the 4 layers
+    TRY(vt_split(memory, 64, B, Nk, vt_c, st));   // V = raw memory (64-d), shared by the 4 layers
   }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
   TRY(launch_add_bcast(curr, 256, m->P("#vision_pos"), 256, 0, 0.1f, x1, 256, TOK, 256, st));
@@ -590,11 +605,10 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     if (split) {
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_s, st));
       for (int c = 0; c < 4; ++c)
-        TRY(launch_vt_split(qkv + 512 + c * 64, 768, Bs, TOK, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, st));
+        TRY(vt_split(qkv + 512 + c * 64, 768, Bs, TOK, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, st));
       ProfScope _p("kernel.self_attention", st);
       for (int c = 0; c < 4; ++c)   // DV=256 as four 64-column passes (scores recomputed; 1/7 of the cross-attention work)
-        TRY(launch_attention_split(qkv, 768, khi_s, klo_s, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, a + c * 64, 256, Bs, TOK,
-                                   TOK, sc, st));
+        TRY(attn_split(qkv, 768, khi_s, klo_s, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, a + c * 64, 256, Bs, TOK, TOK, sc, st));
     } else {
       TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
       AttnArgs sa{};
@@ -620,7 +634,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     if (split) {
       TRY(launch_rope_split(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, khi, klo, st));
       ProfScope _p("kernel.cross_attention", st);
-      TRY(launch_attention_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
+      TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
     } else {
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
       AttnArgs ca{};
