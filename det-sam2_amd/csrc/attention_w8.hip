@@ -16,9 +16,9 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int D = 256, DV = 64, BQ = 128, BKEYS = 32;
+constexpr int D = 256, BQ = 128, BKEYS = 32;
 constexpr int KROWB = D * 2 + 16, KPLANE = BKEYS * KROWB;
-constexpr int VROWB = 80, VPLANE = DV * VROWB;
+constexpr int VROWB = 80;
 constexpr int KS = D / 32;   // 8 k-steps of 32
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
@@ -44,21 +44,23 @@ __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, f
 // {4g+r} of key-block 0 and {16+4g+r} of key-block 1 in its accumulators; its 8 k-slots are pos 8g..8g+7.
 __device__ __forceinline__ int vt_pos16(int key) { return 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4); }
 
+// vt[b][tile][plane][dv 0..DVT-1][pos 0..31]
+template <int DVT>
 __global__ void k_vt_split16(const float* v, int ldv, int batch, int L, unsigned short* vt) {
   const int ntile = (L + 31) / 32;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)batch * ntile * 2048) return;
-  const int dv = (int)(i & 63), key = (int)((i >> 6) & 31);
-  const size_t bt = i >> 11;
+  if (i >= (size_t)batch * ntile * 32 * DVT) return;
+  const int dv = (int)(i % DVT), key = (int)((i / DVT) & 31);
+  const size_t bt = i / (32 * DVT);
   const int tile = (int)(bt % ntile), b = (int)(bt / ntile);
   const int ki = tile * 32 + key;
   const float x = ki < L ? v[((size_t)b * L + ki) * ldv + dv] : 0.f;
   const unsigned h = cvt_pk_bf16(x, 0.f);
   const unsigned l = cvt_pk_bf16(x - bf_lo(h), 0.f);
-  unsigned short* base = vt + bt * 2 * 2048;
+  unsigned short* base = vt + bt * 2 * (32 * DVT);
   const int off = dv * 32 + vt_pos16(key);
   base[off] = (unsigned short)(h & 0xffffu);
-  base[2048 + off] = (unsigned short)(l & 0xffffu);
+  base[32 * DVT + off] = (unsigned short)(l & 0xffffu);
 }
 
 struct W8Args {
@@ -70,7 +72,9 @@ struct W8Args {
   float scale;
 };
 
+template <int DV>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
+  constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
   __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
 
@@ -106,22 +110,21 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }
   }
 
-  f32x4 o[4];
+  f32x4 o[NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
   const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
   // staging: K planes = 2 x (32 rows x 32 uint4); thread handles uint4 #(tid + 512 i), i = 0..3; V^T planes =
   // 2 x (64 rows x 4 uint4), one uint4 per thread
   const int kpart = tid & 31, krow = (tid >> 5) & 15;         // rows krow and krow+16 of each plane
-  const int vplane = tid >> 8, vrow = (tid & 255) >> 2, vpart = tid & 3;
+  // V^T tile = 2 planes x DV rows x 4 uint4 = 8*DV uint4; thread loads uint4 #(tid + 512 j), j < DV/64
   const size_t kbase = (size_t)b * a.Lk;
-  const uint4* vbase = a.vt + (size_t)b * nkt * 512;
+  const uint4* vbase = a.vt + (size_t)b * nkt * (8 * DV);
   const int kso0 = krow * KROWB + kpart * 16, kso1 = (krow + 16) * KROWB + kpart * 16;
-  const int vso = vrow * VROWB + vpart * 16;
 
-  uint4 rk0, rk1, rk2, rk3, rv;
+  uint4 rk0, rk1, rk2, rk3, rv[NVLD];
 #define W8_LOAD(KT)                                                           \
   {                                                                           \
     const int kt_ = (KT);                                                     \
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     rk1 = a.k_hi[(kbase + k1_) * 32 + kpart];                                 \
     rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                                 \
     rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                                 \
-    rv = vbase[(size_t)kt_ * 512 + tid];                                      \
+    _Pragma("unroll") for (int j = 0; j < NVLD; ++j) rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; \
   }
 #define W8_STORE(BUF)                                                         \
   {                                                                           \
@@ -140,7 +143,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso1]) = rk1;                       \
     *reinterpret_cast<uint4*>(&Kp[BUF][1][kso0]) = rk2;                       \
     *reinterpret_cast<uint4*>(&Kp[BUF][1][kso1]) = rk3;                       \
-    *reinterpret_cast<uint4*>(&Vp[BUF][vplane][vso]) = rv;                    \
+    _Pragma("unroll") for (int j = 0; j < NVLD; ++j) {                        \
+      const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
+      const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
+      *reinterpret_cast<uint4*>(&Vp[BUF][pl_][rw_ * VROWB + pt_ * 16]) = rv[j]; \
+    }                                                                         \
   }
 
   W8_LOAD(0)
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0, pb1);
     // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
       o[t] *= alpha;
       const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
       const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
@@ -204,26 +211,35 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   const float inv = 1.f / l_tot;
   float* op = a.o + ((size_t)b * a.Lq + q0i + wave * 16 + l15) * a.ldo + 4 * grp;
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
     *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
 }
 
 }  // namespace
 
-int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
-  const size_t n = (size_t)batch * ((L + 31) / 32) * 2048;
-  hipLaunchKernelGGL(k_vt_split16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
-                     reinterpret_cast<unsigned short*>(vt));
+int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st) {
+  DS2_REQUIRE(dv == 64 || dv == 128, "vt_split16: dv must be 64 or 128");
+  const size_t n = (size_t)batch * ((L + 31) / 32) * 32 * dv;
+  if (dv == 64)
+    hipLaunchKernelGGL((k_vt_split16<64>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
+                       reinterpret_cast<unsigned short*>(vt));
+  else
+    hipLaunchKernelGGL((k_vt_split16<128>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
+                       reinterpret_cast<unsigned short*>(vt));
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
-                        int batch, int Lq, int Lk, float scale, hipStream_t st) {
-  DS2_REQUIRE(Lq % BQ == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0, "attention_w8: Lq must be a multiple of 128");
+                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st) {
+  DS2_REQUIRE(Lq % BQ == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128),
+              "attention_w8: Lq must be a multiple of 128, dv 64 or 128");
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale};
-  hipLaunchKernelGGL(k_attention_w8, dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
+  if (dv == 64)
+    hipLaunchKernelGGL((k_attention_w8<64>), dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_attention_w8<128>), dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

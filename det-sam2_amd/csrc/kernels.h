@@ -81,6 +81,6 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);
 
 // 8-wave variant on v_mfma_f32_16x16x32_bf16 (attention_w8.hip); V^T tiles use a different key permutation
-int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st);
+int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st);   // dv = 64 | 128
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
-                        int batch, int Lq, int Lk, float scale, hipStream_t st);
+                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st);

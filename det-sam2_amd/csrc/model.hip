@@ -164,11 +164,11 @@ bool use_w8() {
   return v;
 }
 int vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
-  return use_w8() ? launch_vt_split16(v, ldv, batch, L, vt, st) : launch_vt_split(v, ldv, batch, L, vt, st);
+  return use_w8() ? launch_vt_split16(v, ldv, batch, L, vt, 64, st) : launch_vt_split(v, ldv, batch, L, vt, st);
 }
 int attn_split(const float* q, int ldq, const void* khi, const void* klo, const void* vt, float* o, int ldo, int batch,
                int Lq, int Lk, float scale, hipStream_t st) {
-  return use_w8() ? launch_attention_w8(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, st)
+  return use_w8() ? launch_attention_w8(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, 64, st)
                   : launch_attention_split(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, st);
 }
 struct Planes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
@@ -604,11 +604,20 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
     if (split) {
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_s, st));
-      for (int c = 0; c < 4; ++c)
-        TRY(vt_split(qkv + 512 + c * 64, 768, Bs, TOK, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, st));
       ProfScope _p("kernel.self_attention", st);
-      for (int c = 0; c < 4; ++c)   // DV=256 as four 64-column passes (scores recomputed; 1/7 of the cross-attention work)
-        TRY(attn_split(qkv, 768, khi_s, klo_s, (char*)vt_s + (size_t)c * Bs * nt_s * 8192, a + c * 64, 256, Bs, TOK, TOK, sc, st));
+      if (use_w8()) {   // DV=256 as two 128-column passes (scores recomputed once)
+        for (int c = 0; c < 2; ++c) {
+          void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 16384;
+          TRY(launch_vt_split16(qkv + 512 + c * 128, 768, Bs, TOK, vt, 128, st));
+          TRY(launch_attention_w8(qkv, 768, khi_s, klo_s, vt, a + c * 128, 256, Bs, TOK, TOK, sc, 128, st));
+        }
+      } else {          // four 64-column passes
+        for (int c = 0; c < 4; ++c) {
+          void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 8192;
+          TRY(launch_vt_split(qkv + 512 + c * 64, 768, Bs, TOK, vt, st));
+          TRY(launch_attention_split(qkv, 768, khi_s, klo_s, vt, a + c * 64, 256, Bs, TOK, TOK, sc, st));
+        }
+      }
     } else {
       TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
       AttnArgs sa{};
