@@ -57,16 +57,22 @@ __device__ __forceinline__ int vt_pos(int key) {
   return 16 * (r >> 3) + 8 * h + (r & 7);
 }
 
+// D / DV are the true head dims (multiples of 4); the MFMA shapes need DP = D rounded up to 16 and DVP = DV
+// rounded up to 32: the pad columns/rows of the LDS images are zeroed once and never written again.
 template <int D, int DV>
 __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
-  static_assert(D % 16 == 0 && DV % 32 == 0, "pad head dims");
-  constexpr int KS = D / 16, NT = DV / 32;
-  constexpr int KROWB = D * 2 + 16;                    // bytes per K row per plane
-  constexpr int KPLANE = BKEYS * KROWB, VPLANE = DV * VROWB;
+  static_assert(D % 4 == 0 && DV % 4 == 0, "head dims must be multiples of 4");
+  constexpr int DP = (D + 15) / 16 * 16, DVP = (DV + 31) / 32 * 32;
+  constexpr int KS = DP / 16, NT = DVP / 32;
+  constexpr int KROWB = DP * 2 + 16;                   // bytes per K row per plane
+  constexpr int KPLANE = BKEYS * KROWB, VPLANE = DVP * VROWB;
   constexpr int NK4 = (8 * D + 255) / 256, NV4 = (8 * DV + 255) / 256;
-  static_assert(2 * KPLANE >= 32 * (D + 1) * 4, "Q staging must fit in one K buffer");
-  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
+  constexpr int QSLD = DP + 1;                          // fp32 Q staging row stride
+  constexpr int QBYTES = 32 * QSLD * 4;
+  constexpr int KBUF = 2 * KPLANE > QBYTES ? 2 * KPLANE : QBYTES;   // one K buffer doubles as the Q staging area
+  __shared__ __attribute__((aligned(16))) unsigned char Kraw[2][KBUF];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
+#define Kp(buf, plane, off) Kraw[buf][(plane) * KPLANE + (off)]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -78,7 +84,9 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   // ---- Q: stage fp32 rows through LDS, scale, split into two bf16 planes held in registers (B operand)
   bf16x8 q0[KS], q1[KS];
   {
-    float* Qs = reinterpret_cast<float*>(&Kp[0][0][0]);   // [32][D+1] floats
+    float* Qs = reinterpret_cast<float*>(&Kraw[0][0]);   // [32][DP+1] floats
+    for (int idx = tid; idx < 32 * QSLD; idx += 256) Qs[idx] = 0.f;   // pad columns D..DP stay zero
+    __syncthreads();
     for (int w = 0; w < 4; ++w) {
       for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
           const long row = qm.row(b, qi);
           if (row >= 0) v = *reinterpret_cast<const float4*>(a.q + row * a.ldq + h * D + c4 * 4);
         }
-        float* dst = Qs + r * (D + 1) + c4 * 4;
+        float* dst = Qs + r * QSLD + c4 * 4;
         dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
       }
       __syncthreads();
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
         for (int ks = 0; ks < KS; ++ks) {
           float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = Qs[l31 * (D + 1) + ks * 16 + half * 8 + j];
+          for (int j = 0; j < 8; ++j) v[j] = Qs[l31 * QSLD + ks * 16 + half * 8 + j];
           split8(v, q0[ks], q1[ks]);
         }
       }
@@ -158,8 +166,8 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
         lo.x = cvt_pk_bf16(rk[i].x - bf_lo(hi.x), rk[i].y - bf_hi(hi.x));
         lo.y = cvt_pk_bf16(rk[i].z - bf_lo(hi.y), rk[i].w - bf_hi(hi.y));
         const int off = r * KROWB + c4 * 8;
-        *reinterpret_cast<uint2*>(&Kp[buf][0][off]) = hi;
-        *reinterpret_cast<uint2*>(&Kp[buf][1][off]) = lo;
+        *reinterpret_cast<uint2*>(&Kp(buf, 0, off)) = hi;
+        *reinterpret_cast<uint2*>(&Kp(buf, 1, off)) = lo;
       }
     }
   };
@@ -183,6 +191,10 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
     }
   };
 
+  // zero the LDS images once: pad columns (D..DP of K rows) and pad rows (DV..DVP of V^T) are never written
+  for (int idx = tid; idx < 2 * KBUF / 4; idx += 256) reinterpret_cast<unsigned*>(&Kraw[0][0])[idx] = 0u;
+  for (int idx = tid; idx < 4 * VPLANE / 4; idx += 256) reinterpret_cast<unsigned*>(&Vp[0][0][0])[idx] = 0u;
+  __syncthreads();
   const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
   load_k(0);
   store_k(0);
@@ -198,8 +210,8 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
     if (wave_active) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-      const unsigned char* k0p = &Kp[cur][0][l31 * KROWB + half * 16];
-      const unsigned char* k1p = &Kp[cur][1][l31 * KROWB + half * 16];
+      const unsigned char* k0p = &Kp(cur, 0, l31 * KROWB + half * 16);
+      const unsigned char* k1p = &Kp(cur, 1, l31 * KROWB + half * 16);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(k0p + ks * 32);
@@ -267,7 +279,11 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) op[t * 32 + mfma32_row(e, half)] = o[t][e] * inv;
+    for (int e = 0; e < 16; ++e) {
+      const int dv = t * 32 + mfma32_row(e, half);
+      if (dv < DV) op[dv] = o[t][e] * inv;
+    }
+#undef Kp
 }
 
 template <int D, int DV>
@@ -285,6 +301,10 @@ int launch_t(const AttnArgs& a, hipStream_t st) {
 int launch_attention_bf16x3(const AttnArgs& a, hipStream_t st) {
   DS2_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
   if (a.D == 256 && a.DV == 64 && a.heads == 1) return launch_t<256, 64>(a, st);
+#define DS2_CASE(d) \
+  if (a.D == d && a.DV == d) return launch_t<d, d>(a, st);
+  DS2_CASE(96) DS2_CASE(72) DS2_CASE(56) DS2_CASE(32) DS2_CASE(16)
+#undef DS2_CASE
   if (a.D == 256 && a.DV == 256 && a.heads == 1) {
     // DV = 256 does not fit the register file next to the 128 Q registers: four DV=64 column passes
     // (scores recomputed per pass; self-attention is 1/7 of the cross-attention work).
