@@ -275,14 +275,33 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   if (qi >= a.Lq) return;
   const long orow = qm.row(b, qi);
   if (orow < 0) return;
-  float* op = a.o + orow * a.ldo + h * DV;
+  if (a.o_hi) {   // registers 4k..4k+3 of a fragment are 4 consecutive output columns
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int dv = t * 32 + mfma32_row(e, half);
-      if (dv < DV) op[dv] = o[t][e] * inv;
-    }
+      for (int k = 0; k < 4; ++k) {
+        const int dv = t * 32 + 8 * k + 4 * half;
+        if (dv < DV) {
+          const float v0 = o[t][4 * k] * inv, v1 = o[t][4 * k + 1] * inv, v2 = o[t][4 * k + 2] * inv, v3 = o[t][4 * k + 3] * inv;
+          uint2 hh, ll;
+          hh.x = cvt_pk_bf16(v0, v1);
+          hh.y = cvt_pk_bf16(v2, v3);
+          ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
+          ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+          *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + h * DV + dv) = hh;
+          *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + h * DV + dv) = ll;
+        }
+      }
+  } else {
+    float* op = a.o + orow * a.ldo + h * DV;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int dv = t * 32 + mfma32_row(e, half);
+        if (dv < DV) op[dv] = o[t][e] * inv;
+      }
+  }
 #undef Kp
 }
 

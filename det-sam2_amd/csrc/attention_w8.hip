@@ -70,6 +70,7 @@ struct W8Args {
   float* o; int ldo;
   int batch, Lq, Lk;
   float scale;
+  unsigned short *o_hi, *o_lo; int ldop;   // optional: emit the result as bf16 planes (consumer is a GEMM)
 };
 
 template <int DV>
@@ -209,10 +210,25 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   float l_tot = l_run + __shfl_xor(l_run, 16);
   l_tot += __shfl_xor(l_tot, 32);
   const float inv = 1.f / l_tot;
-  float* op = a.o + ((size_t)b * a.Lq + q0i + wave * 16 + l15) * a.ldo + 4 * grp;
+  const size_t orow = (size_t)b * a.Lq + q0i + wave * 16 + l15;
+  if (a.o_hi) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-    *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+    for (int t = 0; t < NT; ++t) {
+      const float v0 = o[t][0] * inv, v1 = o[t][1] * inv, v2 = o[t][2] * inv, v3 = o[t][3] * inv;
+      uint2 h, l;
+      h.x = cvt_pk_bf16(v0, v1);
+      h.y = cvt_pk_bf16(v2, v3);
+      l.x = cvt_pk_bf16(v0 - bf_lo(h.x), v1 - bf_hi(h.x));
+      l.y = cvt_pk_bf16(v2 - bf_lo(h.y), v3 - bf_hi(h.y));
+      *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + 16 * t + 4 * grp) = h;
+      *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + 16 * t + 4 * grp) = l;
+    }
+  } else {
+    float* op = a.o + orow * a.ldo + 4 * grp;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+  }
 }
 
 }  // namespace
@@ -231,11 +247,13 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 }
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
-                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st) {
+                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop) {
   DS2_REQUIRE(Lq % BQ == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128),
               "attention_w8: Lq must be a multiple of 128, dv 64 or 128");
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
-           reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale};
+           reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
+           reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop};
+  DS2_REQUIRE(o || o_hi, "attention_w8: no output");
   if (dv == 64)
     hipLaunchKernelGGL((k_attention_w8<64>), dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
   else

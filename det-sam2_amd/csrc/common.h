@@ -84,6 +84,9 @@ struct AttnArgs {
   int win_q, win_k;             // 0 = plain [batch, L] rows
   int Hq, Wq, Hk, Wk, nwx;
   const float *k_pad, *v_pad;   // row used for padded key positions (the qkv bias), may be null
+  // bf16x3 kernels only: if set, the result is written as two bf16 planes [rows, ldop] (GEMM operand format)
+  // instead of fp32 `o`
+  unsigned short *o_hi, *o_lo; int ldop;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);         // dispatches on g_ds2_precision
 int launch_attention_bf16x3(const AttnArgs& a, hipStream_t st);  // DS2_ERR_UNSUPPORTED if no kernel for (D,DV)

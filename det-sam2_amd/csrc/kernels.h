@@ -83,4 +83,11 @@ int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, voi
 // 8-wave variant on v_mfma_f32_16x16x32_bf16 (attention_w8.hip); V^T tiles use a different key permutation
 int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st);   // dv = 64 | 128
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
-                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st);
+                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi = nullptr,
+                        void* o_lo = nullptr, int ldop = 0);   // o_hi/o_lo: emit bf16 planes [rows, ldop] instead of fp32
+
+// producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)
+int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
+                           int C, float eps, int act, hipStream_t st);
+int launch_add_bcast_split(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, void* hi, void* lo,
+                           int ldp, int rows, int C, hipStream_t st);

@@ -42,6 +42,62 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   for (int c = lane; c < C; c += 64) yr[c] = ds2_act((xr[c] - mean) * rstd * w[c] + b[c], act);
 }
 
+// LayerNorm whose consumer is a bf16x3 GEMM: emits the two bf16 planes of the result (x = hi + lo) instead of
+// fp32 (gemm_split.hip operand format; columns C..ldp are zero).  hi/lo are viewed as packed pairs.
+__device__ __forceinline__ unsigned ln_cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__global__ __launch_bounds__(256) void k_layernorm_split(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                         const float* __restrict__ b, unsigned* __restrict__ hi,
+                                                         unsigned* __restrict__ lo, int ldp, int rows, int C, float eps,
+                                                         int act) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; v += d * d; }
+  const float rstd = 1.f / sqrtf(wave_sum(v) / (float)C + eps);
+  unsigned* hr = hi + (size_t)row * (ldp / 2);
+  unsigned* lr = lo + (size_t)row * (ldp / 2);
+  for (int c2 = lane; c2 < ldp / 2; c2 += 64) {
+    const int c = 2 * c2;
+    const float y0 = c < C ? ds2_act((xr[c] - mean) * rstd * w[c] + b[c], act) : 0.f;
+    const float y1 = c + 1 < C ? ds2_act((xr[c + 1] - mean) * rstd * w[c + 1] + b[c + 1], act) : 0.f;
+    const unsigned h = ln_cvt_pk_bf16(y0, y1);
+    hr[c2] = h;
+    lr[c2] = ln_cvt_pk_bf16(y0 - __uint_as_float(h << 16), y1 - __uint_as_float(h & 0xffff0000u));
+  }
+}
+
+// out = a + alpha*b (row-broadcast b) emitted directly as bf16 planes (cross-attention key input memory + pos)
+__global__ void k_add_bcast_split(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, uint2* hi,
+                                  uint2* lo, int ldp, int rows, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = ldp / 4;
+  if (i >= (size_t)rows * q) return;
+  const int c4 = (int)(i % q);
+  const size_t r = i / q;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < C) {
+    const size_t rb = b_mod > 0 ? r % b_mod : r;
+    const float4 x = *reinterpret_cast<const float4*>(a + r * lda + c4 * 4);
+    const float4 y = *reinterpret_cast<const float4*>(b + rb * ldb + c4 * 4);
+    v = make_float4(x.x + alpha * y.x, x.y + alpha * y.y, x.z + alpha * y.z, x.w + alpha * y.w);
+  }
+  uint2 h, l;
+  h.x = ln_cvt_pk_bf16(v.x, v.y);
+  h.y = ln_cvt_pk_bf16(v.z, v.w);
+  l.x = ln_cvt_pk_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+  l.y = ln_cvt_pk_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+  hi[i] = h;
+  lo[i] = l;
+}
+
 // ------------------------------------------------------------------ simple elementwise
 __global__ void k_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, float* out,
                             int ldo, int rows, int C) {
@@ -501,6 +557,22 @@ int launch_layernorm(const float* x, int ldx, const float* w, const float* b, fl
                      float eps, int act, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && C > 0, "layernorm: bad dims");
   hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, w, b, y, ldy, rows, C, eps, act);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
+                           int C, float eps, int act, hipStream_t st) {
+  DS2_REQUIRE(rows > 0 && C > 0 && ldp % 32 == 0 && ldp >= C, "layernorm_split: bad dims");
+  hipLaunchKernelGGL(k_layernorm_split, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, w, b, reinterpret_cast<unsigned*>(hi),
+                     reinterpret_cast<unsigned*>(lo), ldp, rows, C, eps, act);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_add_bcast_split(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, void* hi, void* lo,
+                           int ldp, int rows, int C, hipStream_t st) {
+  DS2_REQUIRE(ldp % 32 == 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "add_bcast_split: bad dims");
+  hipLaunchKernelGGL(k_add_bcast_split, grid1((size_t)rows * (ldp / 4)), dim3(256), 0, st, a, lda, b, ldb, b_mod, alpha,
+                     reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), ldp, rows, C);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

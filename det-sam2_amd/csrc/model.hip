@@ -97,6 +97,15 @@ struct ds2_model {
   char* ws = nullptr;
   size_t ws_cap = 0, ws_top = 0;
   std::string missing;  // first missing parameter seen by P()
+  // bf16x3 operand planes of activations living in the arena, keyed by the fp32 buffer they stand for
+  // (producers that emit planes directly register them here; gemm() looks its A operand up)
+  struct ActPlanes { unsigned short *hi, *lo; int ld; };
+  std::unordered_map<const void*, ActPlanes> act_planes;
+  void release(size_t mark) {   // rewind the arena and forget planes of buffers above the mark
+    for (auto it = act_planes.begin(); it != act_planes.end();)
+      it = (reinterpret_cast<const char*>(it->first) >= ws + mark) ? act_planes.erase(it) : std::next(it);
+    ws_top = mark;
+  }
 
   const float* P(const std::string& name) {
     auto it = params.find(name);
@@ -120,6 +129,7 @@ struct ds2_model {
   }
   int require(size_t bytes, hipStream_t st) {   // (re)size the arena; only syncs when it has to grow
     ws_top = 0;
+    act_planes.clear();
     if (bytes <= ws_cap) return DS2_OK;
     DS2_CHECK_HIP(hipStreamSynchronize(st));
     if (ws) DS2_CHECK_HIP(hipFree(ws));
@@ -188,9 +198,29 @@ int scratch_require(size_t bytes, hipStream_t st) {
 inline int round32(int k) { return (k + 31) / 32 * 32; }
 }  // namespace
 
+static int round32i(int k) { return (k + 31) / 32 * 32; }
+// allocate + register the planes that stand for fp32 buffer `key` ([rows, cols]); pad columns are zeroed
+static int new_act_planes(ds2_model* m, const void* key, int rows, int cols, ds2_model::ActPlanes* out, hipStream_t st) {
+  const int ld = round32i(cols);
+  const size_t bytes = (size_t)rows * ld * 2;
+  out->hi = reinterpret_cast<unsigned short*>(m->alloc_bytes(bytes));
+  out->lo = reinterpret_cast<unsigned short*>(m->alloc_bytes(bytes));
+  out->ld = ld;
+  if (!out->hi || !out->lo) { ds2_set_error("workspace exhausted allocating activation planes"); return DS2_ERR_STATE; }
+  if (ld != cols) {   // producers only write the real columns
+    DS2_CHECK_HIP(hipMemsetAsync(out->hi, 0, bytes, st));
+    DS2_CHECK_HIP(hipMemsetAsync(out->lo, 0, bytes, st));
+  }
+  m->act_planes[key] = *out;
+  return DS2_OK;
+}
+
+// C = act(A W^T + bias) * gamma + R.   bf16x3 mode: A is taken from registered planes when its producer emitted
+// them (else split by a pre-pass); with planes_out the result is emitted as planes registered under key C and
+// the fp32 buffer C is NOT written (its only consumers must be GEMMs).
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
-                const float* gamma = nullptr, bool w_static = false) {
+                const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false) {
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
@@ -201,7 +231,14 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   }
   DS2_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
   const int Kp = round32(K);
-  const size_t a_bytes = (size_t)M * Kp * 2, w_bytes = (size_t)N * Kp * 2;
+  const size_t w_bytes = (size_t)N * Kp * 2;
+  const unsigned short *ahi = nullptr, *alo = nullptr;
+  int a_ld = Kp;
+  if (m) {
+    auto ia = m->act_planes.find(A);
+    if (ia != m->act_planes.end() && ia->second.ld == Kp) { ahi = ia->second.hi; alo = ia->second.lo; }
+  }
+  const size_t a_bytes = ahi ? 0 : (size_t)M * Kp * 2;
   Planes wp;
   auto it = w_static ? g_wcache.find(W) : g_wcache.end();
   if (it != g_wcache.end()) {
@@ -221,27 +258,48 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     wp.ld = Kp;
     TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
   }
-  unsigned short* ahi = reinterpret_cast<unsigned short*>(g_scratch);
-  unsigned short* alo = ahi + (size_t)M * Kp;
-  TRY(launch_split_rows(A, lda, M, K, ahi, alo, Kp, st));
+  if (!ahi) {
+    unsigned short* sh = reinterpret_cast<unsigned short*>(g_scratch);
+    unsigned short* sl = sh + (size_t)M * Kp;
+    TRY(launch_split_rows(A, lda, M, K, sh, sl, Kp, st));
+    ahi = sh; alo = sl;
+  }
   GemmSplitArgs g{};
   g.M = M; g.N = N; g.Kp = Kp;
-  g.A_hi = ahi; g.A_lo = alo; g.lda = Kp;
+  g.A_hi = ahi; g.A_lo = alo; g.lda = a_ld;
   g.W_hi = wp.hi; g.W_lo = wp.lo; g.ldw = wp.ld;
   g.bias = bias; g.C = C; g.ldc = ldc; g.act = act; g.gamma = gamma; g.R = R; g.ldr = ldr; g.r_mod = r_mod;
+  if (planes_out && m) {
+    ds2_model::ActPlanes op;
+    TRY(new_act_planes(m, C, M, N, &op, st));
+    g.C = nullptr; g.C_hi = op.hi; g.C_lo = op.lo; g.ldcp = op.ld;
+  }
   return launch_gemm_split(g, st);
 }
 // Linear layer by state_dict prefix: y = act(x W^T + b) (+ R)
 static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int N, int K, const float* A, int lda,
                   float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
-                  const float* gamma = nullptr) {
-  return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma, true);
+                  const float* gamma = nullptr, bool planes_out = false) {
+  return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma, true, m,
+              planes_out);
 }
+// planes_out (bf16x3 mode only): the result is emitted as GEMM operand planes registered under key y; the fp32
+// buffer y is not written, so every consumer of y must be a gemm()/linear().
 static int layernorm(ds2_model* m, hipStream_t st, const std::string& p, const float* x, float* y, int rows, int C, float eps,
-                     int act = DS2_ACT_NONE) {
+                     int act = DS2_ACT_NONE, bool planes_out = false) {
   const float* w = m->P(p + ".weight");
   const float* b = m->P(p + ".bias");
   if (!w || !b) { ds2_set_error("missing parameter '%s'", p.c_str()); return DS2_ERR_STATE; }
+  if (planes_out && g_ds2_precision == DS2_PREC_BF16X3) {
+    ds2_model::ActPlanes op;
+    const int ld = round32i(C);
+    op.hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * ld * 2));
+    op.lo = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * ld * 2));
+    op.ld = ld;
+    if (!op.hi || !op.lo) { ds2_set_error("workspace exhausted (layernorm planes)"); return DS2_ERR_STATE; }
+    m->act_planes[y] = op;
+    return launch_layernorm_split(x, C, w, b, op.hi, op.lo, ld, rows, C, eps, act, st);
+  }
   return launch_layernorm(x, C, w, b, y, C, rows, C, eps, act, st);
 }
 
@@ -424,7 +482,8 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
     for (const BlockCfg& b : m->blocks) {
       const size_t hw = (size_t)side * side, hwq = b.q_stride ? hw / 4 : hw;
       outs += hwq * b.dim_out * 4 + 256;
-      const size_t tmp = (hw * b.dim + hw * b.dim_out * 2 + hw * 3 * b.dim_out + hwq * b.dim_out * 3 + hwq * 4 * b.dim_out) * 4 + 4096;
+      // fp32 temporaries + (bf16x3 mode) their operand planes, which take the same number of bytes
+      const size_t tmp = 2 * (hw * (b.dim + 32) + hw * b.dim_out * 2 + hw * 3 * b.dim_out + hwq * (b.dim_out + 32) * 3 + hwq * 4 * b.dim_out) * 4 + 65536;
       if (tmp > tmp_max) tmp_max = tmp;
       if (b.q_stride) side /= 2;
     }
@@ -451,7 +510,7 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
     ALLOC(xn, (size_t)hwq * b.dim_out);           // block output survives the temporaries below
     const size_t mark = m->ws_top;
     ALLOC(t, (size_t)hw * b.dim);
-    TRY(layernorm(m, st, p + ".norm1", x, t, hw, b.dim, 1e-6f));
+    TRY(layernorm(m, st, p + ".norm1", x, t, hw, b.dim, 1e-6f, DS2_ACT_NONE, true));   // consumers: proj / qkv GEMMs
     const float* sc = x;
     if (b.dim != b.dim_out) {                      // hieradet.py:141-142
       ALLOC(scf, (size_t)hw * b.dim_out);
@@ -492,14 +551,20 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
       aa.k_pad = qb ? qb + b.dim_out : nullptr;
       aa.v_pad = qb ? qb + 2 * b.dim_out : nullptr;
     }
+    if (g_ds2_precision == DS2_PREC_BF16X3) {   // attention output goes straight to the proj GEMM: emit planes
+      ds2_model::ActPlanes ap;
+      TRY(new_act_planes(m, a, hwq, b.dim_out, &ap, st));
+      aa.o_hi = ap.hi; aa.o_lo = ap.lo; aa.ldop = ap.ld;
+    }
     TRY(launch_attention(aa, st));
     TRY(linear(m, st, p + ".attn.proj", hwq, b.dim_out, b.dim_out, a, b.dim_out, xn, b.dim_out, DS2_ACT_NONE, sc, b.dim_out));
     ALLOC(t2, (size_t)hwq * b.dim_out);
-    TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f));
+    TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f, DS2_ACT_NONE, true));
     ALLOC(h, (size_t)hwq * 4 * b.dim_out);
-    TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU));
+    TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU,
+               nullptr, 0, 0, nullptr, true));   // hidden activations only feed mlp.layers.1: planes only
     TRY(linear(m, st, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, h, 4 * b.dim_out, xn, b.dim_out, DS2_ACT_NONE, xn, b.dim_out));
-    m->ws_top = mark;
+    m->release(mark);
     x = xn;
     side = side_q;
     for (int s = 0; s < 4; ++s)
@@ -565,7 +630,8 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
   const int nt_c = (Nk + 31) / 32, nt_s = TOK / 32;
   const size_t split_bytes = split ? ((size_t)B * Nk * 256 * 4 + (size_t)B * nt_c * 8192 + (size_t)rows * 256 * 4 +
                                       (size_t)4 * B * nt_s * 8192 + (1u << 20)) : 0;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + (4u << 20);
+  const size_t plane_bytes = split ? ((size_t)rows * (256 * 5 + 64 + F) + (size_t)B * Nk * 64) * 4 + (8u << 20) : 0;
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + (4u << 20);
   TRY(m->require(need, st));
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
@@ -591,25 +657,36 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
   TRY(launch_add_bcast(curr, 256, m->P("#vision_pos"), 256, 0, 0.1f, x1, 256, TOK, 256, st));
   // k input of the cross attention: memory + memory_pos (pos_enc_at_cross_attn_keys, memory_attention.py:79)
-  TRY(launch_add_bcast(memory, 64, memory_pos, 64, 0, 1.0f, kin, 64, B * Nk, 64, st));
+  if (split) {   // emitted directly as the k_proj GEMM's operand planes
+    ds2_model::ActPlanes kp;
+    TRY(new_act_planes(m, kin, B * Nk, 64, &kp, st));
+    TRY(launch_add_bcast_split(memory, 64, memory_pos, 64, 0, 1.0f, kp.hi, kp.lo, kp.ld, B * Nk, 64, st));
+  } else {
+    TRY(launch_add_bcast(memory, 64, memory_pos, 64, 0, 1.0f, kin, 64, B * Nk, 64, st));
+  }
   const float sc = 1.0f / 16.0f;  // 1/sqrt(256)
   for (int l = 0; l < m->cfg.mem_attn_layers; ++l) {
     const std::string p = "memory_attention.layers." + std::to_string(l);
     const std::string ls = std::to_string(l);
+    const size_t layer_mark = m->ws_top;   // operand planes emitted inside a layer die with it
+    m->act_planes.erase(a);
     // -- self attention (RoPE on q,k).  Layer 0 sees the same input for all B objects: computed once.
     const int Bs = (l == 0) ? 1 : B;
     const float* xin = (l == 0) ? x1 : x;
-    TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f));
-    TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
+    TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
+    TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
     TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
     if (split) {
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_s, st));
       ProfScope _p("kernel.self_attention", st);
+      ds2_model::ActPlanes sa_p{};
+      if (use_w8()) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
       if (use_w8()) {   // DV=256 as two 128-column passes (scores recomputed once)
         for (int c = 0; c < 2; ++c) {
           void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 16384;
           TRY(launch_vt_split16(qkv + 512 + c * 128, 768, Bs, TOK, vt, 128, st));
-          TRY(launch_attention_w8(qkv, 768, khi_s, klo_s, vt, a + c * 128, 256, Bs, TOK, TOK, sc, 128, st));
+          TRY(launch_attention_w8(qkv, 768, khi_s, klo_s, vt, nullptr, 256, Bs, TOK, TOK, sc, 128, st, sa_p.hi + c * 128,
+                                  sa_p.lo + c * 128, sa_p.ld));
         }
       } else {          // four 64-column passes
         for (int c = 0; c < 4; ++c) {
@@ -636,14 +713,21 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     }
     // -- cross attention to the memory bank.  V = v_proj(memory) is never materialised:
     //    softmax(QK^T) (M Wv^T + bv) = (softmax(QK^T) M) Wv^T + bv, so P.V runs in the 64-d memory space.
-    TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f));
+    m->act_planes.erase(a);   // self-attention planes are consumed; `a` is re-used below
+    TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
     TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
     if (split) {
       TRY(launch_rope_split(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, khi, klo, st));
       ProfScope _p("kernel.cross_attention", st);
-      TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
+      if (use_w8()) {
+        ds2_model::ActPlanes cp;
+        TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
+        TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld));
+      } else {
+        TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
+      }
     } else {
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
       AttnArgs ca{};
@@ -653,12 +737,14 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
       ProfScope _p("kernel.cross_attention", st);
       TRY(launch_attention(ca, st));
     }
-    TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256));
+    TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr,
+               true));   // only consumer: out_proj GEMM
     TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     // -- FFN
-    TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f));
-    TRY(linear(m, st, p + ".linear1", rows, F, 256, t, 256, h, F, DS2_ACT_RELU));
+    TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
+    TRY(linear(m, st, p + ".linear1", rows, F, 256, t, 256, h, F, DS2_ACT_RELU, nullptr, 0, 0, nullptr, true));
     TRY(linear(m, st, p + ".linear2", rows, 256, F, h, F, x, 256, DS2_ACT_NONE, x, 256));
+    m->release(layer_mark);
   }
   TRY(layernorm(m, st, "memory_attention.norm", x, out, rows, 256, 1e-5f));
   CHECK_PARAMS();
@@ -686,7 +772,7 @@ int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int
   a.scale = 1.0f / sqrtf((float)a.D);
   TRY(launch_attention(a, st));
   TRY(linear(m, st, p + ".out_proj", B * Lq, 256, internal, o, internal, out, 256, DS2_ACT_NONE, R, 256));
-  m->ws_top = mark;
+  m->release(mark);
   return DS2_OK;
 }
 int mlp3(ds2_model* m, hipStream_t st, const std::string& p, int M, const float* A, int lda, int hidden, int n_out, float* out,
@@ -697,7 +783,7 @@ int mlp3(ds2_model* m, hipStream_t st, const std::string& p, int M, const float*
   TRY(linear(m, st, p + ".layers.0", M, hidden, 256, A, lda, h1, hidden, DS2_ACT_RELU));
   TRY(linear(m, st, p + ".layers.1", M, hidden, hidden, h1, hidden, h2, hidden, DS2_ACT_RELU));
   TRY(linear(m, st, p + ".layers.2", M, n_out, hidden, h2, hidden, out, ldc, last_act));
-  m->ws_top = mark;
+  m->release(mark);
   return DS2_OK;
 }
 }  // namespace
@@ -820,7 +906,7 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_encoder", st);
   const int rows = B * TOK;
-  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (8u << 20);
+  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (size_t)rows * (256 * 3 + 1024 * 2) * 4 + (8u << 20);
   TRY(m->require(need, st));
   const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
   ALLOC(high, (size_t)B * 1048576);
@@ -843,7 +929,7 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   ALLOC(g4, (size_t)rows * 256);
   TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
   ALLOC(c4, (size_t)rows * 256);
-  TRY(layernorm(m, st, ds + "10", g4, c4, rows, 256, 1e-6f, DS2_ACT_GELU));
+  TRY(layernorm(m, st, ds + "10", g4, c4, rows, 256, 1e-6f, DS2_ACT_GELU, true));   // consumer: encoder.12 GEMM
   // x = pix_feat_proj(pix_feat) + mask_downsampler(masks)   (memory_encoder.py:172-175); pix_feat is shared by all objects
   ALLOC(pf, (size_t)TOK * 256);
   TRY(linear(m, st, me + ".pix_feat_proj", TOK, 256, 256, fpn2, 256, pf, 256));
@@ -856,8 +942,8 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   for (int l = 0; l < 2; ++l) {
     const std::string p = me + ".fuser.layers." + std::to_string(l);
     TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
-    TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f));
-    TRY(linear(m, st, p + ".pwconv1", rows, 1024, 256, t, 256, h, 1024, DS2_ACT_GELU));
+    TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
+    TRY(linear(m, st, p + ".pwconv1", rows, 1024, 256, t, 256, h, 1024, DS2_ACT_GELU, nullptr, 0, 0, nullptr, true));
     TRY(linear(m, st, p + ".pwconv2", rows, 256, 1024, h, 1024, x, 256, DS2_ACT_NONE, x, 256, 0, m->P(p + ".gamma")));
   }
   ALLOC(o, (size_t)rows * 64);
