@@ -5,6 +5,9 @@
 // (k_split_rows, or directly by the producing kernel).  The tile loop is then 8 unconditional 16-byte global
 // loads, 8 ds_write_b128, 16 ds_read_b128 and 24 v_mfma_f32_32x32x16_bf16 per wave - no conversion VALU.
 // The epilogue can emit fp32 and/or the split planes of the result (for a consumer GEMM).
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -39,6 +42,7 @@ __global__ void k_split_rows(const float* x, int ldx, int rows, int cols, uint2*
   lo[i] = l;
 }
 
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, int nt) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][2][PLANE];   // [buf][A/B][hi/lo]
 
@@ -131,15 +135,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
   __syncthreads();
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {   // LDS[0] holds tile kt, set x holds tile kt+1
-    G_LOAD(y, (kt + 2 < last ? kt + 2 : last))
+    if (!(DBG & 2)) G_LOAD(y, (kt + 2 < last ? kt + 2 : last))
     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch issue ABOVE the MFMAs (the scheduler sinks it otherwise)
-    G_COMPUTE(0)
-    G_STORE(x, 1)
+    if (!(DBG & 4)) G_COMPUTE(0)
+    if (!(DBG & 1)) G_STORE(x, 1)
     __syncthreads();
-    G_LOAD(x, (kt + 3 < last ? kt + 3 : last))
+    if (!(DBG & 2)) G_LOAD(x, (kt + 3 < last ? kt + 3 : last))
     __builtin_amdgcn_sched_barrier(0);
-    G_COMPUTE(1)
-    G_STORE(y, 0)
+    if (!(DBG & 4)) G_COMPUTE(1)
+    if (!(DBG & 1)) G_STORE(y, 0)
     __syncthreads();
   }
   if (kt < nk) G_COMPUTE(0)   // odd tail: tile nk-1 sits in LDS[0]
@@ -160,8 +164,144 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
           const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
           v += g.R[(size_t)rm * g.ldr + n];
         }
+        if (DBG & 8) { if (v == 1.2345e37f) g.C[0] = v; continue; }
         if (g.C && n_ok && m < g.M) g.C[(size_t)m * g.ldc + n] = v;
         if (g.C_hi) {   // split planes of the result: neighbouring lanes hold neighbouring columns -> pack pairs
+          const float vn = __shfl_down(v, 1);
+          if ((l31 & 1) == 0 && m < g.M && n < g.ldcp) {
+            const float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
+            const unsigned h = cvt_pk_bf16(x0, x1);
+            const unsigned l = cvt_pk_bf16(x0 - bf_lo(h), x1 - bf_hi(h));
+            *reinterpret_cast<unsigned*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
+            *reinterpret_cast<unsigned*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Same GEMM with direct-to-LDS staging (global_load_lds, 16 B per lane): no VGPR round trip and no ds_write.
+// (Ablation on MI355X: the MFMA + ds_read part of the kernel above sustains ~640 TF by itself; its global-load ->
+// VGPR -> ds_write_b128 staging, not the matrix pipe, sets the speed.)
+// An LDS-DMA writes wave-uniform base + lane*16, so the LDS image cannot be row-padded; plane tiles are plain
+// [128 rows][64 B] and bank conflicts are avoided with an XOR swizzle of the four 16-byte chunks of a row,
+// chunk' = chunk ^ ((row >> 2) & 3), applied to the SOURCE address of each lane and again on the operand reads.
+constexpr int GROWB = 64, GPLANE = BM * GROWB;   // 8 KiB per plane tile
+
+__global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmSplitArgs g, int mt, int nt) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2][2][2][GPLANE];   // [buf][A/B][hi/lo]
+
+  const int nwg = mt * nt;
+  const int orig = blockIdx.x;
+  const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  const int tile_m = wg / nt, tile_n = wg % nt;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // staging: wave w fills rows [32w, 32w+32) of each of the 4 plane tiles with two 1-KiB DMAs (16 rows each).
+  // lane -> (row = lane>>2, physical chunk = lane&3); it fetches logical chunk (lane&3) ^ ((row>>2)&3).
+  const int srow0 = wave * 32 + (lane >> 2), srow1 = srow0 + 16;
+  const int lc0 = (lane & 3) ^ ((srow0 >> 2) & 3), lc1 = (lane & 3) ^ ((srow1 >> 2) & 3);
+  int ma0 = m0 + srow0, ma1 = m0 + srow1, nb0 = n0 + srow0, nb1 = n0 + srow1;
+  ma0 = ma0 < g.M ? ma0 : g.M - 1;
+  ma1 = ma1 < g.M ? ma1 : g.M - 1;
+  nb0 = nb0 < g.N ? nb0 : g.N - 1;
+  nb1 = nb1 < g.N ? nb1 : g.N - 1;
+  const uint4* pa0h = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma0 * g.lda) + lc0;
+  const uint4* pa0l = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma0 * g.lda) + lc0;
+  const uint4* pa1h = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma1 * g.lda) + lc1;
+  const uint4* pa1l = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma1 * g.lda) + lc1;
+  const uint4* pb0h = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb0 * g.ldw) + lc0;
+  const uint4* pb0l = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb0 * g.ldw) + lc0;
+  const uint4* pb1h = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb1 * g.ldw) + lc1;
+  const uint4* pb1l = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb1 * g.ldw) + lc1;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+#define GL(src, BUF, OP, PL, ROWBASE) \
+  __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&lds[BUF][OP][PL][(ROWBASE) * GROWB]), 16, 0, 0);
+#define GL_TILE(kt, BUF)                                   \
+  {                                                         \
+    const int ko = (kt) * 4;                                \
+    GL(pa0h + ko, BUF, 0, 0, wave * 32)                     \
+    GL(pa1h + ko, BUF, 0, 0, wave * 32 + 16)                \
+    GL(pa0l + ko, BUF, 0, 1, wave * 32)                     \
+    GL(pa1l + ko, BUF, 0, 1, wave * 32 + 16)                \
+    GL(pb0h + ko, BUF, 1, 0, wave * 32)                     \
+    GL(pb1h + ko, BUF, 1, 0, wave * 32 + 16)                \
+    GL(pb0l + ko, BUF, 1, 1, wave * 32)                     \
+    GL(pb1l + ko, BUF, 1, 1, wave * 32 + 16)                \
+  }
+  // operand reads: row r, k-step s, half h -> logical chunk 2s+h, physical chunk (2s+h) ^ ((r>>2)&3)
+  const int ra0 = wm * 64 + l31, ra1 = ra0 + 32, rb0 = wn * 64 + l31, rb1 = rb0 + 32;
+  const int sa0 = (ra0 >> 2) & 3, sa1 = (ra1 >> 2) & 3, sb0 = (rb0 >> 2) & 3, sb1 = (rb1 >> 2) & 3;
+#define GC_FRAG(BUF, OP, PL, ROW, SW, S) \
+  (*reinterpret_cast<const bf16x8*>(&lds[BUF][OP][PL][(ROW) * GROWB + ((((S) * 2 + half) ^ (SW)) << 4)]))
+#define GC_COMPUTE(BUF)                                                                       \
+  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                          \
+    const bf16x8 fa00 = GC_FRAG(BUF, 0, 0, ra0, sa0, s_), fa01 = GC_FRAG(BUF, 0, 1, ra0, sa0, s_); \
+    const bf16x8 fa10 = GC_FRAG(BUF, 0, 0, ra1, sa1, s_), fa11 = GC_FRAG(BUF, 0, 1, ra1, sa1, s_); \
+    const bf16x8 fb00 = GC_FRAG(BUF, 1, 0, rb0, sb0, s_), fb01 = GC_FRAG(BUF, 1, 1, rb0, sb0, s_); \
+    const bf16x8 fb10 = GC_FRAG(BUF, 1, 0, rb1, sb1, s_), fb11 = GC_FRAG(BUF, 1, 1, rb1, sb1, s_); \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa01, fb00, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa01, fb10, acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa11, fb00, acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa11, fb10, acc[1][1], 0, 0, 0);      \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb01, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb11, acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb01, acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb11, acc[1][1], 0, 0, 0);      \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb00, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb10, acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb00, acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb10, acc[1][1], 0, 0, 0);      \
+  }
+
+  const int nk = g.Kp / BK, last = nk - 1;
+  GL_TILE(0, 0)
+  __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  for (int kt = 0; kt < nk; kt += 2) {
+    GL_TILE((kt + 1 < last ? kt + 1 : last), 1)   // DMA of tile kt+1 runs under the MFMAs of tile kt
+    GC_COMPUTE(0)
+    __syncthreads();
+    if (kt + 1 < nk) {
+      GL_TILE((kt + 2 < last ? kt + 2 : last), 0)
+      GC_COMPUTE(1)
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int n = n0 + wn * 64 + tn * 32 + l31;
+    const bool n_ok = n < g.N;
+    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
+    const float gam = (g.gamma && n_ok) ? g.gamma[n] : 1.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + tm * 32 + mfma32_row(e, half);
+        float v = ds2_act(acc[tm][tn][e] + bias, g.act) * gam;
+        if (g.R && n_ok && m < g.M) {
+          const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
+          v += g.R[(size_t)rm * g.ldr + n];
+        }
+        if (g.C && n_ok && m < g.M) g.C[(size_t)m * g.ldc + n] = v;
+        if (g.C_hi) {
           const float vn = __shfl_down(v, 1);
           if ((l31 & 1) == 0 && m < g.M && n < g.ldcp) {
             const float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
@@ -193,7 +333,23 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
-  hipLaunchKernelGGL(k_gemm_split, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
+  static const bool glds = [] { const char* e = getenv("DS2_GEMM_KERNEL"); return e && strcmp(e, "glds") == 0; }();
+  if (glds) {
+    hipLaunchKernelGGL(k_gemm_glds, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
+  static const int dbg = [] { const char* e = getenv("DS2_GEMM_DBG"); return e ? atoi(e) : 0; }();
+  switch (dbg) {   // ablation builds for profiling only (results are wrong for dbg != 0)
+    case 1: hipLaunchKernelGGL(k_gemm_split<1>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    case 2: hipLaunchKernelGGL(k_gemm_split<2>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    case 3: hipLaunchKernelGGL(k_gemm_split<3>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    case 4: hipLaunchKernelGGL(k_gemm_split<4>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    case 7: hipLaunchKernelGGL(k_gemm_split<7>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    case 8: hipLaunchKernelGGL(k_gemm_split<8>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    case 15: hipLaunchKernelGGL(k_gemm_split<15>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
+    default: hipLaunchKernelGGL(k_gemm_split<0>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
+  }
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
