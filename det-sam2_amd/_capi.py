@@ -37,6 +37,7 @@ SIGNATURES = {
     "ds2_model_finalize": (C.c_int, [c_vp, c_vp]),
     "ds2_ingest_frames": (C.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
     "ds2_image_encoder": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_image_encoder_batch": (C.c_int, [c_vp, c_vp, i32, c_vp, c_vp, c_vp, c_vp]),
     "ds2_bank_assemble": (C.c_int, [c_vp, i32, i32, C.POINTER(c_vp), C.POINTER(i32), i32, C.POINTER(c_vp),
                                     C.POINTER(C.c_float), c_vp, c_vp, c_vp]),
     "ds2_memory_attention": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp]),

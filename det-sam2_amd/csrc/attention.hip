@@ -22,13 +22,15 @@ namespace {
 constexpr int BQ = 128, BKEYS = 32;
 
 struct RowMap {
-  int win, H, W, nwx, L;
+  int win, H, W, nwx, L, wins;
   __device__ __forceinline__ long row(int b, int i) const {   // -1 => padded position
     if (win == 0) return (long)b * L + i;
+    long base = 0;
+    if (wins > 0) { const int img = b / wins; b -= img * wins; base = (long)img * H * W; }
     const int wy = b / nwx, wx = b - wy * nwx;
     const int ly = i / win, lx = i - ly * win;
     const int y = wy * win + ly, x = wx * win + lx;
-    return (y < H && x < W) ? (long)y * W + x : -1;
+    return (y < H && x < W) ? base + (long)y * W + x : -1;
   }
 };
 
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
   const int l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
 
-  const RowMap qm{a.win_q, a.Hq, a.Wq, a.nwx, a.Lq};
-  const RowMap km{a.win_k, a.Hk, a.Wk, a.nwx, a.Lk};
+  const RowMap qm{a.win_q, a.Hq, a.Wq, a.nwx, a.Lq, a.wins};
+  const RowMap km{a.win_k, a.Hk, a.Wk, a.nwx, a.Lk, a.wins};
 
   // ---- stage the block's 128 query rows through LDS into per-lane B-operand registers
   float qreg[D / 2];

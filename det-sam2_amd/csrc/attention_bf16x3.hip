@@ -40,13 +40,15 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1) {
 }
 
 struct RowMap {
-  int win, H, W, nwx, L;
+  int win, H, W, nwx, L, wins;
   __device__ __forceinline__ long row(int b, int i) const {
     if (win == 0) return (long)b * L + i;
+    long base = 0;
+    if (wins > 0) { const int img = b / wins; b -= img * wins; base = (long)img * H * W; }
     const int wy = b / nwx, wx = b - wy * nwx;
     const int ly = i / win, lx = i - ly * win;
     const int y = wy * win + ly, x = wx * win + lx;
-    return (y < H && x < W) ? (long)y * W + x : -1;
+    return (y < H && x < W) ? base + (long)y * W + x : -1;
   }
 };
 
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0i = blockIdx.x * BQ;
-  const RowMap qm{a.win_q, a.Hq, a.Wq, a.nwx, a.Lq};
-  const RowMap km{a.win_k, a.Hk, a.Wk, a.nwx, a.Lk};
+  const RowMap qm{a.win_q, a.Hq, a.Wq, a.nwx, a.Lq, a.wins};
+  const RowMap km{a.win_k, a.Hk, a.Wk, a.nwx, a.Lk, a.wins};
   const float sc = a.scale * 1.44269504088896340736f;
 
   // ---- Q: stage fp32 rows through LDS, scale, split into two bf16 planes held in registers (B operand)

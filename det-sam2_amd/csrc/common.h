@@ -83,6 +83,8 @@ struct AttnArgs {
   // windowed mode (Hiera): batch item = window (wy*nwx + wx) of one image stored in natural (y,x) row order
   int win_q, win_k;             // 0 = plain [batch, L] rows
   int Hq, Wq, Hk, Wk, nwx;
+  int wins;                     // windowed mode with several images: windows per image (0 = one image); image i's
+                                // tokens are rows [i*H*W, (i+1)*H*W) and batch item = i*wins + window
   const float *k_pad, *v_pad;   // row used for padded key positions (the qkv bias), may be null
   // bf16x3 kernels only: if set, the result is written as two bf16 planes [rows, ldop] (GEMM operand format)
   // instead of fp32 `o`

@@ -469,34 +469,36 @@ extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n,
 }
 
 // ------------------------------------------------------------------------------------------------ A4 + A5
-extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float* fpn0, float* fpn1, float* fpn2, void* stream) {
-  DS2_REQUIRE(m && m->finalized && frame_f16 && fpn0 && fpn1 && fpn2, "ds2_image_encoder: bad argument");
+extern "C" int ds2_image_encoder_batch(ds2_model* m, const uint16_t* frames_f16, int32_t n, float* fpn0, float* fpn1, float* fpn2,
+                                       void* stream) {
+  DS2_REQUIRE(m && m->finalized && frames_f16 && fpn0 && fpn1 && fpn2 && n >= 1 && n <= 16, "ds2_image_encoder_batch: bad argument");
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.image_encoder", st);
   const int C0 = m->cfg.embed_dim;
   // workspace bound: every block output kept (sum <= depth * 65536*C0 floats is a loose bound) + temporaries
-  size_t need = (size_t)65536 * 148 * 4;
+  size_t need = (size_t)n * 65536 * 148 * 4;
   {
     int side = 256;
     size_t outs = 0, tmp_max = 0;
     for (const BlockCfg& b : m->blocks) {
-      const size_t hw = (size_t)side * side, hwq = b.q_stride ? hw / 4 : hw;
+      const size_t hw = (size_t)n * side * side, hwq = b.q_stride ? hw / 4 : hw;
       outs += hwq * b.dim_out * 4 + 256;
       // fp32 temporaries + (bf16x3 mode) their operand planes, which take the same number of bytes
       const size_t tmp = 2 * (hw * (b.dim + 32) + hw * b.dim_out * 2 + hw * 3 * b.dim_out + hwq * (b.dim_out + 32) * 3 + hwq * 4 * b.dim_out) * 4 + 65536;
       if (tmp > tmp_max) tmp_max = tmp;
       if (b.q_stride) side /= 2;
     }
-    need += outs + tmp_max + (size_t)(65536 + 16384 + 4096 * 2 + 1024) * 256 * 4 + (1u << 20);
+    need += outs + tmp_max + (size_t)n * (65536 + 16384 + 4096 * 2 + 1024) * 256 * 4 + (1u << 20);
   }
   TRY(m->require(need, st));
 
   // PatchEmbed (backbones/utils.py:93-96) + pos embed (hieradet.py:273-281), fused as GEMM epilogue
-  ALLOC(col, (size_t)65536 * 148);
-  TRY(launch_im2col_patch(frame_f16, col, 1024, st));
-  ALLOC(x0, (size_t)65536 * C0);
-  TRY(gemm(st, 65536, C0, 148, col, 148, m->P("@patch_w"), 148, m->P("image_encoder.trunk.patch_embed.proj.bias"), x0, C0,
-           DS2_ACT_NONE, m->P("#pos_embed"), C0, 0, nullptr, true));
+  ALLOC(col, (size_t)n * 65536 * 148);
+  for (int i = 0; i < n; ++i)
+    TRY(launch_im2col_patch(frames_f16 + (size_t)i * 3 * 1024 * 1024, col + (size_t)i * 65536 * 148, 1024, st));
+  ALLOC(x0, (size_t)n * 65536 * C0);
+  TRY(gemm(st, n * 65536, C0, 148, col, 148, m->P("@patch_w"), 148, m->P("image_encoder.trunk.patch_embed.proj.bias"), x0, C0,
+           DS2_ACT_NONE, m->P("#pos_embed"), C0, 65536, nullptr, true));
   const float* x = x0;
   int side = 256;
   const float* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -505,8 +507,8 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
   for (size_t i = 0; i < m->blocks.size(); ++i) {
     const BlockCfg& b = m->blocks[i];
     const std::string p = "image_encoder.trunk.blocks." + std::to_string(i);
-    const int hw = side * side;
-    const int side_q = b.q_stride ? side / 2 : side, hwq = side_q * side_q;
+    const int hw1 = side * side, hw = n * hw1;                                   // tokens per image / in the batch
+    const int side_q = b.q_stride ? side / 2 : side, hwq1 = side_q * side_q, hwq = n * hwq1;
     ALLOC(xn, (size_t)hwq * b.dim_out);           // block output survives the temporaries below
     const size_t mark = m->ws_top;
     ALLOC(t, (size_t)hw * b.dim);
@@ -517,7 +519,9 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
       TRY(linear(m, st, p + ".proj", hw, b.dim_out, b.dim, t, b.dim, scf, b.dim_out));
       if (b.q_stride) {
         ALLOC(scp, (size_t)hwq * b.dim_out);
-        TRY(launch_maxpool2x2(scf, b.dim_out, scp, b.dim_out, side, side, b.dim_out, st));
+        for (int i = 0; i < n; ++i)
+          TRY(launch_maxpool2x2(scf + (size_t)i * hw1 * b.dim_out, b.dim_out, scp + (size_t)i * hwq1 * b.dim_out, b.dim_out, side, side,
+                                b.dim_out, st));
         sc = scp;
       } else {
         sc = scf;
@@ -529,7 +533,9 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
     int ldq = 3 * b.dim_out;
     if (b.q_stride) {                              // q pooling (hieradet.py:65-68); even windows => plain 2x2 pooling
       ALLOC(qp, (size_t)hwq * b.dim_out);
-      TRY(launch_maxpool2x2(qkv, 3 * b.dim_out, qp, b.dim_out, side, side, b.dim_out, st));
+      for (int i = 0; i < n; ++i)
+        TRY(launch_maxpool2x2(qkv + (size_t)i * hw1 * 3 * b.dim_out, 3 * b.dim_out, qp + (size_t)i * hwq1 * b.dim_out, b.dim_out, side,
+                              side, b.dim_out, st));
       q = qp;
       ldq = b.dim_out;
     }
@@ -540,11 +546,11 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
     aa.heads = b.heads; aa.D = aa.DV = b.dim_out / b.heads;
     aa.scale = 1.0f / sqrtf((float)aa.D);
     if (b.window == 0) {
-      aa.batch = 1; aa.Lq = hwq; aa.Lk = hw; aa.win_q = aa.win_k = 0;
+      aa.batch = n; aa.Lq = hwq1; aa.Lk = hw1; aa.win_q = aa.win_k = 0;
     } else {
       const int nw = cdiv(side, b.window);
       aa.win_k = b.window; aa.win_q = b.q_stride ? b.window / 2 : b.window;
-      aa.batch = nw * nw; aa.nwx = nw;
+      aa.batch = n * nw * nw; aa.nwx = nw; aa.wins = nw * nw;
       aa.Lq = aa.win_q * aa.win_q; aa.Lk = aa.win_k * aa.win_k;
       aa.Hq = aa.Wq = side_q; aa.Hk = aa.Wk = side;
       const float* qb = m->P(p + ".attn.qkv.bias");
@@ -572,21 +578,26 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
   }
   DS2_REQUIRE(n_stage == 4, "image encoder: expected 4 stage outputs, got %d", n_stage);
   // FpnNeck (image_encoder.py:101-134): convs[n-i] on xs[i]; top-down nearest only into level 2; scalp=1
-  ALLOC(lat3, (size_t)1024 * 256);
-  ALLOC(lat2, (size_t)4096 * 256);
-  ALLOC(lat1, (size_t)16384 * 256);
-  ALLOC(lat0, (size_t)65536 * 256);
-  TRY(linear(m, st, "image_encoder.neck.convs.0.conv", 1024, 256, stage_dim[3], stage_out[3], stage_dim[3], lat3, 256));
-  TRY(linear(m, st, "image_encoder.neck.convs.1.conv", 4096, 256, stage_dim[2], stage_out[2], stage_dim[2], lat2, 256));
-  TRY(linear(m, st, "image_encoder.neck.convs.2.conv", 16384, 256, stage_dim[1], stage_out[1], stage_dim[1], lat1, 256));
-  TRY(linear(m, st, "image_encoder.neck.convs.3.conv", 65536, 256, stage_dim[0], stage_out[0], stage_dim[0], lat0, 256));
-  TRY(launch_up2_add(lat2, lat3, fpn2, 64, 64, 256, st));
+  ALLOC(lat3, (size_t)n * 1024 * 256);
+  ALLOC(lat2, (size_t)n * 4096 * 256);
+  ALLOC(lat1, (size_t)n * 16384 * 256);
+  ALLOC(lat0, (size_t)n * 65536 * 256);
+  TRY(linear(m, st, "image_encoder.neck.convs.0.conv", n * 1024, 256, stage_dim[3], stage_out[3], stage_dim[3], lat3, 256));
+  TRY(linear(m, st, "image_encoder.neck.convs.1.conv", n * 4096, 256, stage_dim[2], stage_out[2], stage_dim[2], lat2, 256));
+  TRY(linear(m, st, "image_encoder.neck.convs.2.conv", n * 16384, 256, stage_dim[1], stage_out[1], stage_dim[1], lat1, 256));
+  TRY(linear(m, st, "image_encoder.neck.convs.3.conv", n * 65536, 256, stage_dim[0], stage_out[0], stage_dim[0], lat0, 256));
+  for (int i = 0; i < n; ++i)
+    TRY(launch_up2_add(lat2 + (size_t)i * 4096 * 256, lat3 + (size_t)i * 1024 * 256, fpn2 + (size_t)i * 4096 * 256, 64, 64, 256, st));
   // conv_s0 / conv_s1 (sam2_base.py:455-460)
-  TRY(linear(m, st, "sam_mask_decoder.conv_s1", 16384, 64, 256, lat1, 256, fpn1, 64));
-  TRY(linear(m, st, "sam_mask_decoder.conv_s0", 65536, 32, 256, lat0, 256, fpn0, 32));
+  TRY(linear(m, st, "sam_mask_decoder.conv_s1", n * 16384, 64, 256, lat1, 256, fpn1, 64));
+  TRY(linear(m, st, "sam_mask_decoder.conv_s0", n * 65536, 32, 256, lat0, 256, fpn0, 32));
   CHECK_PARAMS();
   (void)stage_side;
   return DS2_OK;
+}
+
+extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float* fpn0, float* fpn1, float* fpn2, void* stream) {
+  return ds2_image_encoder_batch(m, frame_f16, 1, fpn0, fpn1, fpn2, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ A11

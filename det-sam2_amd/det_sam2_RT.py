@@ -154,7 +154,7 @@ class VideoProcessor:
                 return str(x)
             return x
 
-        st = {k: v for k, v in self.inference_state.items() if k != "cached_features"}
+        st = {k: v for k, v in self.inference_state.items() if k not in ("cached_features", "_encode_order")}
         st["cached_features"] = {}
         with open(save_path, "wb") as f:
             pickle.dump(to_host(st), f)

@@ -148,6 +148,15 @@ class HipSam2(HipOps):
         _capi.check(self.lib.ds2_image_encoder(self.h, _p(frame_f16), _p(f0), _p(f1), _p(f2), self._stream()), "ds2_image_encoder")
         return f0, f1, f2
 
+    def image_encoder_batch(self, frames_f16: torch.Tensor):
+        """fp16 [n,3,S,S] -> list of n (fpn0, fpn1, fpn2) tuples (views of three batched buffers)."""
+        assert frames_f16.dtype == torch.float16 and frames_f16.is_cuda and frames_f16.is_contiguous() and frames_f16.dim() == 4
+        n = frames_f16.shape[0]
+        f0, f1, f2 = self._empty(n, 65536, 32), self._empty(n, 16384, 64), self._empty(n, TOK, 256)
+        _capi.check(self.lib.ds2_image_encoder_batch(self.h, _p(frames_f16), n, _p(f0), _p(f1), _p(f2), self._stream()),
+                    "ds2_image_encoder_batch")
+        return [(f0[i], f1[i], f2[i]) for i in range(n)]
+
     def bank_assemble(self, B, mem_entries, ptr_entries):
         """mem_entries: [(bf16 [B,4096,64], tpos_row)], ptr_entries: [(fp32 [B,256], pos/t_diff_max)] (A11)."""
         n_mem, n_ptr = len(mem_entries), len(ptr_entries)

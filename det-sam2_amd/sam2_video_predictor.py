@@ -36,7 +36,10 @@ class SAM2VideoPredictor:
         self.image_size = self.cfg.image_size
         self.hidden_dim, self.mem_dim, self.num_maskmem = self.cfg.d_model, self.cfg.mem_dim, self.cfg.num_maskmem
         self.trace = None          # optional list of bank-selection traces (tests)
-        self.stats = {"encoder_runs": 0, "tracked_frames": 0}
+        self.stats = {"encoder_runs": 0, "encoder_launches": 0, "tracked_frames": 0}
+        # frames encoded per image-encoder launch: the driver hands frames over 30 at a time, and one frame's
+        # Hiera stage-3/4 GEMMs (4096 / 1024 tokens) cannot fill 256 CUs.  Same results as one-by-one.
+        self.encode_batch = 4
 
     # ------------------------------------------------------------------ frame ingest (A3)
     def _load_frames(self, video_path):
@@ -118,13 +121,30 @@ class SAM2VideoPredictor:
 
     # ------------------------------------------------------------------ features (A4/A5)
     def _get_image_feature(self, st, frame_idx):
-        """_get_image_feature (sam2_video_predictor.py:1174-1212) with a whole-window cache."""
-        f = st["cached_features"].get(frame_idx)
+        """_get_image_feature (sam2_video_predictor.py:1174-1212) with a whole-window cache and batched encoding:
+        on a miss, the next not-yet-encoded frames of the current propagation order ride along in one launch."""
+        cache = st["cached_features"]
+        f = cache.get(frame_idx)
         if f is None:
-            img = st["images"][st["images_idx"].index(frame_idx)]
-            f = self.hip.image_encoder(img)
-            st["cached_features"][frame_idx] = f
-            self.stats["encoder_runs"] += 1
+            todo = [frame_idx]
+            order = st.get("_encode_order")
+            if self.encode_batch > 1 and order is not None and frame_idx in order:
+                have = set(st["images_idx"])
+                for t in order[order.index(frame_idx) + 1:]:
+                    if len(todo) >= self.encode_batch:
+                        break
+                    if t not in cache and t in have:
+                        todo.append(t)
+            if len(todo) == 1:
+                feats = [self.hip.image_encoder(st["images"][st["images_idx"].index(frame_idx)])]
+            else:
+                pos = torch.tensor([st["images_idx"].index(t) for t in todo], device=st["images"].device)
+                feats = self.hip.image_encoder_batch(st["images"].index_select(0, pos))
+            for t, ft in zip(todo, feats):
+                cache[t] = ft
+            self.stats["encoder_runs"] += len(todo)
+            self.stats["encoder_launches"] += 1
+            f = cache[frame_idx]
         return f
 
     # ------------------------------------------------------------------ object table (A17)
@@ -396,6 +416,7 @@ class SAM2VideoPredictor:
         else:
             end = min(start_frame_idx + max_frame_num_to_track, n - 1)
             order = range(start_frame_idx, end + 1)
+        st["_encode_order"] = list(order)   # lets the feature cache batch-encode upcoming frames
         for t in order:
             if t in cfi["cond_frame_outputs"]:
                 key = "cond_frame_outputs"

@@ -72,6 +72,11 @@ int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t he
  * + conv_s0/conv_s1 (mask_decoder.py:73-78).  frame_f16 [3,S,S] ->
  * fpn0 [65536,32], fpn1 [16384,64], fpn2 [4096,256]. */
 int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float* fpn0, float* fpn1, float* fpn2, void* stream);
+/* Same for n frames at once (frames_f16 [n,3,S,S] -> fpn0 [n,65536,32], fpn1 [n,16384,64], fpn2 [n,4096,256]):
+ * the per-frame GEMMs of Hiera stages 3-4 (4096 / 1024 tokens) are too small to fill 256 CUs; the driver buffers
+ * 30 frames before every pass (det_sam2_RT.py:429), so several can be encoded per launch. */
+int ds2_image_encoder_batch(ds2_model* m, const uint16_t* frames_f16, int32_t n, float* fpn0, float* fpn1, float* fpn2,
+                            void* stream);
 
 /* ---- A11: memory-bank assembly, the tensor part of _prepare_memory_conditioned_features
  * (sam2_base.py:565-648).  feats[e]: bf16 [B,4096,64] of memory frame e, tpos_row[e] = index into

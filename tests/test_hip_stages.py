@@ -69,6 +69,18 @@ def test_image_encoder(name, prec):
     assert max(errs) < TOL[prec], errs
 
 
+def test_image_encoder_batch_equals_single(prec):
+    cfg, sd, hm = model("sam2.1_hiera_t", prec)
+    imgs, _, _ = load_frames([synthetic_frame(t) for t in (1, 2, 3)])
+    d = hm.device
+    batch = hm.image_encoder_batch(imgs.to(d))
+    for i in range(3):
+        single = hm.image_encoder(imgs[i].to(d))
+        torch.cuda.synchronize()
+        for a, b in zip(batch[i], single):
+            assert rel_err(a, b) < 1e-6
+
+
 def test_memory_attention_and_bank(prec):
     cfg, sd, hm = model("sam2.1_hiera_t", prec)
     g = torch.Generator().manual_seed(11)
