@@ -148,35 +148,83 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
   }
   if (kt < nk) G_COMPUTE(0)   // odd tail: tile nk-1 sits in LDS[0]
 
+  // ---- epilogue, staged through LDS: the MFMA fragment layout (one column, 16 scattered rows per lane) would give
+  // 4-byte scattered global stores; each wave parks its 64x64 tile in LDS and re-reads it row-wise so that every
+  // lane handles 4 consecutive columns: 16-byte loads of bias/residual, 16-byte fp32 stores, 8-byte plane stores.
+  __syncthreads();                                   // operand tiles are dead
+  constexpr int EPLD = 68;                           // floats per staged row (64 + 4 pad)
+  float* ep = reinterpret_cast<float*>(&lds[0][0][0][0]) + wave * (64 * EPLD);
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int n = n0 + wn * 64 + tn * 32 + l31;
-    const bool n_ok = n < g.N;
-    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
-    const float gam = (g.gamma && n_ok) ? g.gamma[n] : 1.f;
+  for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + tm * 32 + mfma32_row(e, half);
-        float v = ds2_act(acc[tm][tn][e] + bias, g.act) * gam;
-        if (g.R && n_ok && m < g.M) {
-          const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
-          v += g.R[(size_t)rm * g.ldr + n];
-        }
-        if (DBG & 8) { if (v == 1.2345e37f) g.C[0] = v; continue; }
-        if (g.C && n_ok && m < g.M) g.C[(size_t)m * g.ldc + n] = v;
-        if (g.C_hi) {   // split planes of the result: neighbouring lanes hold neighbouring columns -> pack pairs
-          const float vn = __shfl_down(v, 1);
-          if ((l31 & 1) == 0 && m < g.M && n < g.ldcp) {
-            const float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
-            const unsigned h = cvt_pk_bf16(x0, x1);
-            const unsigned l = cvt_pk_bf16(x0 - bf_lo(h), x1 - bf_hi(h));
-            *reinterpret_cast<unsigned*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
-            *reinterpret_cast<unsigned*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
-          }
+      for (int e = 0; e < 16; ++e) ep[(tm * 32 + mfma32_row(e, half)) * EPLD + tn * 32 + l31] = acc[tm][tn][e];
+  __syncthreads();
+  if (DBG & 8) return;
+  const int c4 = lane & 15, r0 = lane >> 4;
+  const int n = n0 + wn * 64 + c4 * 4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  {
+    float* bp = reinterpret_cast<float*>(&bias4);
+    float* gp = reinterpret_cast<float*>(&gam4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (g.bias && n + j < g.N) bp[j] = g.bias[n + j];
+      if (g.gamma && n + j < g.N) gp[j] = g.gamma[n + j];
+    }
+  }
+  const bool vec_ok = (n + 3 < g.N);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 4 + r0;
+    const int m = m0 + wm * 64 + r;
+    if (m >= g.M) continue;
+    const float4 a4 = *reinterpret_cast<const float4*>(&ep[r * EPLD + c4 * 4]);
+    float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
+                  ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
+    if (g.R) {
+      const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
+      const float* rp = g.R + (size_t)rm * g.ldr + n;
+      if (vec_ok && (g.ldr & 3) == 0) {
+        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < g.N) v[j] += rp[j];
+      }
+    }
+    if (g.C) {
+      float* cp = g.C + (size_t)m * g.ldc + n;
+      if (vec_ok && (g.ldc & 3) == 0) {
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < g.N) cp[j] = v[j];
+      }
+    }
+    if (g.C_hi && n < g.ldcp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j >= g.N) v[j] = 0.f;                 // pad columns of the planes are zero
+      if (g.rope_cis) {   // columns (n, n+1), (n+2, n+3) are complex pairs (apply_rotary_enc, position_encoding.py:196-220)
+        const int t = m % g.rope_L;
+        if (t < g.rope_n) {
+          const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
+          const float a0 = v[0] * c.x - v[1] * c.y, a1 = v[0] * c.y + v[1] * c.x;
+          const float a2 = v[2] * c.z - v[3] * c.w, a3 = v[2] * c.w + v[3] * c.z;
+          v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
         }
       }
+      uint2 h, l;
+      h.x = cvt_pk_bf16(v[0], v[1]);
+      h.y = cvt_pk_bf16(v[2], v[3]);
+      l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
+      l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
+      *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
+      *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
     }
   }
 }
@@ -304,7 +352,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmSplitArgs g, int mt, i
         if (g.C_hi) {
           const float vn = __shfl_down(v, 1);
           if ((l31 & 1) == 0 && m < g.M && n < g.ldcp) {
-            const float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
+            float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
+            if (g.rope_cis) {   // columns (n, n+1) are one complex pair (apply_rotary_enc, position_encoding.py:196-220)
+              const int t = m % g.rope_L;
+              if (t < g.rope_n) {
+                const float2 c = reinterpret_cast<const float2*>(g.rope_cis)[(size_t)(t % g.rope_grid) * 128 + (n >> 1)];
+                const float r0 = x0 * c.x - x1 * c.y, r1 = x0 * c.y + x1 * c.x;
+                x0 = r0; x1 = r1;
+              }
+            }
             const unsigned h = cvt_pk_bf16(x0, x1);
             const unsigned l = cvt_pk_bf16(x0 - bf_lo(h), x1 - bf_hi(h));
             *reinterpret_cast<unsigned*>(g.C_hi + (size_t)m * g.ldcp + n) = h;

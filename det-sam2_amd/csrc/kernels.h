@@ -76,6 +76,9 @@ struct GemmSplitArgs {
   float* C; int ldc;                              // fp32 result (may be null if only planes are wanted)
   int act; const float* gamma; const float* R; int ldr; int r_mod;
   unsigned short *C_hi, *C_lo; int ldcp;          // optional split planes of the result [M, ldcp] (pad cols zeroed)
+  // optional axial RoPE applied to the result before it is split into planes (cross-attention keys): row m is
+  // token t = m % rope_L of its batch item; tokens t < rope_n are rotated with cis[(t % rope_grid)][col/2]
+  const float* rope_cis; int rope_L, rope_n, rope_grid;
 };
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);

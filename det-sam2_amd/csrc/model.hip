@@ -220,7 +220,8 @@ static int new_act_planes(ds2_model* m, const void* key, int rows, int cols, ds2
 // the fp32 buffer C is NOT written (its only consumers must be GEMMs).
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
-                const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false) {
+                const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false,
+                const float* rope_cis = nullptr, int rope_L = 0, int rope_n = 0, int rope_grid = 0) {
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
@@ -273,6 +274,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, C, M, N, &op, st));
     g.C = nullptr; g.C_hi = op.hi; g.C_lo = op.lo; g.ldcp = op.ld;
+    g.rope_cis = rope_cis; g.rope_L = rope_L; g.rope_n = rope_n; g.rope_grid = rope_grid;
   }
   return launch_gemm_split(g, st);
 }
@@ -658,11 +660,10 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
   // bf16x3 mode: attention operands are split into bf16 planes once by their producers (attention_split.hip)
   void *khi = nullptr, *klo = nullptr, *vt_c = nullptr, *khi_s = nullptr, *klo_s = nullptr, *vt_s = nullptr;
   if (split) {
-    khi = m->alloc_bytes((size_t)B * Nk * 512); klo = m->alloc_bytes((size_t)B * Nk * 512);
     vt_c = m->alloc_bytes((size_t)B * nt_c * 8192);
     khi_s = m->alloc_bytes((size_t)rows * 512); klo_s = m->alloc_bytes((size_t)rows * 512);
     vt_s = m->alloc_bytes((size_t)4 * B * nt_s * 8192);
-    if (!khi || !klo || !vt_c || !khi_s || !klo_s || !vt_s) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
+    if (!vt_c || !khi_s || !klo_s || !vt_s) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     TRY(vt_split(memory, 64, B, Nk, vt_c, st));   // V = raw memory (64-d), shared by the 4 layers
   }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
@@ -728,9 +729,13 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
     TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
-    TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
     if (split) {
-      TRY(launch_rope_split(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, khi, klo, st));
+      // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
+      TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
+               m->P(p + ".cross_attn_image.k_proj.bias"), K, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m, true, cis, Nk,
+               Nk - n_ptr_tok, TOK));
+      const ds2_model::ActPlanes kpl = m->act_planes[K];
+      khi = kpl.hi; klo = kpl.lo;
       ProfScope _p("kernel.cross_attention", st);
       if (use_w8()) {
         ds2_model::ActPlanes cp;
@@ -740,6 +745,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
         TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
       }
     } else {
+      TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
       AttnArgs ca{};
       ca.q = q; ca.k = K; ca.v = memory; ca.o = a64;
