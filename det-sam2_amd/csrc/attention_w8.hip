@@ -10,13 +10,15 @@
 // online softmax with per-lane statistics (two __shfl_xor to share the row max across the four lane groups),
 // P^T fed to O^T = V^T P^T straight from the accumulators, V^T stored key-permuted so its operand is one
 // ds_read_b128.  Operands arrive pre-split (k_rope_split, k_vt_split16).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int D = 256, BQ = 128, BKEYS = 32;
+constexpr int D = 256, BKEYS = 32;
 constexpr int KROWB = D * 2 + 16, KPLANE = BKEYS * KROWB;
 constexpr int VROWB = 80;
 constexpr int KS = D / 32;   // 8 k-steps of 32
@@ -73,8 +75,12 @@ struct W8Args {
   unsigned short *o_hi, *o_lo; int ldop;   // optional: emit the result as bf16 planes (consumer is a GEMM)
 };
 
-template <int DV>
+// QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
+// (32 queries per wave, 256 per block): LDS traffic per MFMA halves - with QG = 1 the LDS pipe is about as busy as
+// the matrix pipe - at the price of 128 VGPRs of Q planes.
+template <int DV, int QG>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
+  constexpr int BQ = 128 * QG;
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
   __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
@@ -87,11 +93,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   const int b = bid / nqb, q0i = (bid % nqb) * BQ;
   const float sc = a.scale * 1.44269504088896340736f;
 
-  // ---- Q: 4 rounds of 32 rows through LDS (fp32, scaled); waves 2r, 2r+1 pick up their 16 rows in round r
-  bf16x8 q0[KS], q1[KS];
+  // ---- Q: rounds of 32 rows through LDS (fp32, scaled); each wave picks up its 16*QG rows
+  bf16x8 q0[QG][KS], q1[QG][KS];
   {
     float* Qs = reinterpret_cast<float*>(&Kp[0][0][0]);   // [32][D+1]
-    for (int r4 = 0; r4 < 4; ++r4) {
+    for (int r4 = 0; r4 < BQ / 32; ++r4) {
       for (int idx = tid; idx < 32 * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
         const float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
@@ -99,22 +105,31 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
         dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
       }
       __syncthreads();
-      if ((wave >> 1) == r4) {
-        const float* qrow = Qs + ((wave & 1) * 16 + l15) * (D + 1) + grp * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const float* qr = qrow + ks * 32;
-          split8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7], q0[ks], q1[ks]);
+      for (int g = 0; g < QG; ++g) {
+        const int row = wave * 16 * QG + g * 16;            // first row of this wave's group g inside the block
+        if (row / 32 == r4) {
+          const float* qrow = Qs + ((row & 31) + l15) * (D + 1) + grp * 8;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const float* qr = qrow + ks * 32;
+            split8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7], q0[g][ks], q1[g][ks]);
+          }
         }
       }
       __syncthreads();
     }
   }
 
-  f32x4 o[NT];
+  f32x4 o[QG][NT];
+  float m_run[QG], l_run[QG];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int g = 0; g < QG; ++g) {
+    m_run[g] = -INFINITY;
+    l_run[g] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
   // staging: K planes = 2 x (32 rows x 32 uint4); thread handles uint4 #(tid + 512 i), i = 0..3; V^T planes =
@@ -157,8 +172,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
     W8_LOAD(kt + 1 < nkt ? kt + 1 : kt)
-    // ---- S^T = K Q^T for the two 16-key blocks of the tile
-    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- S^T = K Q^T for the two 16-key blocks of the tile (each K fragment serves QG query groups)
+    f32x4 s0[QG], s1[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) { s0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const unsigned char* kp0 = &Kp[cur][0][l15 * KROWB + grp * 16];
     const unsigned char* kp1 = &Kp[cur][1][l15 * KROWB + grp * 16];
 #pragma unroll
@@ -167,67 +184,89 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + ks * 64);
       const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + ks * 64);
       const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[ks], s1, 0, 0, 0);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q1[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[ks], s1, 0, 0, 0);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q0[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q0[ks], s1, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[g][ks], s0[g], 0, 0, 0);
+        s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[g][ks], s1[g], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q1[g][ks], s0[g], 0, 0, 0);
+        s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[g][ks], s1[g], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q0[g][ks], s0[g], 0, 0, 0);
+        s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q0[g][ks], s1[g], 0, 0, 0);
+      }
     }
     if (kt == nkt - 1) {   // keys >= Lk only exist in the last tile; lane holds keys 4*grp + r (+16)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (kt * BKEYS + 4 * grp + r >= a.Lk) s0[r] = -INFINITY;
-        if (kt * BKEYS + 16 + 4 * grp + r >= a.Lk) s1[r] = -INFINITY;
-      }
+      for (int g = 0; g < QG; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt * BKEYS + 4 * grp + r >= a.Lk) s0[g][r] = -INFINITY;
+          if (kt * BKEYS + 16 + 4 * grp + r >= a.Lk) s1[g][r] = -INFINITY;
+        }
     }
-    float tmax = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f(m_run - m_new);
-    const float p0 = exp2f(s0[0] - m_new), p1 = exp2f(s0[1] - m_new), p2 = exp2f(s0[2] - m_new), p3 = exp2f(s0[3] - m_new);
-    const float p4 = exp2f(s1[0] - m_new), p5 = exp2f(s1[1] - m_new), p6 = exp2f(s1[2] - m_new), p7 = exp2f(s1[3] - m_new);
-    l_run = l_run * alpha + (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)));
-    m_run = m_new;
-    bf16x8 pb0, pb1;
-    split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0, pb1);
-    // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block
+    bf16x8 pb0[QG], pb1[QG];
+    float alpha[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      float tmax = fmaxf(fmaxf(fmaxf(s0[g][0], s0[g][1]), fmaxf(s0[g][2], s0[g][3])),
+                         fmaxf(fmaxf(s1[g][0], s1[g][1]), fmaxf(s1[g][2], s1[g][3])));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run[g], tmax);
+      alpha[g] = exp2f(m_run[g] - m_new);
+      const float p0 = exp2f(s0[g][0] - m_new), p1 = exp2f(s0[g][1] - m_new), p2 = exp2f(s0[g][2] - m_new), p3 = exp2f(s0[g][3] - m_new);
+      const float p4 = exp2f(s1[g][0] - m_new), p5 = exp2f(s1[g][1] - m_new), p6 = exp2f(s1[g][2] - m_new), p7 = exp2f(s1[g][3] - m_new);
+      l_run[g] = l_run[g] * alpha[g] + (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)));
+      m_run[g] = m_new;
+      split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0[g], pb1[g]);
+    }
+    // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block (each V^T fragment serves QG groups)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      o[t] *= alpha;
       const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
       const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
-      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0, o[t], 0, 0, 0);
-      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1, o[t], 0, 0, 0);
-      o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0, o[t], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        o[g][t] *= alpha[g];
+        o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
+        o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
+        o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0[g], o[g][t], 0, 0, 0);
+      }
     }
     W8_STORE(cur ^ 1)
     __syncthreads();
     cur ^= 1;
   }
 
-  float l_tot = l_run + __shfl_xor(l_run, 16);
-  l_tot += __shfl_xor(l_tot, 32);
-  const float inv = 1.f / l_tot;
-  const size_t orow = (size_t)b * a.Lq + q0i + wave * 16 + l15;
-  if (a.o_hi) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const float v0 = o[t][0] * inv, v1 = o[t][1] * inv, v2 = o[t][2] * inv, v3 = o[t][3] * inv;
-      uint2 h, l;
-      h.x = cvt_pk_bf16(v0, v1);
-      h.y = cvt_pk_bf16(v2, v3);
-      l.x = cvt_pk_bf16(v0 - bf_lo(h.x), v1 - bf_hi(h.x));
-      l.y = cvt_pk_bf16(v2 - bf_lo(h.y), v3 - bf_hi(h.y));
-      *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + 16 * t + 4 * grp) = h;
-      *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + 16 * t + 4 * grp) = l;
+  for (int g = 0; g < QG; ++g) {
+    float l_tot = l_run[g] + __shfl_xor(l_run[g], 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.f / l_tot;
+    const size_t orow = (size_t)b * a.Lq + q0i + wave * 16 * QG + g * 16 + l15;
+    if (a.o_hi) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float v0 = o[g][t][0] * inv, v1 = o[g][t][1] * inv, v2 = o[g][t][2] * inv, v3 = o[g][t][3] * inv;
+        uint2 h, l;
+        h.x = cvt_pk_bf16(v0, v1);
+        h.y = cvt_pk_bf16(v2, v3);
+        l.x = cvt_pk_bf16(v0 - bf_lo(h.x), v1 - bf_hi(h.x));
+        l.y = cvt_pk_bf16(v2 - bf_lo(h.y), v3 - bf_hi(h.y));
+        *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + 16 * t + 4 * grp) = h;
+        *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + 16 * t + 4 * grp) = l;
+      }
+    } else {
+      float* op = a.o + orow * a.ldo + 4 * grp;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[g][t][0] * inv, o[g][t][1] * inv, o[g][t][2] * inv, o[g][t][3] * inv);
     }
-  } else {
-    float* op = a.o + orow * a.ldo + 4 * grp;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
   }
 }
 
@@ -248,16 +287,19 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop) {
-  DS2_REQUIRE(Lq % BQ == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128),
-              "attention_w8: Lq must be a multiple of 128, dv 64 or 128");
+  DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128),
+              "attention_w8: Lq must be a multiple of 256, dv 64 or 128");
+  static const bool qg1 = [] { const char* e = getenv("DS2_ATTN_QG"); return e && atoi(e) == 1; }();
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop};
   DS2_REQUIRE(o || o_hi, "attention_w8: no output");
-  if (dv == 64)
-    hipLaunchKernelGGL((k_attention_w8<64>), dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
+  if (dv == 64 && !qg1)
+    hipLaunchKernelGGL((k_attention_w8<64, 2>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
+  else if (dv == 64)
+    hipLaunchKernelGGL((k_attention_w8<64, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL((k_attention_w8<128>), dim3(batch * (Lq / BQ)), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((k_attention_w8<128, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
