@@ -273,13 +273,16 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 }  // namespace
 
 int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st) {
-  DS2_REQUIRE(dv == 64 || dv == 128, "vt_split16: dv must be 64 or 128");
+  DS2_REQUIRE(dv == 64 || dv == 128 || dv == 256, "vt_split16: dv must be 64, 128 or 256");
   const size_t n = (size_t)batch * ((L + 31) / 32) * 32 * dv;
   if (dv == 64)
     hipLaunchKernelGGL((k_vt_split16<64>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
                        reinterpret_cast<unsigned short*>(vt));
-  else
+  else if (dv == 128)
     hipLaunchKernelGGL((k_vt_split16<128>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
+                       reinterpret_cast<unsigned short*>(vt));
+  else
+    hipLaunchKernelGGL((k_vt_split16<256>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
                        reinterpret_cast<unsigned short*>(vt));
   DS2_CHECK_LAUNCH();
   return DS2_OK;
@@ -287,8 +290,8 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop) {
-  DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128),
-              "attention_w8: Lq must be a multiple of 256, dv 64 or 128");
+  DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
+              "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
   static const bool qg1 = [] { const char* e = getenv("DS2_ATTN_QG"); return e && atoi(e) == 1; }();
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
@@ -298,8 +301,10 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
     hipLaunchKernelGGL((k_attention_w8<64, 2>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
   else if (dv == 64)
     hipLaunchKernelGGL((k_attention_w8<64, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
-  else
+  else if (dv == 128)
     hipLaunchKernelGGL((k_attention_w8<128, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+  else   // self-attention in one pass: 16 dv blocks (64 accumulator registers), 150 KB of LDS
+    hipLaunchKernelGGL((k_attention_w8<256, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

@@ -693,13 +693,9 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
       ProfScope _p("kernel.self_attention", st);
       ds2_model::ActPlanes sa_p{};
       if (use_w8()) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
-      if (use_w8()) {   // DV=256 as two 128-column passes (scores recomputed once)
-        for (int c = 0; c < 2; ++c) {
-          void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 16384;
-          TRY(launch_vt_split16(qkv + 512 + c * 128, 768, Bs, TOK, vt, 128, st));
-          TRY(launch_attention_w8(qkv, 768, khi_s, klo_s, vt, nullptr, 256, Bs, TOK, TOK, sc, 128, st, sa_p.hi + c * 128,
-                                  sa_p.lo + c * 128, sa_p.ld));
-        }
+      if (use_w8()) {   // all 256 value columns in one pass
+        TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));
+        TRY(launch_attention_w8(qkv, 768, khi_s, klo_s, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi, sa_p.lo, sa_p.ld));
       } else {          // four 64-column passes
         for (int c = 0; c < 4; ++c) {
           void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 8192;
