@@ -248,6 +248,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
   DS2_REQUIRE(a.batch > 0 && a.heads > 0 && a.Lq > 0 && a.Lk > 0, "attention: bad sizes");
   DS2_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
   DS2_REQUIRE(a.batch <= 65535 && a.heads <= 65535, "attention: grid too large");
+  if (attention_fewq_supported(a)) return launch_attention_fewq(a, st);   // few queries x many keys: split-key fp32 path
   if (g_ds2_precision == DS2_PREC_BF16X3) {
     const int rc = launch_attention_bf16x3(a, st);
     if (rc != DS2_ERR_UNSUPPORTED) return rc;

@@ -11,6 +11,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef DS2_GEMM_INTERLEAVE
+#define DS2_GEMM_INTERLEAVE 1
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
       }                                                                                   \
   }
 
+#if DS2_GEMM_INTERLEAVE == 0
   // prologue: tile 0 -> LDS[0]; tile 1 -> set x.  All loads/stores in the steady state are UNCONDITIONAL (tile
   // index clamped to nk-1): a branch around a load makes the compiler's s_waitcnt placement conservative
   // (vmcnt(0) before the first ds_write), which serialises the two-deep prefetch.
@@ -147,6 +152,59 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
     __syncthreads();
   }
   if (kt < nk) G_COMPUTE(0)   // odd tail: tile nk-1 sits in LDS[0]
+#else
+  // Interleaved steady state: the 8 ds_write_b128 of the NEXT tile and the 8 global loads of the tile after
+  // next are issued in the shadow of the first 8 MFMAs of the current tile (an MFMA occupies the matrix pipe for 32
+  // cycles; LDS / VMEM issue slots are free meanwhile), instead of after the 24th MFMA.
+#define G_READ(cur, s, A0, A1, B0, B1)                                                    \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                         \
+    const int ar = (wm * 64 + t * 32 + l31) * ROWB + (s) * 32 + half * 16;                \
+    const int br = (wn * 64 + t * 32 + l31) * ROWB + (s) * 32 + half * 16;                \
+    A0[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][0][ar]);                        \
+    A1[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][0][1][ar]);                        \
+    B0[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][0][br]);                        \
+    B1[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][1][br]);                        \
+  }
+#define G_MFMA(A0, A1, B0, B1)                                                            \
+  _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
+    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                    \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[tm], B0[tn], acc[tm][tn], 0, 0, 0); \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B1[tn], acc[tm][tn], 0, 0, 0); \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B0[tn], acc[tm][tn], 0, 0, 0); \
+    }
+#define G_ITER(cur, nxt, P, ktl)                                                          \
+  {                                                                                       \
+    bf16x8 fa0[2], fa1[2], fb0[2], fb1[2], ga0[2], ga1[2], gb0[2], gb1[2];                \
+    G_READ(cur, 0, fa0, fa1, fb0, fb1)                                                    \
+    G_MFMA(fa0, fa1, fb0, fb1)                                                            \
+    G_STORE(P, nxt)                                                                       \
+    G_LOAD(P, ktl)                                                                        \
+    G_READ(cur, 1, ga0, ga1, gb0, gb1)                                                    \
+    G_MFMA(ga0, ga1, gb0, gb1)                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                  \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                  \
+    }                                                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                                   \
+  }
+  const int last = nk - 1;
+  G_LOAD(x, 0)
+  G_STORE(x, 0)
+  G_LOAD(x, (1 < last ? 1 : last))
+  G_LOAD(y, (2 < last ? 2 : last))
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {   // LDS[0] holds tile kt, set x tile kt+1, set y tile kt+2
+    G_ITER(0, 1, x, (kt + 3 < last ? kt + 3 : last))
+    __syncthreads();
+    G_ITER(1, 0, y, (kt + 4 < last ? kt + 4 : last))
+    __syncthreads();
+  }
+  if (kt < nk) G_COMPUTE(0)   // odd tail: tile nk-1 sits in LDS[0]
+#endif
 
   // ---- epilogue, staged through LDS: the MFMA fragment layout (one column, 16 scattered rows per lane) would give
   // 4-byte scattered global stores; each wave parks its 64x64 tile in LDS and re-reads it row-wise so that every
@@ -210,6 +268,186 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
       for (int j = 0; j < 4; ++j)
         if (n + j >= g.N) v[j] = 0.f;                 // pad columns of the planes are zero
       if (g.rope_cis) {   // columns (n, n+1), (n+2, n+3) are complex pairs (apply_rotary_enc, position_encoding.py:196-220)
+        const int t = m % g.rope_L;
+        if (t < g.rope_n) {
+          const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
+          const float a0 = v[0] * c.x - v[1] * c.y, a1 = v[0] * c.y + v[1] * c.x;
+          const float a2 = v[2] * c.z - v[3] * c.w, a3 = v[2] * c.w + v[3] * c.z;
+          v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+        }
+      }
+      uint2 h, l;
+      h.x = cvt_pk_bf16(v[0], v[1]);
+      h.y = cvt_pk_bf16(v[2], v[3]);
+      l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
+      l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
+      *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
+      *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// BK = 64 variant: every staged row is one full 128-byte line per plane (BK = 32 rows are 64-byte half lines, which
+// the texture-addresser path fetches at about half efficiency).  One LDS buffer (72 KiB, two blocks per CU) +
+// register prefetch of the next K tile; two barriers per 64-deep K tile.
+constexpr int BK64 = 64, ROWB64 = 144, PLANE64 = BM * ROWB64;   // 128 B data + 16 B pad per row
+
+__global__ __launch_bounds__(256, 2) void k_gemm_split64(GemmSplitArgs g, int mt, int nt) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][PLANE64];   // [A/B][hi/lo]
+
+  const int nwg = mt * nt;
+  const int orig = blockIdx.x;
+  const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
+  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  const int tile_m = wg / nt, tile_n = wg % nt;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, half = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // staging: a plane tile is 128 rows x 8 uint4; thread -> rows (tid>>3) + 32 i, part tid&7: a wave instruction
+  // fetches 8 complete 128-byte lines
+  const int srow = tid >> 3, spart = tid & 7;
+  const uint4 *pah[4], *pal[4], *pbh[4], *pbl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ma = m0 + srow + 32 * i, nb = n0 + srow + 32 * i;
+    ma = ma < g.M ? ma : g.M - 1;
+    nb = nb < g.N ? nb : g.N - 1;
+    pah[i] = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma * g.lda) + spart;
+    pal[i] = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma * g.lda) + spart;
+    pbh[i] = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb * g.ldw) + spart;
+    pbl[i] = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb * g.ldw) + spart;
+  }
+  const int nk = (g.Kp + BK64 - 1) / BK64;
+  const int kq = g.Kp / 8;   // uint4 per row; the last K tile may be half (Kp is a multiple of 32): clamp the part index
+  uint4 ah0, ah1, ah2, ah3, al0, al1, al2, al3, bh0, bh1, bh2, bh3, bl0, bl1, bl2, bl3;
+#define G64_LOAD(kt)                                                                   \
+  {                                                                                    \
+    int ko = (kt) * 8;                                                                 \
+    const bool tail_ = ko + spart >= kq;      /* second half of a 32-wide last tile: feed zeros */ \
+    ko = tail_ ? 0 : ko;                                                               \
+    ah0 = pah[0][ko]; ah1 = pah[1][ko]; ah2 = pah[2][ko]; ah3 = pah[3][ko];            \
+    al0 = pal[0][ko]; al1 = pal[1][ko]; al2 = pal[2][ko]; al3 = pal[3][ko];            \
+    bh0 = pbh[0][ko]; bh1 = pbh[1][ko]; bh2 = pbh[2][ko]; bh3 = pbh[3][ko];            \
+    bl0 = pbl[0][ko]; bl1 = pbl[1][ko]; bl2 = pbl[2][ko]; bl3 = pbl[3][ko];            \
+    if (tail_) {                                                                       \
+      const uint4 z_ = make_uint4(0, 0, 0, 0);                                         \
+      ah0 = ah1 = ah2 = ah3 = al0 = al1 = al2 = al3 = z_;                              \
+      bh0 = bh1 = bh2 = bh3 = bl0 = bl1 = bl2 = bl3 = z_;                              \
+    }                                                                                  \
+  }
+#define G64_ST(OP, PL, I, V) *reinterpret_cast<uint4*>(&lds[OP][PL][(srow + 32 * (I)) * ROWB64 + spart * 16]) = V;
+#define G64_STORE()                                                                    \
+  {                                                                                    \
+    G64_ST(0, 0, 0, ah0) G64_ST(0, 0, 1, ah1) G64_ST(0, 0, 2, ah2) G64_ST(0, 0, 3, ah3) \
+    G64_ST(0, 1, 0, al0) G64_ST(0, 1, 1, al1) G64_ST(0, 1, 2, al2) G64_ST(0, 1, 3, al3) \
+    G64_ST(1, 0, 0, bh0) G64_ST(1, 0, 1, bh1) G64_ST(1, 0, 2, bh2) G64_ST(1, 0, 3, bh3) \
+    G64_ST(1, 1, 0, bl0) G64_ST(1, 1, 1, bl1) G64_ST(1, 1, 2, bl2) G64_ST(1, 1, 3, bl3) \
+  }
+
+  G64_LOAD(0)
+  G64_STORE()
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    G64_LOAD(kt + 1 < nk ? kt + 1 : kt)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int koff = s4 * 32 + half * 16;
+      bf16x8 fa0[2], fa1[2], fb0[2], fb1[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ar = (wm * 64 + t * 32 + l31) * ROWB64 + koff;
+        const int br = (wn * 64 + t * 32 + l31) * ROWB64 + koff;
+        fa0[t] = *reinterpret_cast<const bf16x8*>(&lds[0][0][ar]);
+        fa1[t] = *reinterpret_cast<const bf16x8*>(&lds[0][1][ar]);
+        fb0[t] = *reinterpret_cast<const bf16x8*>(&lds[1][0][br]);
+        fb1[t] = *reinterpret_cast<const bf16x8*>(&lds[1][1][br]);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[tm], fb0[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb1[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb0[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+    __syncthreads();          // every wave is done reading this K tile
+    G64_STORE()
+    __syncthreads();
+  }
+
+  // ---- epilogue (same LDS-staged, coalesced form as k_gemm_split)
+  constexpr int EPLD = 68;
+  float* ep = reinterpret_cast<float*>(&lds[0][0][0]) + wave * (64 * EPLD);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ep[(tm * 32 + mfma32_row(e, half)) * EPLD + tn * 32 + l31] = acc[tm][tn][e];
+  __syncthreads();
+  const int c4 = lane & 15, r0 = lane >> 4;
+  const int n = n0 + wn * 64 + c4 * 4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  {
+    float* bp = reinterpret_cast<float*>(&bias4);
+    float* gp = reinterpret_cast<float*>(&gam4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (g.bias && n + j < g.N) bp[j] = g.bias[n + j];
+      if (g.gamma && n + j < g.N) gp[j] = g.gamma[n + j];
+    }
+  }
+  const bool vec_ok = (n + 3 < g.N);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int rr = it * 4 + r0;
+    const int m = m0 + wm * 64 + rr;
+    if (m >= g.M) continue;
+    const float4 a4 = *reinterpret_cast<const float4*>(&ep[rr * EPLD + c4 * 4]);
+    float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
+                  ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
+    if (g.R) {
+      const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
+      const float* rp = g.R + (size_t)rm * g.ldr + n;
+      if (vec_ok && (g.ldr & 3) == 0) {
+        const float4 r4 = *reinterpret_cast<const float4*>(rp);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < g.N) v[j] += rp[j];
+      }
+    }
+    if (g.C) {
+      float* cp = g.C + (size_t)m * g.ldc + n;
+      if (vec_ok && (g.ldc & 3) == 0) {
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n + j < g.N) cp[j] = v[j];
+      }
+    }
+    if (g.C_hi && n < g.ldcp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n + j >= g.N) v[j] = 0.f;
+      if (g.rope_cis) {
         const int t = m % g.rope_L;
         if (t < g.rope_n) {
           const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
@@ -389,6 +627,12 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
+  static const bool bk64 = [] { const char* e = getenv("DS2_GEMM_KERNEL"); return e && strcmp(e, "bk64") == 0; }();
+  if (bk64 && g.Kp >= 64) {
+    hipLaunchKernelGGL(k_gemm_split64, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
   static const bool glds = [] { const char* e = getenv("DS2_GEMM_KERNEL"); return e && strcmp(e, "glds") == 0; }();
   if (glds) {
     hipLaunchKernelGGL(k_gemm_glds, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);

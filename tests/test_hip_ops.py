@@ -69,6 +69,9 @@ def test_layernorm(ops, rows, C, act):
     (2, 1, 256, 256, 200, 300),
     (2, 1, 256, 64, 130, 1000),
     (3, 8, 16, 16, 9, 500),
+    (3, 8, 16, 16, 9, 4096),    # few queries x many keys: split-key path (attention_fewq.hip)
+    (2, 8, 16, 16, 16, 1100),   # ... ragged last key chunk, Lq at the path's maximum
+    (2, 4, 32, 32, 7, 1024),
     (3, 8, 16, 16, 500, 9),
     (2, 8, 32, 32, 9, 9),
     (1, 2, 72, 72, 256, 256),
