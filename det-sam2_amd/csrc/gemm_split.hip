@@ -122,11 +122,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
       fb1[t] = *reinterpret_cast<const bf16x8*>(&lds[cur][1][1][br]);                     \
     }                                                                                     \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
-      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                  \
+      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                    \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[tm], fb0[tn], acc[tm][tn], 0, 0, 0); \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
+      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                    \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb1[tn], acc[tm][tn], 0, 0, 0); \
+    _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
+      _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                    \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb0[tn], acc[tm][tn], 0, 0, 0); \
-      }                                                                                   \
   }
 
 #if DS2_GEMM_INTERLEAVE == 0
@@ -167,11 +170,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
   }
 #define G_MFMA(A0, A1, B0, B1)                                                            \
   _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
-    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) {                                    \
+    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                      \
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[tm], B0[tn], acc[tm][tn], 0, 0, 0); \
+  _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
+    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                      \
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B1[tn], acc[tm][tn], 0, 0, 0); \
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B0[tn], acc[tm][tn], 0, 0, 0); \
-    }
+  _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
+    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                      \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B0[tn], acc[tm][tn], 0, 0, 0);
 #define G_ITER(cur, nxt, P, ktl)                                                          \
   {                                                                                       \
     bf16x8 fa0[2], fa1[2], fb0[2], fb1[2], ga0[2], ga1[2], gb0[2], gb1[2];                \
@@ -626,6 +632,26 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
               "gemm_split: bad dims M=%d N=%d Kp=%d lda=%d ldw=%d", g.M, g.N, g.Kp, g.lda, g.ldw);
   DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
+  // Block-tile choice.  All variants are bound by the global->LDS operand path (~12-19 B/clk/CU measured; a bf16x3
+  // operand element is 4 bytes), so larger tiles win whenever they still fill the 256 CUs; cost model calibrated
+  // with tools/gemm_ablate.sh: cost = rounds * block_work / efficiency with efficiencies 1 : 1.15 : 1.28 for
+  // 128x128 (2 blocks/CU) : 256x128 three-stage ring : 256x256.
+  static const int tile_env = [] { const char* e = getenv("DS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  int tile = tile_env;
+  if (tile == 0) {
+    const int ncols = g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N;
+    const long b128 = (long)cdiv(g.M, 128) * cdiv(ncols, 128);
+    const long br3 = (long)cdiv(g.M, 256) * cdiv(ncols, 128);
+    const long b256 = (long)cdiv(g.M, 256) * cdiv(ncols, 256);
+    const double c128 = 2.0 * (double)((b128 + 511) / 512);
+    const double cr3 = br3 >= 256 ? 2.0 / 1.15 * (double)((br3 + 255) / 256) : 1e30;
+    const double c256 = b256 >= 256 ? 4.0 / 1.28 * (double)((b256 + 255) / 256) : 1e30;
+    tile = 1;
+    if (cr3 < c128 && cr3 <= c256) tile = 3;
+    if (c256 < c128 && c256 < cr3) tile = 4;
+  }
+  if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
+  if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
   static const bool bk64 = [] { const char* e = getenv("DS2_GEMM_KERNEL"); return e && strcmp(e, "bk64") == 0; }();
   if (bk64 && g.Kp >= 64) {
