@@ -43,6 +43,8 @@ SIGNATURES = {
     "ds2_memory_attention": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp]),
     "ds2_sam_heads": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ds2_memory_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
+    "ds2_connected_components": (C.c_int, [c_vp, i32, i32, i32, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_fill_holes": (C.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
     "ds2_mask_output": (C.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
     "ds2_set_precision": (C.c_int, [i32]),
     "ds2_get_precision": (C.c_int, []),

@@ -37,4 +37,6 @@ def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode=
     if mode != "eval":
         raise NotImplementedError("inference only (mode='eval')")
     dev = "cuda:0" if device in ("cuda", None) else str(device)
-    return SAM2VideoPredictor(cfg, _load_state_dict(cfg, ckpt_path), device=dev, max_batch=kwargs.get("max_batch", 16))
+    # build_sam.py:134 appends ++model.fill_hole_area=8 when apply_postprocessing (hole filling of the low-res masks)
+    return SAM2VideoPredictor(cfg, _load_state_dict(cfg, ckpt_path), device=dev, max_batch=kwargs.get("max_batch", 16),
+                              fill_hole_area=kwargs.get("fill_hole_area", cfg.fill_hole_area))

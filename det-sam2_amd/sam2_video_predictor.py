@@ -30,8 +30,12 @@ NO_OBJ_SCORE = -1024.0  # sam2_base.py:21
 
 
 class SAM2VideoPredictor:
-    def __init__(self, cfg, state_dict, device="cuda:0", max_batch=16):
+    def __init__(self, cfg, state_dict, device="cuda:0", max_batch=16, fill_hole_area=0):
         self.cfg = resolve_config(cfg)
+        # sam2_video_predictor.py:26,37: class default 0; build_sam2_video_predictor passes 8 (build_sam.py:134).
+        # The reference applies it only when its CUDA extension is present (misc.py:389-391: the CPU reference, and
+        # therefore the committed goldens, skip it) - here it is always applied when > 0 (HIP kernel, A14).
+        self.fill_hole_area = int(fill_hole_area)
         self.hip = HipSam2(self.cfg, state_dict, device, max_batch)
         self.device = self.hip.device
         self.image_size = self.cfg.image_size
@@ -234,6 +238,7 @@ class SAM2VideoPredictor:
         multimask = self.cfg.multimask_min_pt_num <= npts <= self.cfg.multimask_max_pt_num   # _use_multimask :922-932
         low, ptr, obj, _ = self.hip.sam_heads(1, f2, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
                                               pix_bcast=True, add_no_mem_embed=True)
+        low = self._fill_holes(low)
         obj_tmp["cond_frame_outputs"][frame_idx] = {
             "maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1),
             "obj_ptr": ptr, "object_score_logits": obj.unsqueeze(1)}
@@ -381,6 +386,13 @@ class SAM2VideoPredictor:
             self.trace.append(tr)
         return mem_entries, ptr_entries
 
+    def _fill_holes(self, low):
+        """fill_holes_in_mask_scores on the low-res logits [B,256,256] (sam2_video_predictor.py:1343-1346)."""
+        if self.fill_hole_area <= 0:
+            return low
+        from .misc import fill_holes_in_mask_scores
+        return fill_holes_in_mask_scores(low, self.fill_hole_area)
+
     def _track_frame(self, st, frame_idx, B, reverse):
         """_run_single_frame_inference + track_step for a non-conditioning frame (is_init_cond_frame=False,
         no prompts, run_mem_encoder=True)  (sam2_video_predictor.py:1280-1365; sam2_base.py:857-919)."""
@@ -390,7 +402,7 @@ class SAM2VideoPredictor:
         pix = self.hip.memory_attention(B, f2, memory, memory_pos, 4 * len(ptr_entries))
         low, ptr, obj, _ = self.hip.sam_heads(B, pix, f0, f1, None, None, multimask=True)   # num_pts=0 => multimask
         mem = self.hip.memory_encoder(B, f2, low, obj, binarize=False)
-        # NOTE fill_holes_in_mask_scores (misc.py:365-393) is a silent no-op in the CPU reference => not applied
+        low = self._fill_holes(low)   # after the memory encoder, as in _run_single_frame_inference (:1343-1346)
         self.stats["tracked_frames"] += 1
         return {"maskmem_features": mem, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1), "obj_ptr": ptr,
                 "object_score_logits": obj.unsqueeze(1)}

@@ -113,6 +113,19 @@ int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bc
 int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, const float* low_res, const float* obj_logits,
                        int32_t binarize, uint16_t* maskmem_bf16, void* stream);
 
+/* ---- A14: sam2._C.get_connected_componnets (sam2/csrc/connected_components.cu:213-289; the reference's only native
+ * op, called from sam2/utils/misc.py:48-61).  mask uint8 [N,1,H,W] (non-zero = foreground) -> labels int32
+ * [N,1,H,W] (> 0 and equal exactly inside one 8-connected component, 0 on background; here the component's
+ * smallest raster index + 1) and counts int32 [N,1,H,W] (component area per pixel, 0 on background).
+ * work: int32 scratch of 2*N*H*W elements.  Any H, W (the reference requires even sizes). */
+int ds2_connected_components(const uint8_t* mask, int32_t N, int32_t H, int32_t W, int32_t* labels, int32_t* counts,
+                             int32_t* work, void* stream);
+
+/* ---- A14: fill_holes_in_mask_scores (sam2/utils/misc.py:365-393; sam2_video_predictor.py:1343-1346): in place on
+ * logits fp32 [N,1,H,W]: every 8-connected component of {logit <= 0} with area <= max_area gets logit 0.1.
+ * work: int32 scratch of 3*N*H*W elements.  max_area <= 0 is an error (misc.py:371). */
+int ds2_fill_holes(float* logits, int32_t N, int32_t H, int32_t W, int32_t max_area, int32_t* work, void* stream);
+
 /* ---- A15: _get_orig_video_res_output (sam2_video_predictor.py:618-642) + `> 0` (det_sam2_RT.py:396-399):
  * low_res [B,256,256] -> logits fp32 [B,Hv,Wv] (may be NULL) and/or masks packed 8 px/byte, MSB first
  * (numpy.packbits order) [B,Hv,Wv/8] (may be NULL). */

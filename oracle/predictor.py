@@ -58,8 +58,11 @@ def select_closest_cond_frames(frame_idx, cond, max_num, preload_idx=None):
 class OraclePredictor:
     """Functional counterpart of SAM2VideoPredictor(SAM2Base) for the hot path."""
 
-    def __init__(self, sd, cfg):
+    def __init__(self, sd, cfg, fill_hole_area=0):
         self.sd, self.cfg = sd, cfg
+        # 0 = what the CPU reference does (its CUDA-only extension is missing => misc.py:389-391 skips the step);
+        # > 0 = the reference's behaviour WITH the extension, restated in oracle/cc.py
+        self.fill_hole_area = fill_hole_area
         self.image_size = cfg.image_size
         self.hidden_dim, self.mem_dim = cfg.d_model, cfg.mem_dim
         self.num_maskmem = cfg.num_maskmem
@@ -431,10 +434,14 @@ class OraclePredictor:
         f = cur["maskmem_features"]
         if f is not None:
             f = f.to(torch.bfloat16)
+        pm = cur["pred_masks"]
+        if self.fill_hole_area > 0:   # sam2_video_predictor.py:1343-1346
+            from .cc import fill_holes_in_mask_scores
+            pm = torch.from_numpy(fill_holes_in_mask_scores(pm.numpy(), self.fill_hole_area))
         compact = {"maskmem_features": f, "maskmem_pos_enc": self.maskmem_pos_enc(st, cur["maskmem_pos_enc"]),
-                   "pred_masks": cur["pred_masks"], "obj_ptr": cur["obj_ptr"],
+                   "pred_masks": pm, "obj_ptr": cur["obj_ptr"],
                    "object_score_logits": cur["object_score_logits"]}
-        return compact, cur["pred_masks"]
+        return compact, pm
 
     def propagate_in_video(self, st, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
         """propagate_in_video (sam2_video_predictor.py:911-1025); generator."""

@@ -16,8 +16,8 @@ from .predictor import OraclePredictor
 class OracleVideoProcessor:
     def __init__(self, sd, cfg, detector, skip_classes=frozenset({11, 14, 15, 19}), frame_buffer_size=30,
                  detect_interval=30, max_frame_num_to_track=60, max_inference_state_frames=60,
-                 release_images=True):
-        self.predictor = OraclePredictor(sd, cfg)
+                 release_images=True, fill_hole_area=0):
+        self.predictor = OraclePredictor(sd, cfg, fill_hole_area=fill_hole_area)
         self.detector = detector
         self.skip_classes = set(skip_classes)
         self.frame_buffer_size, self.detect_interval = frame_buffer_size, detect_interval
