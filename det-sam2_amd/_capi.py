@@ -42,6 +42,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_float), c_vp, c_vp, c_vp]),
     "ds2_memory_attention": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp]),
     "ds2_sam_heads": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_sam_heads_mask": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, c_vp, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ds2_memory_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
     "ds2_connected_components": (C.c_int, [c_vp, i32, i32, i32, c_vp, c_vp, c_vp, c_vp]),
     "ds2_fill_holes": (C.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),

@@ -565,6 +565,68 @@ __global__ void k_mask_output(const float* low, int B, int hin, int Hv, int Wv, 
 
 inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
+
+// ---- PromptEncoder._embed_masks (prompt_encoder.py:97-100, mask_downscaling :60-68): mask logits [B,256,256] ->
+// dense prompt embedding [B,64*64,256]: conv2x2 s2 (1->4) + LayerNorm2d + GELU, conv2x2 s2 (4->16) + LayerNorm2d +
+// GELU, conv1x1 (16->256); fused with src = image_embedding + dense (mask_decoder.py:203).  One block per token.
+struct MaskDownArgs {
+  const float *w0, *b0, *ln1w, *ln1b, *w3, *b3, *ln4w, *ln4b, *w6, *b6;
+};
+__global__ __launch_bounds__(256) void k_mask_downscale_add(const float* mask, MaskDownArgs a, const float* src, int src_bcast,
+                                                            float* keys) {
+  __shared__ float in[16], v1[16], g1[16], v2[16], g2[16];
+  const int tok = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const int ty = tok >> 6, tx = tok & 63;
+  if (t < 16) in[t] = mask[((size_t)b * 256 + ty * 4 + (t >> 2)) * 256 + tx * 4 + (t & 3)];
+  __syncthreads();
+  if (t < 16) {   // t = position p (py, px) * 4 + channel c
+    const int p = t >> 2, c = t & 3, py = p >> 1, px = p & 1;
+    float acc = a.b0[c];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) acc = fmaf(a.w0[c * 4 + dy * 2 + dx], in[(py * 2 + dy) * 4 + px * 2 + dx], acc);
+    v1[t] = acc;
+  }
+  __syncthreads();
+  if (t < 16) {   // LayerNorm2d over the 4 channels of the position (sam2_utils.py:150-162, eps 1e-6) + GELU
+    const int p = t >> 2, c = t & 3;
+    const float u = 0.25f * (v1[p * 4] + v1[p * 4 + 1] + v1[p * 4 + 2] + v1[p * 4 + 3]);
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s2 += (v1[p * 4 + k] - u) * (v1[p * 4 + k] - u);
+    const float x = (v1[t] - u) / sqrtf(0.25f * s2 + 1e-6f);
+    g1[t] = ds2_act(a.ln1w[c] * x + a.ln1b[c], DS2_ACT_GELU);
+  }
+  __syncthreads();
+  if (t < 16) {   // conv 4->16 over the 2x2 positions: weight [16][4][2][2]
+    float acc = a.b3[t];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc = fmaf(a.w3[(t * 4 + c) * 4 + p], g1[p * 4 + c], acc);
+    v2[t] = acc;
+  }
+  __syncthreads();
+  if (t < 16) {
+    float u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u += v2[k];
+    u *= 0.0625f;
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s2 += (v2[k] - u) * (v2[k] - u);
+    const float x = (v2[t] - u) / sqrtf(0.0625f * s2 + 1e-6f);
+    g2[t] = ds2_act(a.ln4w[t] * x + a.ln4b[t], DS2_ACT_GELU);
+  }
+  __syncthreads();
+  float acc = a.b6[t];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc = fmaf(a.w6[t * 16 + c], g2[c], acc);
+  const size_t o = ((size_t)b * 4096 + tok) * 256 + t;
+  keys[o] = src[src_bcast ? (size_t)tok * 256 + t : o] + acc;
+}
+
 }  // namespace
 
 // ====================================================================== launchers
@@ -736,6 +798,14 @@ int launch_bank_ptr(const BankArgs& a, const float* dim_t, hipStream_t st) {
 int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits, uint8_t* packed, hipStream_t st) {
   DS2_REQUIRE(Wv % 8 == 0, "mask_output: video width must be a multiple of 8 (got %d)", Wv);
   hipLaunchKernelGGL(k_mask_output, grid1((size_t)B * Hv * (Wv / 8)), dim3(256), 0, st, low, B, hin, Hv, Wv, logits, packed);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
+int launch_mask_downscale_add(const float* mask, const float* const* prm, const float* src, int src_bcast, float* keys, int B,
+                              hipStream_t st) {
+  MaskDownArgs a{prm[0], prm[1], prm[2], prm[3], prm[4], prm[5], prm[6], prm[7], prm[8], prm[9]};
+  hipLaunchKernelGGL(k_mask_downscale_add, dim3(4096, B), dim3(256), 0, st, mask, a, src, src_bcast, keys);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

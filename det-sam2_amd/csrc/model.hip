@@ -805,6 +805,14 @@ extern "C" int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int
                              const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
                              int32_t P, int32_t multimask, float* low_res, float* obj_ptr, float* obj_logits, float* ious,
                              void* stream) {
+  return ds2_sam_heads_mask(m, B, pix_feat, pix_bcast, add_no_mem_embed, fpn0, fpn1, point_coords, point_labels, P, nullptr,
+                            multimask, low_res, obj_ptr, obj_logits, ious, stream);
+}
+
+extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
+                                  const float* fpn0, const float* fpn1, const float* point_coords,
+                                  const int32_t* point_labels, int32_t P, const float* mask_inputs, int32_t multimask,
+                                  float* low_res, float* obj_ptr, float* obj_logits, float* ious, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && pix_feat && fpn0 && fpn1 && low_res && obj_ptr && obj_logits,
               "ds2_sam_heads: bad argument");
   DS2_REQUIRE(P >= 0 && P <= 8 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
@@ -835,17 +843,24 @@ extern "C" int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int
                            1024.f, tokens, st));
   // src = image_embeddings + dense_prompt (no_mask_embed broadcast)  (mask_decoder.py:203)
   ALLOC(keys, (size_t)rows * 256);
-  if (pix_bcast) {
-    const float* src = pix_feat;
-    if (add_no_mem_embed) {   // directly_add_no_mem_embed (sam2_base.py:651-657)
-      ALLOC(pm, (size_t)TOK * 256);
-      TRY(launch_add_rowvec(pix_feat, 256, m->P("no_mem_embed"), pm, 256, TOK, 256, st));
-      src = pm;
-    }
+  const float* src = pix_feat;
+  if (pix_bcast && add_no_mem_embed) {   // directly_add_no_mem_embed (sam2_base.py:651-657)
+    ALLOC(pm, (size_t)TOK * 256);
+    TRY(launch_add_rowvec(pix_feat, 256, m->P("no_mem_embed"), pm, 256, TOK, 256, st));
+    src = pm;
+  }
+  DS2_REQUIRE(pix_bcast || !add_no_mem_embed, "ds2_sam_heads: add_no_mem_embed requires pix_bcast");
+  if (mask_inputs) {   // dense prompt = mask_downscaling(mask) instead of no_mask_embed (prompt_encoder.py:97-100,163-168)
+    const std::string pe = "sam_prompt_encoder.mask_downscaling.";
+    const float* prm[10] = {m->P(pe + "0.weight"), m->P(pe + "0.bias"), m->P(pe + "1.weight"), m->P(pe + "1.bias"),
+                            m->P(pe + "3.weight"), m->P(pe + "3.bias"), m->P(pe + "4.weight"), m->P(pe + "4.bias"),
+                            m->P(pe + "6.weight"), m->P(pe + "6.bias")};
+    for (int i = 0; i < 10; ++i) DS2_REQUIRE(prm[i], "ds2_sam_heads: mask_downscaling parameter %d missing", i);
+    TRY(launch_mask_downscale_add(mask_inputs, prm, src, pix_bcast ? 1 : 0, keys, B, st));
+  } else if (pix_bcast) {
     for (int b = 0; b < B; ++b)
       TRY(launch_add_rowvec(src, 256, m->P("@dense_vec"), keys + (size_t)b * TOK * 256, 256, TOK, 256, st));
   } else {
-    DS2_REQUIRE(!add_no_mem_embed, "ds2_sam_heads: add_no_mem_embed requires pix_bcast");
     TRY(launch_add_rowvec(pix_feat, 256, m->P("@dense_vec"), keys, 256, rows, 256, st));
   }
   ALLOC(queries, (size_t)B * T * 256);

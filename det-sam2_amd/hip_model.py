@@ -183,17 +183,22 @@ class HipSam2(HipOps):
         return out
 
     def sam_heads(self, B, pix_feat, fpn0, fpn1, point_coords=None, point_labels=None, multimask=False,
-                  pix_bcast=False, add_no_mem_embed=False):
-        """-> low_res [B,256,256], obj_ptr [B,256], obj_logits [B], ious [B] (A7+A8)."""
+                  pix_bcast=False, add_no_mem_embed=False, mask_inputs=None):
+        """-> low_res [B,256,256], obj_ptr [B,256], obj_logits [B], ious [B] (A7+A8).  mask_inputs [B,256,256]:
+        optional mask prompt (logits) for the prompt encoder's dense embedding."""
         P = 0 if point_coords is None else point_coords.shape[1]
         low, ptr = self._empty(B, 256, 256), self._empty(B, 256)
         obj, iou = self._empty(B), self._empty(B)
         if P:
             assert point_coords.dtype == torch.float32 and point_labels.dtype == torch.int32
             point_coords, point_labels = point_coords.contiguous(), point_labels.contiguous()
-        _capi.check(self.lib.ds2_sam_heads(self.h, B, _p(pix_feat), int(pix_bcast), int(add_no_mem_embed), _p(fpn0), _p(fpn1),
-                                           _p(point_coords), _p(point_labels), P, int(multimask), _p(low), _p(ptr), _p(obj),
-                                           _p(iou), self._stream()), "ds2_sam_heads")
+        if mask_inputs is not None:
+            assert mask_inputs.dtype == torch.float32 and tuple(mask_inputs.shape) == (B, 256, 256), mask_inputs.shape
+            mask_inputs = mask_inputs.contiguous()
+        _capi.check(self.lib.ds2_sam_heads_mask(self.h, B, _p(pix_feat), int(pix_bcast), int(add_no_mem_embed), _p(fpn0),
+                                                _p(fpn1), _p(point_coords), _p(point_labels), P, _p(mask_inputs),
+                                                int(multimask), _p(low), _p(ptr), _p(obj), _p(iou), self._stream()),
+                    "ds2_sam_heads_mask")
         return low, ptr, obj, iou
 
     def memory_encoder(self, B, fpn2, low_res, obj_logits, binarize):

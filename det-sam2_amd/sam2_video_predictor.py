@@ -229,15 +229,17 @@ class SAM2VideoPredictor:
         obj_tmp, obj_out = st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]
         prev = obj_tmp["cond_frame_outputs"].get(frame_idx) or obj_out["cond_frame_outputs"].get(frame_idx) \
             or obj_out["non_cond_frame_outputs"].get(frame_idx)
+        # a second prompt for the same object on the same frame (e.g. YOLO emits two boxes of one class): the previous
+        # prediction, clamped to [-32, 32], is fed back as a mask prompt (sam2_video_predictor.py:470-483)
+        prev_logits = None
         if prev is not None and prev["pred_masks"] is not None:
-            raise NotImplementedError("a second prompt for the same object on the same frame needs the mask-prompt path "
-                                      "(prev_sam_mask_logits, sam2_video_predictor.py:470-483): next row F3")
+            prev_logits = torch.clamp(prev["pred_masks"].to(self.device, torch.float32), -32.0, 32.0).reshape(1, 256, 256)
         # single-object SAM pass without memory (is_init_cond_frame): pix = feat + no_mem_embed (sam2_base.py:651-657)
         f0, f1, f2 = self._get_image_feature(st, frame_idx)
         npts = pin["point_labels"].shape[1]
         multimask = self.cfg.multimask_min_pt_num <= npts <= self.cfg.multimask_max_pt_num   # _use_multimask :922-932
         low, ptr, obj, _ = self.hip.sam_heads(1, f2, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
-                                              pix_bcast=True, add_no_mem_embed=True)
+                                              pix_bcast=True, add_no_mem_embed=True, mask_inputs=prev_logits)
         low = self._fill_holes(low)
         obj_tmp["cond_frame_outputs"][frame_idx] = {
             "maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1),

@@ -40,11 +40,14 @@ def synthetic_box(obj: int, frame_idx: int, seed: int = 0, size: int = 1024) -> 
 
 class SyntheticDetector:
     """Callable ``(frame_abs_idx, frame_rgb) -> list[detection dict]`` at the YOLO output contract
-    (det_sam2_RT.py:228-244).  ``appear`` maps object id -> first frame on which it is detected."""
+    (det_sam2_RT.py:228-244).  ``appear`` maps object id -> first frame on which it is detected; ``duplicates``
+    maps object id -> number of EXTRA detections of that class per frame (YOLO emitting several boxes of one class:
+    every further box is a second prompt for the same object on the same frame, sam2_video_predictor.py:470-483)."""
 
-    def __init__(self, num_objects: int, seed: int = 0, size: int = 1024, appear=None):
+    def __init__(self, num_objects: int, seed: int = 0, size: int = 1024, appear=None, duplicates=None):
         self.num_objects, self.seed, self.size = num_objects, seed, size
         self.appear = dict(appear or {})
+        self.duplicates = dict(duplicates or {})
 
     def __call__(self, frame_idx, frame=None):
         out = []
@@ -54,4 +57,8 @@ class SyntheticDetector:
             out.append({"coordinates": synthetic_box(o, frame_idx, self.seed, self.size),
                         "class": np.array([float(o)], np.float32),
                         "confidence": np.array([0.99], np.float32)})
+            for k in range(self.duplicates.get(o, 0)):   # same class, a differently jittered box
+                out.append({"coordinates": synthetic_box(o, frame_idx + 1000 * (k + 1), self.seed, self.size),
+                            "class": np.array([float(o)], np.float32),
+                            "confidence": np.array([0.9], np.float32)})
         return out

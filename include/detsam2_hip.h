@@ -106,6 +106,16 @@ int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bc
                   int32_t P, int32_t multimask_output, float* low_res, float* obj_ptr, float* obj_logits,
                   float* ious, void* stream);
 
+/* ---- A7+A8 with a MASK prompt: same as ds2_sam_heads plus mask_inputs fp32 [B,256,256] (logits at the prompt
+ * encoder's mask_input_size) whose PromptEncoder._embed_masks / mask_downscaling embedding
+ * (prompt_encoder.py:60-68,97-100,163-168) replaces no_mask_embed as the dense prompt.  Used for a second prompt on
+ * the same object and frame, where the reference feeds the previous prediction clamped to [-32,32] back in
+ * (prev_sam_mask_logits, sam2_video_predictor.py:470-483; sam2_base.py:776-782).  mask_inputs == NULL = ds2_sam_heads. */
+int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
+                       const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
+                       int32_t P, const float* mask_inputs, int32_t multimask_output, float* low_res, float* obj_ptr,
+                       float* obj_logits, float* ious, void* stream);
+
 /* ---- A13: SAM2Base._encode_new_memory (sam2_base.py:692-743) = 256->1024 bilinear upsample
  * (:355-360) + sigmoid|binarize, *20-10 + MemoryEncoder.forward (memory_encoder.py:158-181) +
  * no_obj_embed_spatial + bf16 storage.  fpn2 [4096,256] raw level-2 feature, low_res [B,256,256],

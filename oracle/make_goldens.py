@@ -141,6 +141,20 @@ def e2e_cfg1(name="sam2.1_hiera_t"):
     print("e2e_cfg1", dt, "s", out["frames"], passes, final_keys)
 
 
+def e2e_dup(name="sam2.1_hiera_t"):
+    """Two boxes of the SAME class on the prompted frame: the second add_new_points_or_box call feeds the first
+    call's clamped logits back as a mask prompt (prev_sam_mask_logits, sam2_video_predictor.py:470-483)."""
+    det = SyntheticDetector(2, duplicates={0: 1})
+    kw = dict(skip_classes=set(), frame_buffer_size=4, detect_interval=4, max_frame_num_to_track=4,
+              max_inference_state_frames=-1)
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 4, det, **kw)
+    out = {"seconds": np.float64(dt), "frames": np.array([y[1] for y in yields]),
+           "low": np.stack([y[3] for y in yields]),
+           "bits": np.stack([np.packbits(y[4]) for y in yields])}
+    np.savez_compressed(os.path.join(GOLD, "e2e_dup.npz"), **out)
+    print("e2e_dup", dt, "s", out["frames"], out["low"].shape, passes, final_keys)
+
+
 def e2e_stream2(name="sam2.1_hiera_t"):
     """Two-pass stream exercising second-visit tracking, release_old_frames and the online
     new-object path (A17): 8 frames, buffer 4, detect every 4, track 8, keep 6; objects 0,1 from

@@ -54,6 +54,27 @@ def test_config1_matches_reference(golden_dir, prec):
     assert vp.predictor.stats["encoder_runs"] == 8
 
 
+def test_duplicate_class_matches_reference(golden_dir, prec):
+    """Two boxes of one class on the prompted frame => second prompt with the first prediction as mask prompt."""
+    g = np.load(os.path.join(golden_dir, "e2e_dup.npz"))
+    vp = _vp(SyntheticDetector(2, duplicates={0: 1}), prec, frame_buffer_size=4, detect_interval=4, max_frame_num_to_track=4,
+             max_inference_state_frames=-1)
+    for t in range(4):
+        vp.process_frame(t, synthetic_frame(t))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    worst_iou, worst_logit = 0.0, 0.0
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].cpu().numpy()
+        worst_logit = max(worst_logit, float(np.abs(low - g["low"][i]).max()))
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            worst_iou = max(worst_iou, 1.0 - _iou(vp.video_segments[int(t)][o], ref[o]))
+    record("e2e_dup", prec=prec, one_minus_iou=worst_iou, max_abs_dlogit=worst_logit)
+    assert worst_iou <= 1e-3 and worst_logit <= (5e-3 if prec == "fp32" else 5e-2), (worst_iou, worst_logit)
+
+
 def test_stream2_matches_reference(golden_dir, prec):
     """Two passes, release_old_frames with image release, online new object (A17)."""
     g = np.load(os.path.join(golden_dir, "e2e_stream2.npz"))

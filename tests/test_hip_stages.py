@@ -137,6 +137,28 @@ def test_sam_heads(prompt, multimask, prec):
     assert max(e_low, e_ptr, e_obj) < TOL[prec], (e_low, e_ptr, e_obj)
 
 
+def test_sam_heads_with_mask_prompt(prec):
+    """box + mask prompt (second prompt on the same object/frame: prev_sam_mask_logits, sam2_video_predictor.py:470-483)."""
+    cfg, sd, hm = model("sam2.1_hiera_t", prec)
+    g = torch.Generator().manual_seed(6)
+    B = 2
+    feats = torch.randn(B, 256, 64, 64, generator=g)
+    hr0, hr1 = torch.randn(1, 32, 256, 256, generator=g), torch.randn(1, 64, 128, 128, generator=g)
+    pin = {"point_coords": torch.rand(B, 2, 2, generator=g) * 1024, "point_labels": torch.tensor([[2, 3]] * B, dtype=torch.int32)}
+    mask = torch.clamp(torch.randn(B, 1, 256, 256, generator=g) * 12, -32, 32)
+    with torch.inference_mode():
+        ref = OraclePredictor(sd, cfg).forward_sam_heads(feats, pin, mask, [hr0.expand(B, -1, -1, -1), hr1.expand(B, -1, -1, -1)], False)
+        ref0 = OraclePredictor(sd, cfg).forward_sam_heads(feats, pin, None, [hr0.expand(B, -1, -1, -1), hr1.expand(B, -1, -1, -1)], False)
+    d = hm.device
+    low, ptr, obj, iou = hm.sam_heads(B, nhwc(feats).to(d), nhwc(hr0)[0].to(d), nhwc(hr1)[0].to(d), pin["point_coords"].to(d),
+                                      pin["point_labels"].to(d), False, mask_inputs=mask[:, 0].contiguous().to(d))
+    torch.cuda.synchronize()
+    e_low, e_ptr, e_obj = rel_err(low, ref[3][:, 0]), rel_err(ptr, ref[5]), rel_err(obj, ref[6][:, 0])
+    record("sam_heads_mask", prec=prec, e_low=e_low, e_ptr=e_ptr, e_obj=e_obj, effect=rel_err(ref0[3], ref[3]))
+    assert rel_err(ref0[3], ref[3]) > 1e-2          # the mask prompt matters
+    assert max(e_low, e_ptr, e_obj) < TOL[prec], (e_low, e_ptr, e_obj)
+
+
 @pytest.mark.parametrize("binarize", [False, True])
 def test_memory_encoder(binarize, prec):
     cfg, sd, hm = model("sam2.1_hiera_t", prec)

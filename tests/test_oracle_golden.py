@@ -132,3 +132,25 @@ def test_e2e_stream2_matches_reference_golden(tiny, golden_dir):
         assert np.abs(low - g[f"low{i}"].astype(np.float32)).max() <= 2e-2 + 1e-3 * np.abs(low).max()
         ref_bits = np.unpackbits(g[f"bits{i}"])[: mask[:, :, ::2, ::2].size].reshape(mask[:, :, ::2, ::2].shape).astype(bool)
         assert 1.0 - _iou(mask[:, :, ::2, ::2], ref_bits) <= 1e-3
+
+
+def test_e2e_duplicate_class_matches_reference_golden(tiny, golden_dir):
+    """Two boxes of one class on the prompted frame: second prompt with prev_sam_mask_logits as mask prompt
+    (sam2_video_predictor.py:470-483; prompt_encoder mask_downscaling)."""
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_dup.npz"))
+    vp = OracleVideoProcessor(sd, cfg, SyntheticDetector(2, duplicates={0: 1}), skip_classes=set(), frame_buffer_size=4,
+                              detect_interval=4, max_frame_num_to_track=4, max_inference_state_frames=-1)
+    with torch.inference_mode():
+        for t in range(4):
+            vp.process_frame(t, synthetic_frame(t))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].numpy()
+        assert low.shape == g["low"][i].shape
+        assert np.abs(low - g["low"][i]).max() <= 2e-4
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            assert 1.0 - _iou(vp.video_segments[int(t)][o], ref[o]) <= 1e-3
