@@ -155,6 +155,55 @@ def e2e_dup(name="sam2.1_hiera_t"):
     print("e2e_dup", dt, "s", out["frames"], out["low"].shape, passes, final_keys)
 
 
+PRELOAD_A = dict(skip_classes=set(), frame_buffer_size=3, detect_interval=1, max_frame_num_to_track=3,
+                 max_inference_state_frames=-1)        # bank-building run: every frame is a conditioning frame
+PRELOAD_B = dict(skip_classes=set(), frame_buffer_size=4, detect_interval=-1, max_frame_num_to_track=4,
+                 max_inference_state_frames=-1)        # preloaded run: no detector, tracks from the bank alone
+
+
+def e2e_preload(name="sam2.1_hiera_t"):
+    """A18: run A builds a 3-frame bank (2 objects, a box on every frame) and pickles it with the reference's own
+    save_inference_state (det_sam2_RT.py:489-497); run B loads it through the prologue of VideoProcessor.run
+    (:539-549: load, mark preload cond frames, pre_frames, init_preloading_state) and tracks 4 new frames with
+    detect_interval=-1."""
+    det = SyntheticDetector(2)
+    vpa, ya, pa, ka, dta = _run_reference_stream(name, 3, det, **PRELOAD_A)
+    scratch = os.path.join(os.path.dirname(GOLD), "_scratch")      # inside the repo, removed below
+    os.makedirs(scratch, exist_ok=True)
+    tmp = os.path.join(scratch, "bank.pkl")
+    vpa.save_inference_state(tmp)
+    cfg = resolve_config(name)
+    vp = RS.make_reference_video_processor(f"configs/sam2.1/{name}.yaml", synthetic_state_dict(cfg, 0), **PRELOAD_B)
+    vp.inference_state = vp.load_inference_state(tmp)
+    od = vp.inference_state["output_dict"]
+    vp.inference_state["preloading_memory_cond_frame_idx"] = list(od["cond_frame_outputs"].keys())
+    vp.inference_state["preloading_memory_non_cond_frames_idx"] = list(od["non_cond_frame_outputs"].keys())
+    vp.pre_frames = vp.inference_state["num_frames"]
+    vp.predictor.init_preloading_state(vp.inference_state)
+    yields = []
+    orig = vp.predictor.propagate_in_video
+
+    def capturing(state, **kw):
+        for t, ids, logits in orig(state, **kw):
+            o = state["output_dict"]
+            key = "cond_frame_outputs" if t in o["cond_frame_outputs"] else "non_cond_frame_outputs"
+            yields.append((t, list(ids), o[key][t]["pred_masks"].clone().numpy(), (logits > 0).numpy()))
+            yield t, ids, logits
+
+    vp.predictor.propagate_in_video = capturing
+    t0 = time.time()
+    for i in range(4):
+        vp.process_frame(vp.pre_frames + i, synthetic_frame(100 + i))
+    dt = time.time() - t0
+    out = {"seconds": np.float64(dt), "frames": np.array([y[0] for y in yields]),
+           "low": np.stack([y[2] for y in yields]), "bits": np.stack([np.packbits(y[3]) for y in yields]),
+           "bank_low": np.stack([y[3] for y in ya])}
+    np.savez_compressed(os.path.join(GOLD, "e2e_preload.npz"), **out)
+    os.remove(tmp)
+    os.rmdir(scratch)
+    print("e2e_preload", dta, dt, "s", out["frames"], out["low"].shape, sorted(vp.video_segments))
+
+
 def e2e_stream2(name="sam2.1_hiera_t"):
     """Two-pass stream exercising second-visit tracking, release_old_frames and the online
     new-object path (A17): 8 frames, buffer 4, detect every 4, track 8, keep 6; objects 0,1 from
@@ -178,7 +227,7 @@ def e2e_stream2(name="sam2.1_hiera_t"):
 if __name__ == "__main__":
     assert RS.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["schema", "l1", "e2e_cfg1", "e2e_stream2"]
+    which = sys.argv[1:] or ["schema", "l1", "e2e_cfg1", "e2e_stream2", "e2e_dup", "e2e_preload"]
     torch.set_num_threads(8)
     for w in which:
         globals()[w]()

@@ -91,6 +91,25 @@ class OracleVideoProcessor:
             self.frame_buffer.clear()
         return self.inference_state
 
+    # ---- A18: preload memory bank (det_sam2_RT.py:489-503 and the prologue of run, :539-549)
+    def save_inference_state(self, save_path):
+        import pickle
+        with open(save_path, "wb") as f:
+            pickle.dump(self.inference_state, f)
+
+    def load_inference_state(self, load_path):
+        import pickle
+        with open(load_path, "rb") as f:
+            return pickle.load(f)
+
+    def preload(self, load_path):
+        """run() prologue :539-549 (init_preloading_state only moves tensors between devices: nothing to do on CPU)."""
+        self.inference_state = self.load_inference_state(load_path)
+        od = self.inference_state["output_dict"]
+        self.inference_state["preloading_memory_cond_frame_idx"] = list(od["cond_frame_outputs"].keys())
+        self.inference_state["preloading_memory_non_cond_frames_idx"] = list(od["non_cond_frame_outputs"].keys())
+        self.pre_frames = self.inference_state["num_frames"]
+
     def run(self, frames):
         """det_sam2_RT.py:526-615 for an in-memory RGB frame list (the cv2.VideoCapture loop :558-579)."""
         idx = 0

@@ -75,6 +75,31 @@ def test_duplicate_class_matches_reference(golden_dir, prec):
     assert worst_iou <= 1e-3 and worst_logit <= (5e-3 if prec == "fp32" else 5e-2), (worst_iou, worst_logit)
 
 
+def test_preload_bank_matches_reference(golden_dir, prec, tmp_path):
+    """A18: build a bank, pickle it (save_inference_state), preload it in a fresh VideoProcessor.run and track 4 new
+    frames without a detector; masks vs the reference's own preload run."""
+    from oracle.make_goldens import PRELOAD_A, PRELOAD_B
+    g = np.load(os.path.join(golden_dir, "e2e_preload.npz"))
+    bank = str(tmp_path / "bank.pkl")
+    a = _vp(SyntheticDetector(2), prec, save_inference_state_path=bank, **{k: v for k, v in PRELOAD_A.items() if k != "skip_classes"})
+    a.run(frames=[synthetic_frame(t) for t in range(3)])
+    assert os.path.getsize(bank) > 0
+    b = _vp(SyntheticDetector(2), prec, load_inference_state_path=bank, **{k: v for k, v in PRELOAD_B.items() if k != "skip_classes"})
+    segs = b.run(frames=[synthetic_frame(100 + i) for i in range(4)])
+    assert b.pre_frames == 3 and sorted(segs) == [0, 1, 2, 3]          # run() re-bases frame indices (:612)
+    assert b.pass_log[0][1] == list(g["frames"])
+    od = b.inference_state["output_dict"]
+    worst_iou, worst_logit = 0.0, 0.0
+    for i, t in enumerate(g["frames"]):
+        low = od["non_cond_frame_outputs"][int(t)]["pred_masks"].cpu().numpy()
+        worst_logit = max(worst_logit, float(np.abs(low - g["low"][i]).max()))
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            worst_iou = max(worst_iou, 1.0 - _iou(segs[int(t) - 3][o], ref[o]))
+    record("e2e_preload", prec=prec, one_minus_iou=worst_iou, max_abs_dlogit=worst_logit)
+    assert worst_iou <= 1e-3 and worst_logit <= (5e-3 if prec == "fp32" else 5e-2), (worst_iou, worst_logit)
+
+
 def test_stream2_matches_reference(golden_dir, prec):
     """Two passes, release_old_frames with image release, online new object (A17)."""
     g = np.load(os.path.join(golden_dir, "e2e_stream2.npz"))

@@ -154,3 +154,32 @@ def test_e2e_duplicate_class_matches_reference_golden(tiny, golden_dir):
         ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
         for o in range(2):
             assert 1.0 - _iou(vp.video_segments[int(t)][o], ref[o]) <= 1e-3
+
+
+def test_e2e_preload_bank_matches_reference_golden(tiny, golden_dir, tmp_path):
+    """A18: run A builds + pickles a 3-frame bank (all conditioning frames); run B preloads it and tracks 4 new
+    frames with no detector (det_sam2_RT.py:489-503,539-549; sam2_utils.py:56-60 keeps every preload cond frame)."""
+    from oracle.make_goldens import PRELOAD_A, PRELOAD_B
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_preload.npz"))
+    a = OracleVideoProcessor(sd, cfg, SyntheticDetector(2), **PRELOAD_A)
+    with torch.inference_mode():
+        for t in range(3):
+            a.process_frame(t, synthetic_frame(t))
+        a.save_inference_state(str(tmp_path / "bank.pkl"))
+        b = OracleVideoProcessor(sd, cfg, SyntheticDetector(2), **PRELOAD_B)
+        b.preload(str(tmp_path / "bank.pkl"))
+        assert b.pre_frames == 3
+        for i in range(4):
+            b.process_frame(3 + i, synthetic_frame(100 + i))
+    assert b.pass_log[0][1] == list(g["frames"])
+    od = b.inference_state["output_dict"]
+    for i, t in enumerate(g["frames"]):
+        low = od["non_cond_frame_outputs"][int(t)]["pred_masks"].numpy()
+        # bank entries agree to 7e-6; three bf16-stored cond memories => a few rounding-boundary flips of
+        # maskmem_features (2^-8 relative each) show up as <= 5e-4 on logits of magnitude 15 (mean |d| 2e-5)
+        assert np.abs(low - g["low"][i]).max() <= 1e-3
+        assert np.abs(low - g["low"][i]).mean() <= 1e-4
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            assert 1.0 - _iou(b.video_segments[int(t)][o], ref[o]) <= 1e-3
