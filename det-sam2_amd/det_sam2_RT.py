@@ -105,16 +105,26 @@ class VideoProcessor:
         """det_sam2_RT.py:342-411."""
         past = self.inference_state["num_frames"] if self.inference_state else 0
         dets = self.detect_predict(self.frame_buffer, past)
+        self._ingest_buffer()
+        self._prompt_and_propagate(frame_idx, dets)
+        self._release(frame_idx)
+        self._log_pass(frame_idx)
+
+    def _ingest_buffer(self):
+        """init_state / update_state with the buffered frames (det_sam2_RT.py:357-366)."""
         if self.inference_state is None:
             self.inference_state = self.predictor.init_state(video_path=self.frame_buffer)
         else:
             self.inference_state = self.predictor.update_state(video_path=self.frame_buffer, inference_state=self.inference_state)
+
+    def _prompt_and_propagate(self, frame_idx, dets):
+        """prompts + reverse propagation + threshold/host copy of one pass (det_sam2_RT.py:368-399)."""
         self.inference_state = self.Detect_2_SAM2_Prompt(dets)
-        yielded, packed = [], []
+        self._yielded, packed = [], []
         for t, obj_ids, bits in self.predictor.propagate_in_video(
                 self.inference_state, start_frame_idx=frame_idx, max_frame_num_to_track=self.max_frame_num_to_track,
                 reverse=True, output="packed"):
-            yielded.append(t)
+            self._yielded.append(t)
             if t >= self.pre_frames:
                 packed.append((t, list(obj_ids), bits))
         # one device->host transfer per pass, then unpack to the reference's {obj_id: bool[1,Hv,Wv]} format
@@ -124,11 +134,18 @@ class VideoProcessor:
             for (t, ids, _), pb in zip(packed, host):
                 m = np.unpackbits(pb, axis=-1).reshape(len(ids), 1, hv, wv).astype(bool)
                 self.video_segments[t] = {oid: m[i] for i, oid in enumerate(ids)}
+
+    def _release(self, frame_idx):
+        """det_sam2_RT.py:404-411."""
         if self.max_inference_state_frames != -1:
             self.predictor.release_old_frames(self.inference_state, frame_idx, self.max_inference_state_frames,
                                               self.pre_frames, release_images=(self.vis_frame_stride == -1))
+
+    def _log_pass(self, frame_idx):
         od = self.inference_state["output_dict"]
-        self.pass_log.append((frame_idx, yielded, sorted(od["cond_frame_outputs"]), sorted(od["non_cond_frame_outputs"])))
+        self.pass_log.append((frame_idx, list(getattr(self, "_yielded", [])), sorted(od["cond_frame_outputs"]),
+                              sorted(od["non_cond_frame_outputs"])))
+        self._yielded = []
 
     def process_frame(self, frame_idx, frame):
         """det_sam2_RT.py:421-435."""
