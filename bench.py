@@ -40,6 +40,23 @@ def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
     return 2.0 * B * tokens * Nk * (d + dv)
 
 
+def cross_attention_bytes(B, Nk, tokens=4096, d=256, dv=64):
+    """Algorithmic HBM bytes of one cross-attention launch in bf16x3 mode: Q fp32 + K planes (2 x bf16) + V^T planes
+    (2 x bf16) read once, output planes written once."""
+    return 4.0 * B * (tokens * d + Nk * d + Nk * dv + tokens * dv)
+
+
+def pmc_traffic(B, nk, precision):
+    """HBM bytes per cross-attention launch from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, separate runs of this same bench command; PMC cannot be collected from inside the
+    timed run).  None if the file does not match this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_cross_attention.json")
+    if precision != "bf16x3" or B != 16 or nk != 28736 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return float(json.load(f)["traffic_bytes_per_launch"])
+
+
 def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
     """Oracle (CPU restatement, oracle/) timed on the host cores on a bounded sample of the same workload:
     one tracked frame with ONE object (encoder + bank of 7 frames/16 pointers + memory attention + SAM heads +
@@ -170,7 +187,9 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "memory cross-attention (k_attention_w8 in bf16x3 mode, k_attention<256,64> in fp32 mode), 1 launch/layer",
                          "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
-                         "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision], "traffic": None,
+                         "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision],
+                         "traffic": pmc_traffic(B, nk, a.precision), "traffic_unit": "bytes/launch",
+                         "algorithmic_bytes": cross_attention_bytes(B, nk),
                          "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
                          "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time; "
                                  "bf16x3 executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3 by construction"},
