@@ -231,12 +231,12 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
       }
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run, tmax);
-      alpha = exp2f(m_run - m_new);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
       float p[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        p[e] = exp2f(acc[e] - m_new);
+        p[e] = __builtin_amdgcn_exp2f(acc[e] - m_new);
         psum += p[e];
       }
       l_run = l_run * alpha + psum;

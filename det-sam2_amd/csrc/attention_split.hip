@@ -203,11 +203,11 @@ __global__ __launch_bounds__(256) void k_attention_split(SplitArgs a) {
     for (int e = 1; e < 16; ++e) tmax = fmaxf(tmax, acc[e]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      acc[e] = exp2f(acc[e] - m_new);
+      acc[e] = __builtin_amdgcn_exp2f(acc[e] - m_new);
       psum += acc[e];
     }
     l_run = l_run * alpha + psum;

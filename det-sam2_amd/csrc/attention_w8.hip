@@ -19,8 +19,12 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int D = 256, BKEYS = 32;
-constexpr int KROWB = D * 2 + 16, KPLANE = BKEYS * KROWB;
-constexpr int VROWB = 80;
+// LDS row pitches: fragment reads are ds_read_b128 with lane -> (row = lane & 15, 16-byte chunk = lane >> 4); a
+// pitch of 16*a bytes (mod 256) puts lane (row, chunk) on 4-bank slot (a*row + chunk) mod 16.  Over the hardware's
+// 16-lane service groups a = 1 or 5 (pitch 528 / 80) collide 2-way (PMC: SQ_LDS_BANK_CONFLICT = 44 % of LDS cycles),
+// a = 2 or 6 (pitch 544 / 96) are conflict-free.
+constexpr int KROWB = D * 2 + 32, KPLANE = BKEYS * KROWB;
+constexpr int VROWB_WIDE = 96, VROWB_NARROW = 80;   // DV = 256 does not fit LDS with the wide pitch
 constexpr int KS = D / 32;   // 8 k-steps of 32
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
@@ -81,6 +85,7 @@ struct W8Args {
 template <int DV, int QG>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int BQ = 128 * QG;
+  constexpr int VROWB = DV >= 256 ? VROWB_NARROW : VROWB_WIDE;
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
   __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
@@ -218,24 +223,53 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
       const float m_new = fmaxf(m_run[g], tmax);
-      alpha[g] = exp2f(m_run[g] - m_new);
-      const float p0 = exp2f(s0[g][0] - m_new), p1 = exp2f(s0[g][1] - m_new), p2 = exp2f(s0[g][2] - m_new), p3 = exp2f(s0[g][3] - m_new);
-      const float p4 = exp2f(s1[g][0] - m_new), p5 = exp2f(s1[g][1] - m_new), p6 = exp2f(s1[g][2] - m_new), p7 = exp2f(s1[g][3] - m_new);
+      alpha[g] = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+      const float p0 = __builtin_amdgcn_exp2f(s0[g][0] - m_new), p1 = __builtin_amdgcn_exp2f(s0[g][1] - m_new), p2 = __builtin_amdgcn_exp2f(s0[g][2] - m_new), p3 = __builtin_amdgcn_exp2f(s0[g][3] - m_new);
+      const float p4 = __builtin_amdgcn_exp2f(s1[g][0] - m_new), p5 = __builtin_amdgcn_exp2f(s1[g][1] - m_new), p6 = __builtin_amdgcn_exp2f(s1[g][2] - m_new), p7 = __builtin_amdgcn_exp2f(s1[g][3] - m_new);
       l_run[g] = l_run[g] * alpha[g] + (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)));
       m_run[g] = m_new;
       split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0[g], pb1[g]);
     }
-    // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block (each V^T fragment serves QG groups)
+    // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block (each V^T fragment serves QG groups).
+    // The running-max rescale is skipped when no lane of the wave raised its maximum (alpha == 1 exactly; after the
+    // first ~100 key tiles that is the common case), and the three product terms are issued term-major so that
+    // consecutive MFMAs never target the same accumulator.
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
-      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+    for (int g = 0; g < QG; ++g)
+      if (__any(alpha[g] != 1.f)) {
 #pragma unroll
-      for (int g = 0; g < QG; ++g) {
-        o[g][t] *= alpha[g];
-        o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
-        o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
-        o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0[g], o[g][t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) o[g][t] *= alpha[g];
+      }
+    if constexpr (NT <= 4) {
+      bf16x8 v0[NT], v1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
+        v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[t], pb0[g], o[g][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[t], pb1[g], o[g][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[t], pb0[g], o[g][t], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+          o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
+          o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
+          o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0[g], o[g][t], 0, 0, 0);
+        }
       }
     }
     W8_STORE(cur ^ 1)
