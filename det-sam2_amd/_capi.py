@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdetsam2_hip.so")
+# DS2_LIB: alternative build of the same library (A/B timing of kernel variants inside ONE gpurun call, see tools/ab.py)
+LIB_PATH = os.environ.get("DS2_LIB") or os.path.join(_HERE, "lib", "libdetsam2_hip.so")
 
 c_f32p = C.c_void_p
 c_vp = C.c_void_p

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""A/B timing of kernel variants.  Box-to-box noise between gpurun calls is 2-3 %, so variants are compared inside ONE
+call:  build here      : python tools/ab.py build NAME [-DFLAG=1 ...]   -> det-sam2_amd/lib/ab_NAME.so
+       run on the box  : python tools/ab.py run NAME1 NAME2 ... [--rounds 3] (alternates the builds, prints fps + stages)"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(name, flags):
+    import __graft_entry__ as g
+    out = os.path.join(g.PKG, "lib", f"ab_{name}.so")
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", out] + flags + [os.path.join(g.PKG, "csrc", s) for s in g.SOURCES]
+    subprocess.run(cmd, check=True)
+    print(out)
+
+
+def run(names, rounds):
+    import __graft_entry__ as g
+    for r in range(rounds):
+        for n in names:
+            env = dict(os.environ, DS2_LIB=os.path.join(g.PKG, "lib", f"ab_{n}.so"))
+            o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "1", "--no-cpu-baseline"],
+                               env=env, capture_output=True, text=True)
+            try:
+                d = json.loads(o.stdout.strip().splitlines()[-1])
+                print(f"{n:12s} fps {d['value']:.2f} cross {d['roofline']['avg_launch_ms']:.3f} ms  {d['ms_per_step_by_stage']}", flush=True)
+            except Exception:
+                print(n, "FAILED", o.stderr[-400:])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2], sys.argv[3:])
+    else:
+        a = sys.argv[2:]
+        rounds = 3
+        if "--rounds" in a:
+            i = a.index("--rounds")
+            rounds = int(a[i + 1])
+            a = a[:i] + a[i + 2:]
+        run(a, rounds)
