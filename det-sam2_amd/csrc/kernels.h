@@ -11,6 +11,8 @@ int launch_up2_add(const float* lat, const float* coarse, float* out, int H, int
 int launch_rope(float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens, hipStream_t st);
 int launch_im2col_patch(const uint16_t* frame_f16, float* out, int S, hipStream_t st);  // [3,S,S] fp16 -> [(S/4)^2,148]
 int launch_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* out, int n, int S, hipStream_t st);
+int launch_ingest_resize_u8(const uint8_t* rgb, const int* tab, const uint16_t* lut, uint16_t* out, int n, int H, int W, int S,
+                            hipStream_t st);
 int launch_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                     hipStream_t st);
 int launch_pad_cols(const float* in, int rows, int cols, float* out, int cols_out, hipStream_t st);

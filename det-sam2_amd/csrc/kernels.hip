@@ -184,6 +184,35 @@ __global__ void k_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* o
   o[2 * per] = lut[512 + px[2]];
 }
 
+// Frame ingest with resize: cv2.resize(frame, (S, S)) for 8-bit input = OpenCV's fixed-point INTER_LINEAR (resize.cpp,
+// HResizeLinear<uchar,int,short,2048> + VResizeLinear<uchar,int,short,FixedPtCast<int,uchar,22>>): taps/weights per
+// destination column and row come precomputed from the host (tab: [xofs S | a0 S | a1 S | yofs S | b0 S | b1 S]), the
+// kernel is pure integer arithmetic; the resized BYTE then goes through the same normalisation LUT as k_ingest_u8.
+__global__ void k_ingest_resize_u8(const uint8_t* rgb, const int* tab, const uint16_t* lut, uint16_t* out, int n, int H, int W,
+                                   int S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)S * S;
+  if (i >= (size_t)n * per) return;
+  const size_t f = i / per, p = i - f * per;
+  const int dy = (int)(p / S), dx = (int)(p - (size_t)dy * S);
+  const int x0 = tab[dx], a0 = tab[S + dx], a1 = tab[2 * S + dx];
+  const int sy = tab[3 * S + dy], b0 = tab[4 * S + dy], b1 = tab[5 * S + dy];
+  const int x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+  const int y0 = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
+  const int y1 = sy + 1 < 0 ? 0 : (sy + 1 > H - 1 ? H - 1 : sy + 1);
+  const uint8_t* r0 = rgb + (f * H + y0) * (size_t)W * 3;
+  const uint8_t* r1 = rgb + (f * H + y1) * (size_t)W * 3;
+  uint16_t* o = out + f * 3 * per + p;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int s0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+    const int s1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+    int v = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    o[c * per] = lut[c * 256 + v];
+  }
+}
+
 __global__ void k_permute4(const float* in, float* out, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = (size_t)d0 * d1 * d2 * d3;
@@ -687,6 +716,12 @@ int launch_im2col_patch(const uint16_t* frame_f16, float* out, int S, hipStream_
 }
 int launch_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* out, int n, int S, hipStream_t st) {
   hipLaunchKernelGGL(k_ingest_u8, grid1((size_t)n * S * S), dim3(256), 0, st, rgb, lut, out, n, S);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_ingest_resize_u8(const uint8_t* rgb, const int* tab, const uint16_t* lut, uint16_t* out, int n, int H, int W, int S,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_ingest_resize_u8, grid1((size_t)n * S * S), dim3(256), 0, st, rgb, tab, lut, out, n, H, W, S);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

@@ -458,16 +458,46 @@ extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------ A3
+// OpenCV INTER_LINEAR tap/weight tables for 8-bit resize (resize.cpp): f = (float)((d + 0.5) * scale - 0.5) with the
+// scale in double, tap = floor(f), weights cvRound(w * 2048) saturated to int16.  The x pass zeroes the fraction when
+// the tap is clamped; the y pass keeps it and only the row indices are clipped (in the kernel).
+static void resize_tables(int dst, int src, bool clamp_weights, int* ofs, int* w0, int* w1) {
+  const double scale = (double)src / (double)dst;
+  for (int d = 0; d < dst; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_weights) {
+      if (s < 0) { f = 0.f; s = 0; }
+      if (s >= src - 1) { f = 0.f; s = src - 1; }
+    }
+    long a1 = lrintf(f * 2048.f), a0 = lrintf((1.f - f) * 2048.f);   // round-half-even = cvRound
+    a1 = a1 < -32768 ? -32768 : (a1 > 32767 ? 32767 : a1);
+    a0 = a0 < -32768 ? -32768 : (a0 > 32767 ? 32767 : a0);
+    ofs[d] = s; w0[d] = (int)a0; w1[d] = (int)a1;
+  }
+}
+
 extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t height, int32_t width,
                                  uint16_t* frames_f16, void* stream) {
-  DS2_REQUIRE(m && m->finalized && rgb_u8 && frames_f16 && n > 0, "ds2_ingest_frames: bad argument");
-  if (height != m->cfg.image_size || width != m->cfg.image_size) {
-    ds2_set_error("ds2_ingest_frames: only %dx%d frames are supported (identity resize; cv2.resize parity is unpinned), got %dx%d",
-                  m->cfg.image_size, m->cfg.image_size, height, width);
-    return DS2_ERR_UNSUPPORTED;
+  DS2_REQUIRE(m && m->finalized && rgb_u8 && frames_f16 && n > 0 && height > 0 && width > 0, "ds2_ingest_frames: bad argument");
+  const int S = m->cfg.image_size;
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t* lut = reinterpret_cast<const uint16_t*>(m->P("#ingest_lut"));
+  if (height == S && width == S) return launch_ingest_u8(rgb_u8, lut, frames_f16, n, S, st);   // cv::resize early-out: copy
+  const std::string key = "@resize_tab." + std::to_string(height) + "x" + std::to_string(width);
+  const int* tab = m->Pbytes(key) ? reinterpret_cast<const int*>(m->P(key)) : nullptr;   // Pbytes: probe without flagging
+  if (!tab) {   // first frame of this resolution: build the six tables once, keep them on the device
+    std::vector<int> h((size_t)6 * S);
+    resize_tables(S, width, true, h.data(), h.data() + S, h.data() + 2 * S);
+    resize_tables(S, height, false, h.data() + 3 * S, h.data() + 4 * S, h.data() + 5 * S);
+    float* d = nullptr;
+    TRY(m->add_derived(key, (size_t)6 * S, &d));
+    DS2_CHECK_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    DS2_CHECK_HIP(hipStreamSynchronize(st));   // h is a local buffer
+    tab = reinterpret_cast<const int*>(d);
   }
-  return launch_ingest_u8(rgb_u8, reinterpret_cast<const uint16_t*>(m->P("#ingest_lut")), frames_f16, n, m->cfg.image_size,
-                          (hipStream_t)stream);
+  return launch_ingest_resize_u8(rgb_u8, tab, lut, frames_f16, n, height, width, S, st);
 }
 
 // ------------------------------------------------------------------------------------------------ A4 + A5

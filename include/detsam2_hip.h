@@ -61,9 +61,10 @@ int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_
 int ds2_model_finalize(ds2_model* m, void* stream);
 
 /* ---- A3: frame ingest.  load_video_frames, list-of-ndarray branch (sam2/utils/misc.py:280-284,
- * 328-342, 358-359) for frames that are already image_size x image_size (identity resize):
- * rgb_u8 [n,S,S,3] -> frames_f16 [n,3,S,S] = fp16((fp16(x/255) - mean) / std), fp16 roundings as the
- * reference.  Other resolutions return DS2 error 4 (cv2.resize parity is unpinned). */
+ * 328-342, 358-359): rgb_u8 [n,height,width,3] -> cv2.resize to S x S (8-bit INTER_LINEAR, OpenCV's fixed-point
+ * algorithm; identity when already S x S) -> frames_f16 [n,3,S,S] = fp16((fp16(x/255) - mean) / std) with the
+ * reference's fp16 roundings.  cv2 is absent from this image, so the resize step is restated from OpenCV's
+ * published algorithm and is parity-unpinned (oracle/resize.py). */
 int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t height, int32_t width,
                       uint16_t* frames_f16, void* stream);
 

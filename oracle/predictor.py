@@ -22,14 +22,14 @@ from .modeling import NO_OBJ_SCORE
 
 
 def load_frames(frames, image_size=1024, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
-    """load_video_frames, list-of-ndarray branch (misc.py:280-284, 328-342, 358-359).
-    Frames must already be image_size x image_size (cv2.resize would be the identity)."""
+    """load_video_frames, list-of-ndarray branch (misc.py:280-284, 328-342, 358-359).  cv2.resize is restated in
+    oracle/resize.py (parity-unpinned: cv2 is not installed here); identity for image_size x image_size frames."""
+    from .resize import cv2_resize_linear_u8
     if isinstance(frames, np.ndarray):
         frames = [frames]
     images = torch.zeros(len(frames), 3, image_size, image_size, dtype=torch.float16)
     for n, fr in enumerate(frames):
-        assert fr.shape[0] == image_size and fr.shape[1] == image_size, "oracle ingest: identity resize only"
-        images[n] = torch.from_numpy(fr / 255.0).permute(2, 0, 1)
+        images[n] = torch.from_numpy(cv2_resize_linear_u8(fr, (image_size, image_size)) / 255.0).permute(2, 0, 1)
     images -= torch.tensor(mean, dtype=torch.float32)[:, None, None]
     images /= torch.tensor(std, dtype=torch.float32)[:, None, None]
     return images, frames[0].shape[0], frames[0].shape[1]
