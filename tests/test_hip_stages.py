@@ -115,7 +115,7 @@ def test_memory_attention_and_bank(prec):
     assert e_mem == 0.0 and e_pos < 1e-5 and e < TOL[prec], (e_mem, e_pos, e)
 
 
-@pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True)])
+@pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True), ("click", True), ("clicks", False)])
 def test_sam_heads(prompt, multimask, prec):
     cfg, sd, hm = model("sam2.1_hiera_t", prec)
     g = torch.Generator().manual_seed(5)
@@ -125,6 +125,10 @@ def test_sam_heads(prompt, multimask, prec):
     pin = None
     if prompt == "box":
         pin = {"point_coords": torch.rand(B, 2, 2, generator=g) * 1024, "point_labels": torch.tensor([[2, 3]] * B, dtype=torch.int32)}
+    if prompt == "click":     # one positive click => multimask output (multimask_max_pt_num = 1)
+        pin = {"point_coords": torch.rand(B, 1, 2, generator=g) * 1024, "point_labels": torch.tensor([[1]] * B, dtype=torch.int32)}
+    if prompt == "clicks":    # positive + negative + positive clicks
+        pin = {"point_coords": torch.rand(B, 3, 2, generator=g) * 1024, "point_labels": torch.tensor([[1, 0, 1]] * B, dtype=torch.int32)}
     with torch.inference_mode():
         ref = OraclePredictor(sd, cfg).forward_sam_heads(feats, pin, None, [hr0.expand(B, -1, -1, -1), hr1.expand(B, -1, -1, -1)], multimask)
     d = hm.device
