@@ -98,6 +98,87 @@ __global__ void k_add_bcast_split(const float* a, int lda, const float* b, int l
   lo[i] = l;
 }
 
+// Vectorised LayerNorm: one wave per row, the whole row held in registers (NV float4 per lane: C <= 256 NV), ONE
+// 16-byte-per-lane read of x, two-pass statistics in registers (same arithmetic as k_layernorm: mean, then the sum of
+// squared deviations), 16-byte fp32 stores or 8-byte plane stores.  HBM-bound: 4 B read + 4 B written per element.
+template <int NV, bool SPLIT>
+__global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ y, int ldy,
+                                                       uint2* __restrict__ hi, uint2* __restrict__ lo, int ldp, int rows, int C,
+                                                       float eps, int act) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    v[i] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (4 * (lane + 64 * i) < C) {
+      const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * (lane + 64 * i);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + c), b4 = *reinterpret_cast<const float4*>(b + c);
+      o.x = ds2_act((v[i].x - mean) * rstd * w4.x + b4.x, act);
+      o.y = ds2_act((v[i].y - mean) * rstd * w4.y + b4.y, act);
+      o.z = ds2_act((v[i].z - mean) * rstd * w4.z + b4.z, act);
+      o.w = ds2_act((v[i].w - mean) * rstd * w4.w + b4.w, act);
+    }
+    if (SPLIT) {
+      if (c < ldp) {   // columns C..ldp are zero in both planes
+        uint2 h, l;
+        h.x = ln_cvt_pk_bf16(o.x, o.y);
+        h.y = ln_cvt_pk_bf16(o.z, o.w);
+        l.x = ln_cvt_pk_bf16(o.x - __uint_as_float(h.x << 16), o.y - __uint_as_float(h.x & 0xffff0000u));
+        l.y = ln_cvt_pk_bf16(o.z - __uint_as_float(h.y << 16), o.w - __uint_as_float(h.y & 0xffff0000u));
+        hi[(size_t)row * (ldp / 4) + (c >> 2)] = h;
+        lo[(size_t)row * (ldp / 4) + (c >> 2)] = l;
+      }
+    } else if (c < C) {
+      *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
+    }
+  }
+}
+
+#ifndef DS2_LN_VEC
+#define DS2_LN_VEC 1
+#endif
+template <bool SPLIT>
+static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, void* hi, void* lo,
+                                 int ldp, int rows, int C, float eps, int act, hipStream_t st) {
+  const int width = SPLIT ? ldp : C;
+  const bool ok = C % 4 == 0 && ldx % 4 == 0 && (SPLIT || ldy % 4 == 0) && width <= 5 * 256 &&
+                  (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(b) & 15) == 0 && (SPLIT || (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  if (!ok || !DS2_LN_VEC) return false;
+  const int nv = (width + 255) / 256;
+  const dim3 grid(cdiv(rows, 4)), blk(256);
+  uint2* h2 = reinterpret_cast<uint2*>(hi);
+  uint2* l2 = reinterpret_cast<uint2*>(lo);
+#define DS2_LN_CASE(N) \
+  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act); break;
+  switch (nv) {
+    DS2_LN_CASE(1) DS2_LN_CASE(2) DS2_LN_CASE(3) DS2_LN_CASE(4) DS2_LN_CASE(5)
+    default: return false;
+  }
+#undef DS2_LN_CASE
+  return true;
+}
+
 // ------------------------------------------------------------------ simple elementwise
 __global__ void k_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, float* out,
                             int ldo, int rows, int C) {
@@ -662,6 +743,10 @@ __global__ __launch_bounds__(256) void k_mask_downscale_add(const float* mask, M
 int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
                      float eps, int act, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && C > 0, "layernorm: bad dims");
+  if (launch_layernorm_vec<false>(x, ldx, w, b, y, ldy, nullptr, nullptr, 0, rows, C, eps, act, st)) {
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
   hipLaunchKernelGGL(k_layernorm, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, w, b, y, ldy, rows, C, eps, act);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
@@ -669,6 +754,10 @@ int launch_layernorm(const float* x, int ldx, const float* w, const float* b, fl
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
                            int C, float eps, int act, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && C > 0 && ldp % 32 == 0 && ldp >= C, "layernorm_split: bad dims");
+  if (launch_layernorm_vec<true>(x, ldx, w, b, nullptr, 0, hi, lo, ldp, rows, C, eps, act, st)) {
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
   hipLaunchKernelGGL(k_layernorm_split, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, w, b, reinterpret_cast<unsigned*>(hi),
                      reinterpret_cast<unsigned*>(lo), ldp, rows, C, eps, act);
   DS2_CHECK_LAUNCH();
