@@ -50,23 +50,37 @@ __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, f
 // {4g+r} of key-block 0 and {16+4g+r} of key-block 1 in its accumulators; its 8 k-slots are pos 8g..8g+7.
 __device__ __forceinline__ int vt_pos16(int key) { return 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4); }
 
-// vt[b][tile][plane][dv 0..DVT-1][pos 0..31]
+// vt[b][tile][plane][dv 0..DVT-1][pos 0..31].  One thread per (tile, dv) row: 32 key loads (coalesced across the
+// lanes, which differ in dv), split, and two contiguous 64-byte stores (hi / lo plane rows) - HBM-bound, 4 B read +
+// 4 B written per element (the one-element-per-thread version with 2-byte scattered stores ran at 1 TB/s).
 template <int DVT>
-__global__ void k_vt_split16(const float* v, int ldv, int batch, int L, unsigned short* vt) {
+__global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v, int ldv, int batch, int L,
+                                                    unsigned short* __restrict__ vt) {
   const int ntile = (L + 31) / 32;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)batch * ntile * 32 * DVT) return;
-  const int dv = (int)(i % DVT), key = (int)((i / DVT) & 31);
-  const size_t bt = i / (32 * DVT);
+  if (i >= (size_t)batch * ntile * DVT) return;
+  const int dv = (int)(i % DVT);
+  const size_t bt = i / DVT;
   const int tile = (int)(bt % ntile), b = (int)(bt / ntile);
-  const int ki = tile * 32 + key;
-  const float x = ki < L ? v[((size_t)b * L + ki) * ldv + dv] : 0.f;
-  const unsigned h = cvt_pk_bf16(x, 0.f);
-  const unsigned l = cvt_pk_bf16(x - bf_lo(h), 0.f);
-  unsigned short* base = vt + bt * 2 * (32 * DVT);
-  const int off = dv * 32 + vt_pos16(key);
-  base[off] = (unsigned short)(h & 0xffffu);
-  base[32 * DVT + off] = (unsigned short)(l & 0xffffu);
+  const float* src = v + ((size_t)b * L + (size_t)tile * 32) * ldv + dv;
+  const int nvalid = L - tile * 32;          // keys beyond L are zero
+  unsigned h[16], l[16];
+#pragma unroll
+  for (int key = 0; key < 32; key += 2) {    // keys (key, key+1) sit at adjacent positions (pos, pos+1), pos even
+    const float x0 = key < nvalid ? src[(size_t)key * ldv] : 0.f;
+    const float x1 = key + 1 < nvalid ? src[(size_t)(key + 1) * ldv] : 0.f;
+    const unsigned hh = cvt_pk_bf16(x0, x1);
+    const int pos = 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4);
+    h[pos >> 1] = hh;
+    l[pos >> 1] = cvt_pk_bf16(x0 - bf_lo(hh), x1 - bf_hi(hh));
+  }
+  uint4* oh = reinterpret_cast<uint4*>(vt + bt * 2 * (32 * DVT) + (size_t)dv * 32);
+  uint4* ol = reinterpret_cast<uint4*>(vt + bt * 2 * (32 * DVT) + 32 * DVT + (size_t)dv * 32);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    oh[q4] = make_uint4(h[4 * q4], h[4 * q4 + 1], h[4 * q4 + 2], h[4 * q4 + 3]);
+    ol[q4] = make_uint4(l[4 * q4], l[4 * q4 + 1], l[4 * q4 + 2], l[4 * q4 + 3]);
+  }
 }
 
 struct W8Args {
@@ -308,16 +322,15 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 
 int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st) {
   DS2_REQUIRE(dv == 64 || dv == 128 || dv == 256, "vt_split16: dv must be 64, 128 or 256");
-  const size_t n = (size_t)batch * ((L + 31) / 32) * 32 * dv;
+  const size_t n = (size_t)batch * ((L + 31) / 32) * dv;     // one thread per (tile, dv) row
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  unsigned short* out = reinterpret_cast<unsigned short*>(vt);
   if (dv == 64)
-    hipLaunchKernelGGL((k_vt_split16<64>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
-                       reinterpret_cast<unsigned short*>(vt));
+    hipLaunchKernelGGL((k_vt_split16<64>), grid, blk, 0, st, v, ldv, batch, L, out);
   else if (dv == 128)
-    hipLaunchKernelGGL((k_vt_split16<128>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
-                       reinterpret_cast<unsigned short*>(vt));
+    hipLaunchKernelGGL((k_vt_split16<128>), grid, blk, 0, st, v, ldv, batch, L, out);
   else
-    hipLaunchKernelGGL((k_vt_split16<256>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L,
-                       reinterpret_cast<unsigned short*>(vt));
+    hipLaunchKernelGGL((k_vt_split16<256>), grid, blk, 0, st, v, ldv, batch, L, out);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
