@@ -231,6 +231,9 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     return launch_gemm(g, st);
   }
   DS2_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
+  static const bool dbg_shapes = getenv("DS2_DEBUG_GEMM") != nullptr;
+  if (dbg_shapes) fprintf(stderr, "GEMM %d %d %d planesA=%d planes_out=%d act=%d R=%d\n", M, N, K,
+                          (int)(m && m->act_planes.count(A)), (int)planes_out, act, (int)(R != nullptr));
   const int Kp = round32(K);
   const size_t w_bytes = (size_t)N * Kp * 2;
   const unsigned short *ahi = nullptr, *alo = nullptr;

@@ -44,7 +44,7 @@ class SAM2VideoPredictor:
         self.stats = {"encoder_runs": 0, "encoder_launches": 0, "tracked_frames": 0}
         # frames encoded per image-encoder launch: the driver hands frames over 30 at a time, and one frame's
         # Hiera stage-3/4 GEMMs (4096 / 1024 tokens) cannot fill 256 CUs.  Same results as one-by-one.
-        self.encode_batch = int(os.environ.get("DS2_ENCODE_BATCH", "6"))
+        self.encode_batch = int(os.environ.get("DS2_ENCODE_BATCH", "10"))
 
     # ------------------------------------------------------------------ frame ingest (A3)
     def _load_frames(self, video_path):
