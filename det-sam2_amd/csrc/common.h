@@ -93,4 +93,6 @@ struct AttnArgs {
 int launch_attention(const AttnArgs& a, hipStream_t st);         // dispatches on g_ds2_precision
 bool attention_fewq_supported(const AttnArgs& a);                // Lq <= 16 against >= 1024 keys, head dim 16/32
 int launch_attention_fewq(const AttnArgs& a, hipStream_t st);    // split-key exact fp32 path (attention_fewq.hip)
+bool attention_smallwin_supported(const AttnArgs& a);            // 16- / 64-key Hiera windows, bf16x3 (attention_smallwin.hip)
+int launch_attention_smallwin(const AttnArgs& a, hipStream_t st);
 int launch_attention_bf16x3(const AttnArgs& a, hipStream_t st);  // DS2_ERR_UNSUPPORTED if no kernel for (D,DV)

@@ -127,6 +127,9 @@ def _window_ref(q_nat, k_nat, v_nat, kb, vb, side_q, side_k, win_q, win_k, heads
 @pytest.mark.parametrize("side,win,heads,D,pool", [
     (64, 8, 1, 96, False), (64, 8, 2, 72, True), (64, 14, 4, 96, False), (64, 14, 2, 56, True), (32, 7, 2, 96, False),
     (64, 16, 8, 72, False),
+    # small windows (16 / 64 keys): register-only kernel attention_smallwin.hip in bf16x3 mode
+    (64, 4, 4, 72, False), (64, 4, 2, 72, True), (32, 8, 2, 56, False), (64, 8, 3, 96, True), (16, 4, 1, 96, False),
+    (64, 4, 2, 56, True), (64, 4, 2, 56, False), (64, 8, 2, 56, True), (64, 8, 2, 96, False), (64, 4, 3, 96, True),
 ])
 def test_attention_windowed(ops, side, win, heads, D, pool):
     g = torch.Generator().manual_seed(side + win)
