@@ -65,7 +65,6 @@ struct GemmArgs {
   int r_mod;              // if >0 the residual row is (m % r_mod) (broadcast over a leading batch)
 };
 int launch_gemm(const GemmArgs& g, hipStream_t st);          // exact fp32 MFMA
-int launch_gemm_bf16x3(const GemmArgs& g, hipStream_t st);   // split-precision bf16 MFMA (3 products)
 
 // arithmetic mode of the matrix-core kernels (ds2_set_precision)
 enum { DS2_PREC_FP32 = 0, DS2_PREC_BF16X3 = 1 };

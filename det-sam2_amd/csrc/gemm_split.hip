@@ -293,329 +293,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// BK = 64 variant: every staged row is one full 128-byte line per plane (BK = 32 rows are 64-byte half lines, which
-// the texture-addresser path fetches at about half efficiency).  One LDS buffer (72 KiB, two blocks per CU) +
-// register prefetch of the next K tile; two barriers per 64-deep K tile.
-constexpr int BK64 = 64, ROWB64 = 144, PLANE64 = BM * ROWB64;   // 128 B data + 16 B pad per row
-
-__global__ __launch_bounds__(256, 2) void k_gemm_split64(GemmSplitArgs g, int mt, int nt) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][PLANE64];   // [A/B][hi/lo]
-
-  const int nwg = mt * nt;
-  const int orig = blockIdx.x;
-  const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-  const int tile_m = wg / nt, tile_n = wg % nt;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, half = lane >> 5;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // staging: a plane tile is 128 rows x 8 uint4; thread -> rows (tid>>3) + 32 i, part tid&7: a wave instruction
-  // fetches 8 complete 128-byte lines
-  const int srow = tid >> 3, spart = tid & 7;
-  const uint4 *pah[4], *pal[4], *pbh[4], *pbl[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int ma = m0 + srow + 32 * i, nb = n0 + srow + 32 * i;
-    ma = ma < g.M ? ma : g.M - 1;
-    nb = nb < g.N ? nb : g.N - 1;
-    pah[i] = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma * g.lda) + spart;
-    pal[i] = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma * g.lda) + spart;
-    pbh[i] = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb * g.ldw) + spart;
-    pbl[i] = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb * g.ldw) + spart;
-  }
-  const int nk = (g.Kp + BK64 - 1) / BK64;
-  const int kq = g.Kp / 8;   // uint4 per row; the last K tile may be half (Kp is a multiple of 32): clamp the part index
-  uint4 ah0, ah1, ah2, ah3, al0, al1, al2, al3, bh0, bh1, bh2, bh3, bl0, bl1, bl2, bl3;
-#define G64_LOAD(kt)                                                                   \
-  {                                                                                    \
-    int ko = (kt) * 8;                                                                 \
-    const bool tail_ = ko + spart >= kq;      /* second half of a 32-wide last tile: feed zeros */ \
-    ko = tail_ ? 0 : ko;                                                               \
-    ah0 = pah[0][ko]; ah1 = pah[1][ko]; ah2 = pah[2][ko]; ah3 = pah[3][ko];            \
-    al0 = pal[0][ko]; al1 = pal[1][ko]; al2 = pal[2][ko]; al3 = pal[3][ko];            \
-    bh0 = pbh[0][ko]; bh1 = pbh[1][ko]; bh2 = pbh[2][ko]; bh3 = pbh[3][ko];            \
-    bl0 = pbl[0][ko]; bl1 = pbl[1][ko]; bl2 = pbl[2][ko]; bl3 = pbl[3][ko];            \
-    if (tail_) {                                                                       \
-      const uint4 z_ = make_uint4(0, 0, 0, 0);                                         \
-      ah0 = ah1 = ah2 = ah3 = al0 = al1 = al2 = al3 = z_;                              \
-      bh0 = bh1 = bh2 = bh3 = bl0 = bl1 = bl2 = bl3 = z_;                              \
-    }                                                                                  \
-  }
-#define G64_ST(OP, PL, I, V) *reinterpret_cast<uint4*>(&lds[OP][PL][(srow + 32 * (I)) * ROWB64 + spart * 16]) = V;
-#define G64_STORE()                                                                    \
-  {                                                                                    \
-    G64_ST(0, 0, 0, ah0) G64_ST(0, 0, 1, ah1) G64_ST(0, 0, 2, ah2) G64_ST(0, 0, 3, ah3) \
-    G64_ST(0, 1, 0, al0) G64_ST(0, 1, 1, al1) G64_ST(0, 1, 2, al2) G64_ST(0, 1, 3, al3) \
-    G64_ST(1, 0, 0, bh0) G64_ST(1, 0, 1, bh1) G64_ST(1, 0, 2, bh2) G64_ST(1, 0, 3, bh3) \
-    G64_ST(1, 1, 0, bl0) G64_ST(1, 1, 1, bl1) G64_ST(1, 1, 2, bl2) G64_ST(1, 1, 3, bl3) \
-  }
-
-  G64_LOAD(0)
-  G64_STORE()
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    G64_LOAD(kt + 1 < nk ? kt + 1 : kt)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int koff = s4 * 32 + half * 16;
-      bf16x8 fa0[2], fa1[2], fb0[2], fb1[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int ar = (wm * 64 + t * 32 + l31) * ROWB64 + koff;
-        const int br = (wn * 64 + t * 32 + l31) * ROWB64 + koff;
-        fa0[t] = *reinterpret_cast<const bf16x8*>(&lds[0][0][ar]);
-        fa1[t] = *reinterpret_cast<const bf16x8*>(&lds[0][1][ar]);
-        fb0[t] = *reinterpret_cast<const bf16x8*>(&lds[1][0][br]);
-        fb1[t] = *reinterpret_cast<const bf16x8*>(&lds[1][1][br]);
-      }
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[tm], fb0[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb1[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb0[tn], acc[tm][tn], 0, 0, 0);
-        }
-    }
-    __syncthreads();          // every wave is done reading this K tile
-    G64_STORE()
-    __syncthreads();
-  }
-
-  // ---- epilogue (same LDS-staged, coalesced form as k_gemm_split)
-  constexpr int EPLD = 68;
-  float* ep = reinterpret_cast<float*>(&lds[0][0][0]) + wave * (64 * EPLD);
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ep[(tm * 32 + mfma32_row(e, half)) * EPLD + tn * 32 + l31] = acc[tm][tn][e];
-  __syncthreads();
-  const int c4 = lane & 15, r0 = lane >> 4;
-  const int n = n0 + wn * 64 + c4 * 4;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
-  {
-    float* bp = reinterpret_cast<float*>(&bias4);
-    float* gp = reinterpret_cast<float*>(&gam4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (g.bias && n + j < g.N) bp[j] = g.bias[n + j];
-      if (g.gamma && n + j < g.N) gp[j] = g.gamma[n + j];
-    }
-  }
-  const bool vec_ok = (n + 3 < g.N);
-#pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int rr = it * 4 + r0;
-    const int m = m0 + wm * 64 + rr;
-    if (m >= g.M) continue;
-    const float4 a4 = *reinterpret_cast<const float4*>(&ep[rr * EPLD + c4 * 4]);
-    float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
-                  ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
-    if (g.R) {
-      const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
-      const float* rp = g.R + (size_t)rm * g.ldr + n;
-      if (vec_ok && (g.ldr & 3) == 0) {
-        const float4 r4 = *reinterpret_cast<const float4*>(rp);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < g.N) v[j] += rp[j];
-      }
-    }
-    if (g.C) {
-      float* cp = g.C + (size_t)m * g.ldc + n;
-      if (vec_ok && (g.ldc & 3) == 0) {
-        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j < g.N) cp[j] = v[j];
-      }
-    }
-    if (g.C_hi && n < g.ldcp) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j >= g.N) v[j] = 0.f;
-      if (g.rope_cis) {
-        const int t = m % g.rope_L;
-        if (t < g.rope_n) {
-          const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
-          const float a0 = v[0] * c.x - v[1] * c.y, a1 = v[0] * c.y + v[1] * c.x;
-          const float a2 = v[2] * c.z - v[3] * c.w, a3 = v[2] * c.w + v[3] * c.z;
-          v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
-        }
-      }
-      uint2 h, l;
-      h.x = cvt_pk_bf16(v[0], v[1]);
-      h.y = cvt_pk_bf16(v[2], v[3]);
-      l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
-      l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
-      *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
-      *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Same GEMM with direct-to-LDS staging (global_load_lds, 16 B per lane): no VGPR round trip and no ds_write.
-// (Ablation on MI355X: the MFMA + ds_read part of the kernel above sustains ~640 TF by itself; its global-load ->
-// VGPR -> ds_write_b128 staging, not the matrix pipe, sets the speed.)
-// An LDS-DMA writes wave-uniform base + lane*16, so the LDS image cannot be row-padded; plane tiles are plain
-// [128 rows][64 B] and bank conflicts are avoided with an XOR swizzle of the four 16-byte chunks of a row,
-// chunk' = chunk ^ ((row >> 2) & 3), applied to the SOURCE address of each lane and again on the operand reads.
-constexpr int GROWB = 64, GPLANE = BM * GROWB;   // 8 KiB per plane tile
-
-__global__ __launch_bounds__(256, 2) void k_gemm_glds(GemmSplitArgs g, int mt, int nt) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2][2][2][GPLANE];   // [buf][A/B][hi/lo]
-
-  const int nwg = mt * nt;
-  const int orig = blockIdx.x;
-  const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
-  const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-  const int tile_m = wg / nt, tile_n = wg % nt;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l31 = lane & 31, half = lane >> 5;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // staging: wave w fills rows [32w, 32w+32) of each of the 4 plane tiles with two 1-KiB DMAs (16 rows each).
-  // lane -> (row = lane>>2, physical chunk = lane&3); it fetches logical chunk (lane&3) ^ ((row>>2)&3).
-  const int srow0 = wave * 32 + (lane >> 2), srow1 = srow0 + 16;
-  const int lc0 = (lane & 3) ^ ((srow0 >> 2) & 3), lc1 = (lane & 3) ^ ((srow1 >> 2) & 3);
-  int ma0 = m0 + srow0, ma1 = m0 + srow1, nb0 = n0 + srow0, nb1 = n0 + srow1;
-  ma0 = ma0 < g.M ? ma0 : g.M - 1;
-  ma1 = ma1 < g.M ? ma1 : g.M - 1;
-  nb0 = nb0 < g.N ? nb0 : g.N - 1;
-  nb1 = nb1 < g.N ? nb1 : g.N - 1;
-  const uint4* pa0h = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma0 * g.lda) + lc0;
-  const uint4* pa0l = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma0 * g.lda) + lc0;
-  const uint4* pa1h = reinterpret_cast<const uint4*>(g.A_hi + (size_t)ma1 * g.lda) + lc1;
-  const uint4* pa1l = reinterpret_cast<const uint4*>(g.A_lo + (size_t)ma1 * g.lda) + lc1;
-  const uint4* pb0h = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb0 * g.ldw) + lc0;
-  const uint4* pb0l = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb0 * g.ldw) + lc0;
-  const uint4* pb1h = reinterpret_cast<const uint4*>(g.W_hi + (size_t)nb1 * g.ldw) + lc1;
-  const uint4* pb1l = reinterpret_cast<const uint4*>(g.W_lo + (size_t)nb1 * g.ldw) + lc1;
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-#define GL(src, BUF, OP, PL, ROWBASE) \
-  __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&lds[BUF][OP][PL][(ROWBASE) * GROWB]), 16, 0, 0);
-#define GL_TILE(kt, BUF)                                   \
-  {                                                         \
-    const int ko = (kt) * 4;                                \
-    GL(pa0h + ko, BUF, 0, 0, wave * 32)                     \
-    GL(pa1h + ko, BUF, 0, 0, wave * 32 + 16)                \
-    GL(pa0l + ko, BUF, 0, 1, wave * 32)                     \
-    GL(pa1l + ko, BUF, 0, 1, wave * 32 + 16)                \
-    GL(pb0h + ko, BUF, 1, 0, wave * 32)                     \
-    GL(pb1h + ko, BUF, 1, 0, wave * 32 + 16)                \
-    GL(pb0l + ko, BUF, 1, 1, wave * 32)                     \
-    GL(pb1l + ko, BUF, 1, 1, wave * 32 + 16)                \
-  }
-  // operand reads: row r, k-step s, half h -> logical chunk 2s+h, physical chunk (2s+h) ^ ((r>>2)&3)
-  const int ra0 = wm * 64 + l31, ra1 = ra0 + 32, rb0 = wn * 64 + l31, rb1 = rb0 + 32;
-  const int sa0 = (ra0 >> 2) & 3, sa1 = (ra1 >> 2) & 3, sb0 = (rb0 >> 2) & 3, sb1 = (rb1 >> 2) & 3;
-#define GC_FRAG(BUF, OP, PL, ROW, SW, S) \
-  (*reinterpret_cast<const bf16x8*>(&lds[BUF][OP][PL][(ROW) * GROWB + ((((S) * 2 + half) ^ (SW)) << 4)]))
-#define GC_COMPUTE(BUF)                                                                       \
-  _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                          \
-    const bf16x8 fa00 = GC_FRAG(BUF, 0, 0, ra0, sa0, s_), fa01 = GC_FRAG(BUF, 0, 1, ra0, sa0, s_); \
-    const bf16x8 fa10 = GC_FRAG(BUF, 0, 0, ra1, sa1, s_), fa11 = GC_FRAG(BUF, 0, 1, ra1, sa1, s_); \
-    const bf16x8 fb00 = GC_FRAG(BUF, 1, 0, rb0, sb0, s_), fb01 = GC_FRAG(BUF, 1, 1, rb0, sb0, s_); \
-    const bf16x8 fb10 = GC_FRAG(BUF, 1, 0, rb1, sb1, s_), fb11 = GC_FRAG(BUF, 1, 1, rb1, sb1, s_); \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa01, fb00, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa01, fb10, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa11, fb00, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa11, fb10, acc[1][1], 0, 0, 0);      \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb01, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb11, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb01, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb11, acc[1][1], 0, 0, 0);      \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb00, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa00, fb10, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb00, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa10, fb10, acc[1][1], 0, 0, 0);      \
-  }
-
-  const int nk = g.Kp / BK, last = nk - 1;
-  GL_TILE(0, 0)
-  __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
-  for (int kt = 0; kt < nk; kt += 2) {
-    GL_TILE((kt + 1 < last ? kt + 1 : last), 1)   // DMA of tile kt+1 runs under the MFMAs of tile kt
-    GC_COMPUTE(0)
-    __syncthreads();
-    if (kt + 1 < nk) {
-      GL_TILE((kt + 2 < last ? kt + 2 : last), 0)
-      GC_COMPUTE(1)
-      __syncthreads();
-    }
-  }
-
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int n = n0 + wn * 64 + tn * 32 + l31;
-    const bool n_ok = n < g.N;
-    const float bias = (g.bias && n_ok) ? g.bias[n] : 0.f;
-    const float gam = (g.gamma && n_ok) ? g.gamma[n] : 1.f;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + tm * 32 + mfma32_row(e, half);
-        float v = ds2_act(acc[tm][tn][e] + bias, g.act) * gam;
-        if (g.R && n_ok && m < g.M) {
-          const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
-          v += g.R[(size_t)rm * g.ldr + n];
-        }
-        if (g.C && n_ok && m < g.M) g.C[(size_t)m * g.ldc + n] = v;
-        if (g.C_hi) {
-          const float vn = __shfl_down(v, 1);
-          if ((l31 & 1) == 0 && m < g.M && n < g.ldcp) {
-            float x0 = n_ok ? v : 0.f, x1 = (n + 1 < g.N) ? vn : 0.f;
-            if (g.rope_cis) {   // columns (n, n+1) are one complex pair (apply_rotary_enc, position_encoding.py:196-220)
-              const int t = m % g.rope_L;
-              if (t < g.rope_n) {
-                const float2 c = reinterpret_cast<const float2*>(g.rope_cis)[(size_t)(t % g.rope_grid) * 128 + (n >> 1)];
-                const float r0 = x0 * c.x - x1 * c.y, r1 = x0 * c.y + x1 * c.x;
-                x0 = r0; x1 = r1;
-              }
-            }
-            const unsigned h = cvt_pk_bf16(x0, x1);
-            const unsigned l = cvt_pk_bf16(x0 - bf_lo(h), x1 - bf_hi(h));
-            *reinterpret_cast<unsigned*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
-            *reinterpret_cast<unsigned*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
-          }
-        }
-      }
-    }
-  }
-}
-
 }  // namespace
 
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st) {
@@ -653,18 +330,6 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
   if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
-  static const bool bk64 = [] { const char* e = getenv("DS2_GEMM_KERNEL"); return e && strcmp(e, "bk64") == 0; }();
-  if (bk64 && g.Kp >= 64) {
-    hipLaunchKernelGGL(k_gemm_split64, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
-    DS2_CHECK_LAUNCH();
-    return DS2_OK;
-  }
-  static const bool glds = [] { const char* e = getenv("DS2_GEMM_KERNEL"); return e && strcmp(e, "glds") == 0; }();
-  if (glds) {
-    hipLaunchKernelGGL(k_gemm_glds, dim3(mt * nt), dim3(256), 0, st, g, mt, nt);
-    DS2_CHECK_LAUNCH();
-    return DS2_OK;
-  }
   static const int dbg = [] { const char* e = getenv("DS2_GEMM_DBG"); return e ? atoi(e) : 0; }();
   switch (dbg) {   // ablation builds for profiling only (results are wrong for dbg != 0)
     case 1: hipLaunchKernelGGL(k_gemm_split<1>, dim3(mt * nt), dim3(256), 0, st, g, mt, nt); break;
