@@ -31,6 +31,8 @@ int launch_memfeat_finish(const float* feat, const float* obj_logits, const floa
 // keys[b,tok,:] = src[(b,)tok,:] + mask_downscaling(mask[b]) ; prm = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}
 int launch_mask_downscale_add(const float* mask, const float* const* prm, const float* src, int src_bcast, float* keys, int B,
                               hipStream_t st);
+int launch_mlp3_256(const float* A, int lda, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                    const float* b2, int n_out, float* out, int ldc, int last_act, int rows, hipStream_t st);
 int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4, const float* not_a_point,
                          const float* coords, const int* labels, int B, int P, float image_size, float* tokens,
                          hipStream_t st);  // tokens [B, 6+P+1, 256]

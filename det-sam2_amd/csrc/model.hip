@@ -823,6 +823,13 @@ int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int
 }
 int mlp3(ds2_model* m, hipStream_t st, const std::string& p, int M, const float* A, int lda, int hidden, int n_out, float* out,
          int ldc, int last_act) {
+#ifndef DS2_MLP3_FUSED
+#define DS2_MLP3_FUSED 1
+#endif
+  if (DS2_MLP3_FUSED && hidden == 256 && M <= 64 && n_out <= 256)   // one launch, exact fp32 (kernels.hip k_mlp3_256)
+    return launch_mlp3_256(A, lda, m->P(p + ".layers.0.weight"), m->P(p + ".layers.0.bias"), m->P(p + ".layers.1.weight"),
+                           m->P(p + ".layers.1.bias"), m->P(p + ".layers.2.weight"), m->P(p + ".layers.2.bias"), n_out, out, ldc,
+                           last_act, M, st);
   const size_t mark = m->ws_top;
   ALLOC(h1, (size_t)M * hidden);
   ALLOC(h2, (size_t)M * hidden);
