@@ -42,6 +42,8 @@ class HipOps:
 
     def set_precision(self, mode: str):
         """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, default)."""
+        if mode not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {mode!r}")
         _capi.check(self.lib.ds2_set_precision({"fp32": 0, "bf16x3": 1}[mode]), "ds2_set_precision")
 
     def get_precision(self) -> str:

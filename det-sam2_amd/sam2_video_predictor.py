@@ -251,7 +251,8 @@ class SAM2VideoPredictor:
         return self.add_new_points_or_box(*a, **k)
 
     def add_new_mask(self, *a, **k):
-        raise NotImplementedError("add_new_mask (mask prompts) is next-row F3 of the scope table, not built yet")
+        raise NotImplementedError("add_new_mask (user-drawn mask prompts) is not part of the Det-SAM2 hot path "
+                                  "(det_sam2_RT.py only issues box prompts, :297-302)")
 
     def _video_res(self, st, low, packed=False):
         """_get_orig_video_res_output (sam2_video_predictor.py:618-642)."""
