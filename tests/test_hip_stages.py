@@ -115,6 +115,45 @@ def test_memory_attention_and_bank(prec):
     assert e_mem == 0.0 and e_pos < 1e-5 and e < TOL[prec], (e_mem, e_pos, e)
 
 
+def test_memory_attention_at_bench_size():
+    """The measured configuration's dominant stage at FULL size: 16 objects, 7-frame bank + 16 object pointers
+    (Nk = 28736), bf16x3 arithmetic, against the oracle (about 40 s of host time on the GPU box)."""
+    from det_sam2_amd.hip_model import HipSam2
+    cfg = resolve_config("sam2.1_hiera_t")          # the memory-attention weights have the same shapes in every config
+    sd = synthetic_state_dict(cfg, 0)
+    hm = HipSam2(cfg, sd, "cuda:0", max_batch=16)
+    hm.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(21)
+    B, NF, NP = 16, 7, 16
+    curr = torch.randn(4096, 256, generator=g)
+    feats = [torch.randn(B, 64, 64, 64, generator=g).to(torch.bfloat16) for _ in range(NF)]
+    ptrs = [torch.randn(B, 256, generator=g) for _ in range(NP)]
+    tpos_rows = [6, 5, 4, 3, 2, 1, 0]
+    ptr_pos = [float(i) for i in range(NP)]
+    pos2 = M.sine_pos_2d(64, 64, 64)
+    mems, poss = [], []
+    for f, r in zip(feats, tpos_rows):
+        mems.append(f.float().flatten(2).permute(2, 0, 1))
+        poss.append(pos2[None].expand(B, -1, -1, -1).flatten(2).permute(2, 0, 1) + sd["maskmem_tpos_enc"][r])
+    op = M.linear(sd, "obj_ptr_tpos_proj", M.sine_pe_1d(torch.tensor(ptr_pos) / 15.0, 256))
+    op = op.unsqueeze(1).expand(-1, B, 64).repeat_interleave(4, dim=0)
+    pt = torch.stack(ptrs, 0).reshape(-1, B, 4, 64).permute(0, 2, 1, 3).flatten(0, 1)
+    memory, memory_pos = torch.cat(mems + [pt], 0), torch.cat(poss + [op], 0)
+    assert memory.shape[0] == 28736
+    vis_pos = M.sine_pos_2d(256, 64, 64).flatten(1).T
+    with torch.inference_mode():
+        ref = M.memory_attention(sd, cfg, curr[:, None].expand(-1, B, -1), vis_pos[:, None].expand(-1, B, -1), memory,
+                                 memory_pos, 4 * NP)
+    d = hm.device
+    mem_d, pos_d = hm.bank_assemble(B, [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)],
+                                    [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)])
+    out = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP)
+    torch.cuda.synchronize()
+    e = rel_err(out, ref.transpose(0, 1))
+    record("memory_attention_bench_size", B=B, Nk=28736, err=e)
+    assert e < TOL["bf16x3"], e
+
+
 @pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True), ("click", True), ("clicks", False)])
 def test_sam_heads(prompt, multimask, prec):
     cfg, sd, hm = model("sam2.1_hiera_t", prec)
