@@ -56,7 +56,7 @@ def test_ingest_bit_exact():
     assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
 
 
-@pytest.mark.parametrize("name", ["sam2.1_hiera_t", "sam2.1_hiera_b+", "sam2.1_hiera_l"])
+@pytest.mark.parametrize("name", ["sam2.1_hiera_t", "sam2.1_hiera_s", "sam2.1_hiera_b+", "sam2.1_hiera_l"])
 def test_image_encoder(name, prec):
     cfg, sd, hm = model(name, prec)
     imgs, _, _ = load_frames([synthetic_frame(5)])
