@@ -131,7 +131,7 @@ def main():
         pred.add_new_points_or_box(st, 0, o, box=synthetic_box(o % 16, 0, seed))
     gen = pred.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=n_frames, reverse=False, output="packed")
     hv, wv = st["video_height"], st["video_width"]
-    host = torch.empty((K, B, hv, wv // 8), dtype=torch.uint8).pin_memory()
+    host = torch.empty((K, B, hv, (wv + 7) // 8), dtype=torch.uint8).pin_memory()
     next(gen)                                   # frame 0: conditioning frame (no tracking)
     for _ in range(PREFILL + W):                # fill the bank to steady state + warmup
         next(gen)

@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64) void k_bank_ptr(BankArgs a, const float* dim_t)
 // packing order = numpy.packbits (MSB first).  One thread per 8 output pixels.
 __global__ void k_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits, uint8_t* packed) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int wb = Wv / 8;
+  const int wb = (Wv + 7) / 8;          // packed row pitch: numpy.packbits pads the last byte with zero bits
   if (i >= (size_t)B * Hv * wb) return;
   const int xb = (int)(i % wb), y = (int)((i / wb) % Hv), b = (int)(i / ((size_t)wb * Hv));
   const float sy = (float)hin / (float)Hv, sx = (float)hin / (float)Wv;
@@ -713,6 +713,7 @@ __global__ void k_mask_output(const float* low, int B, int hin, int Hv, int Wv, 
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int x = xb * 8 + k;
+    if (x >= Wv) break;
     const float v = (hin == Hv && hin == Wv) ? img[(size_t)y * hin + x] : bilerp(img, hin, ly, lerp_coef(x, sx, hin));
     if (logits) logits[((size_t)b * Hv + y) * Wv + x] = v;
     bits |= (v > 0.f ? 1u : 0u) << (7 - k);
@@ -967,8 +968,7 @@ int launch_bank_ptr(const BankArgs& a, const float* dim_t, hipStream_t st) {
   return DS2_OK;
 }
 int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits, uint8_t* packed, hipStream_t st) {
-  DS2_REQUIRE(Wv % 8 == 0, "mask_output: video width must be a multiple of 8 (got %d)", Wv);
-  hipLaunchKernelGGL(k_mask_output, grid1((size_t)B * Hv * (Wv / 8)), dim3(256), 0, st, low, B, hin, Hv, Wv, logits, packed);
+  hipLaunchKernelGGL(k_mask_output, grid1((size_t)B * Hv * ((Wv + 7) / 8)), dim3(256), 0, st, low, B, hin, Hv, Wv, logits, packed);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

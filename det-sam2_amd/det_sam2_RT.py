@@ -132,7 +132,7 @@ class VideoProcessor:
         if packed:
             host = torch.stack([b for _, _, b in packed]).cpu().numpy()
             for (t, ids, _), pb in zip(packed, host):
-                m = np.unpackbits(pb, axis=-1).reshape(len(ids), 1, hv, wv).astype(bool)
+                m = np.unpackbits(pb, axis=-1)[..., :wv].reshape(len(ids), 1, hv, wv).astype(bool)
                 self.video_segments[t] = {oid: m[i] for i, oid in enumerate(ids)}
 
     def _release(self, frame_idx):

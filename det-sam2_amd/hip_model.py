@@ -211,10 +211,11 @@ class HipSam2(HipOps):
         return out
 
     def mask_output(self, low_res, hv, wv, want_logits=True, want_packed=True):
-        """low_res [B,256,256] -> (logits fp32 [B,1,hv,wv] | None, packed uint8 [B,hv,wv/8] | None) (A15)."""
+        """low_res [B,256,256] -> (logits fp32 [B,1,hv,wv] | None, packed uint8 [B,hv,ceil(wv/8)] | None) (A15);
+        packed rows are numpy.packbits rows (MSB first, last byte zero-padded)."""
         B = low_res.shape[0]
         logits = self._empty(B, 1, hv, wv) if want_logits else None
-        packed = self._empty(B, hv, wv // 8, dtype=torch.uint8) if want_packed else None
+        packed = self._empty(B, hv, (wv + 7) // 8, dtype=torch.uint8) if want_packed else None
         _capi.check(self.lib.ds2_mask_output(self.h, _p(low_res), B, hv, wv, _p(logits), _p(packed), self._stream()),
                     "ds2_mask_output")
         return logits, packed

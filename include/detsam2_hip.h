@@ -139,7 +139,7 @@ int ds2_fill_holes(float* logits, int32_t N, int32_t H, int32_t W, int32_t max_a
 
 /* ---- A15: _get_orig_video_res_output (sam2_video_predictor.py:618-642) + `> 0` (det_sam2_RT.py:396-399):
  * low_res [B,256,256] -> logits fp32 [B,Hv,Wv] (may be NULL) and/or masks packed 8 px/byte, MSB first
- * (numpy.packbits order) [B,Hv,Wv/8] (may be NULL). */
+ * (numpy.packbits rows, last byte zero-padded) [B,Hv,ceil(Wv/8)] (may be NULL). */
 int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
                     uint8_t* packed, void* stream);
 

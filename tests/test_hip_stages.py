@@ -231,12 +231,14 @@ def test_mask_output():
     cfg, sd, hm = model("sam2.1_hiera_t")
     g = torch.Generator().manual_seed(3)
     low = torch.randn(3, 1, 256, 256, generator=g)
-    for hv, wv in ((1024, 1024), (720, 1280), (256, 256)):
+    for hv, wv in ((1024, 1024), (720, 1280), (256, 256), (271, 477), (5, 3)):
         ref = low if (hv, wv) == (256, 256) else F.interpolate(low, size=(hv, wv), mode="bilinear", align_corners=False)
         logits, packed = hm.mask_output(low[:, 0].contiguous().to(hm.device), hv, wv)
         torch.cuda.synchronize()
         e = float((logits.cpu() - ref).abs().max())
-        bits = np.unpackbits(packed.cpu().numpy(), axis=-1).astype(bool)
+        assert packed.shape == (3, hv, (wv + 7) // 8)
+        bits = np.unpackbits(packed.cpu().numpy(), axis=-1)[..., :wv].astype(bool)
+        assert np.array_equal(packed.cpu().numpy(), np.packbits(logits.cpu().numpy()[:, 0] > 0, axis=-1))
         mism = float((bits != (logits.cpu().numpy()[:, 0] > 0)).mean())
         record("mask_output", hv=hv, wv=wv, err=e, mism=mism)
         assert e < 1e-5 and mism == 0.0, (e, mism)
