@@ -184,14 +184,14 @@ static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const 
 // tracked frame, i.e. 21 tile GEMMs + 21 operand splits of ~10 us each when done as GEMMs.  One block per row, the
 // activations stay in LDS; a wave owns output features j and its lanes split the 256-long dot product (16-byte
 // coalesced weight reads, butterfly reduction).  Exact fp32 FMA.
-__global__ __launch_bounds__(256) void k_mlp3_256(const float* __restrict__ A, int lda, const float* __restrict__ w0,
+__global__ __launch_bounds__(512) void k_mlp3_256(const float* __restrict__ A, int lda, const float* __restrict__ w0,
                                                   const float* __restrict__ b0, const float* __restrict__ w1,
                                                   const float* __restrict__ b1, const float* __restrict__ w2,
                                                   const float* __restrict__ b2, int n_out, float* __restrict__ out, int ldc,
                                                   int last_act) {
   __shared__ __attribute__((aligned(16))) float x[2][256];
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  x[0][t] = A[(size_t)row * lda + t];
+  if (t < 256) x[0][t] = A[(size_t)row * lda + t];
   __syncthreads();
 #pragma unroll 1
   for (int layer = 0; layer < 3; ++layer) {
@@ -200,22 +200,22 @@ __global__ __launch_bounds__(256) void k_mlp3_256(const float* __restrict__ A, i
     const int nout = layer == 2 ? n_out : 256;
     const int act = layer == 2 ? last_act : DS2_ACT_RELU;
     const float4 xv = *reinterpret_cast<const float4*>(&x[layer & 1][4 * lane]);
-    // 8 output features per pass: 8 independent 16-byte weight loads in flight per lane (a serial loop pays the full
-    // L2 latency 64 times per layer)
-    for (int j0 = wave * 8; j0 < nout; j0 += 32) {
-      float4 wv[8];
+    // 8 waves x 16 output features per pass: 16 independent 16-byte weight loads in flight per lane (a serial loop
+    // pays the full L2 latency once per feature)
+    for (int j0 = wave * 16; j0 < nout; j0 += 128) {
+      float4 wv[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int j = j0 + u < nout ? j0 + u : nout - 1;
         wv[u] = *reinterpret_cast<const float4*>(w + (size_t)j * 256 + 4 * lane);
       }
-      float s[8];
+      float mine = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s[u] = wave_sum(fmaf(wv[u].x, xv.x, fmaf(wv[u].y, xv.y, fmaf(wv[u].z, xv.z, wv[u].w * xv.w))));
-      if (lane < 8 && j0 + lane < nout) {
-        float mine = s[0];
-#pragma unroll
-        for (int u = 1; u < 8; ++u) mine = lane == u ? s[u] : mine;
+      for (int u = 0; u < 16; ++u) {
+        const float su = wave_sum(fmaf(wv[u].x, xv.x, fmaf(wv[u].y, xv.y, fmaf(wv[u].z, xv.z, wv[u].w * xv.w))));
+        mine = lane == u ? su : mine;
+      }
+      if (lane < 16 && j0 + lane < nout) {
         const int j = j0 + lane;
         const float v = ds2_act(mine + b[j], act);
         if (layer == 2) out[(size_t)row * ldc + j] = v;
@@ -984,7 +984,7 @@ int launch_mask_downscale_add(const float* mask, const float* const* prm, const 
 int launch_mlp3_256(const float* A, int lda, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
                     const float* b2, int n_out, float* out, int ldc, int last_act, int rows, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && n_out > 0 && n_out <= 256 && w0 && b0 && w1 && b1 && w2 && b2, "mlp3: bad argument");
-  hipLaunchKernelGGL(k_mlp3_256, dim3(rows), dim3(256), 0, st, A, lda, w0, b0, w1, b1, w2, b2, n_out, out, ldc, last_act);
+  hipLaunchKernelGGL(k_mlp3_256, dim3(rows), dim3(512), 0, st, A, lda, w0, b0, w1, b1, w2, b2, n_out, out, ldc, last_act);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
