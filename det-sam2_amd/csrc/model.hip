@@ -800,6 +800,21 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
 // ------------------------------------------------------------------------------------------------ A7 + A8
 namespace {
 // Attention module of the two-way transformer (transformer.py:239-284): projections + SDPA + out_proj.
+// keys + key_pe (transformer.py:196-197,211) whose only consumers are projection GEMMs: in bf16x3 mode it is emitted
+// directly as operand planes registered under `kpe` (one pass, re-used by every GEMM that reads it) instead of an fp32
+// tensor that each GEMM would split again.
+#ifndef DS2_KPE_PLANES
+#define DS2_KPE_PLANES 1
+#endif
+int keys_plus_pe(ds2_model* m, hipStream_t st, const float* keys, const float* dense_pe, float* kpe, int rows) {
+  if (DS2_KPE_PLANES && g_ds2_precision == DS2_PREC_BF16X3) {
+    ds2_model::ActPlanes kp;
+    TRY(new_act_planes(m, kpe, rows, 256, &kp, st));
+    return launch_add_bcast_split(keys, 256, dense_pe, 256, TOK, 1.0f, kp.hi, kp.lo, kp.ld, rows, 256, st);
+  }
+  m->act_planes.erase(kpe);
+  return launch_add_bcast(keys, 256, dense_pe, 256, TOK, 1.f, kpe, 256, rows, 256, st);
+}
 // q_in [B*Lq,256], k_in/v_in [B*Lk,256]; result (+ optional residual R) -> out [B*Lq,256].
 int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int Lq, int Lk, int internal,
                   const float* q_in, const float* k_in, const float* v_in, float* out, const float* R) {
@@ -859,7 +874,8 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.sam_heads", st);
   const int rows = B * TOK;
-  const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * 16 * 2048 * 4) * 4 + (8u << 20);
+  const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * 16 * 2048 * 4) * 4 +
+                      (size_t)3 * rows * 256 * 4 /* key + pe operand planes, one set per use */ + (8u << 20);
   TRY(m->require(need, st));
   const std::string md = "sam_mask_decoder", tr = md + ".transformer";
   // no prompt => the reference feeds one dummy point labelled -1 (sam2_base.py:298-301)
@@ -924,7 +940,7 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
     TRY(layernorm(m, st, p + ".norm1", tmpq, queries, BT, 256, 1e-5f));
     // tokens -> image
     TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
-    TRY(launch_add_bcast(keys, 256, dense_pe, 256, TOK, 1.f, kpe, 256, rows, 256, st));
+    TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
     TRY(sam_attention(m, st, p + ".cross_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
     TRY(layernorm(m, st, p + ".norm2", tmpq, queries, BT, 256, 1e-5f));
     // MLP
@@ -937,7 +953,7 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
     TRY(layernorm(m, st, p + ".norm4", tmpk, keys, rows, 256, 1e-5f));
   }
   TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
-  TRY(launch_add_bcast(keys, 256, dense_pe, 256, TOK, 1.f, kpe, 256, rows, 256, st));
+  TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
   TRY(sam_attention(m, st, tr + ".final_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
   float* hs = queries;
   TRY(layernorm(m, st, tr + ".norm_final_attn", tmpq, hs, BT, 256, 1e-5f));
