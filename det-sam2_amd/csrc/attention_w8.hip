@@ -53,9 +53,12 @@ __device__ __forceinline__ int vt_pos16(int key) { return 8 * ((key >> 2) & 3) +
 // vt[b][tile][plane][dv 0..DVT-1][pos 0..31].  One thread per (tile, dv) row: 32 key loads (coalesced across the
 // lanes, which differ in dv), split, and two contiguous 64-byte stores (hi / lo plane rows) - HBM-bound, 4 B read +
 // 4 B written per element (the one-element-per-thread version with 2-byte scattered stores ran at 1 TB/s).
+// Tiles < n_flag_tiles are expected to hold bf16-exact values (memory-bank frame tokens are bf16 storage upcast to
+// fp32, so their lo plane is identically zero): if any lo value there is NOT zero, *flag is raised and the attention
+// kernel keeps the full three-term P.V product for every tile - the fast path is taken only when it is exact.
 template <int DVT>
 __global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v, int ldv, int batch, int L,
-                                                    unsigned short* __restrict__ vt) {
+                                                    unsigned short* __restrict__ vt, int n_flag_tiles, int* __restrict__ flag) {
   const int ntile = (L + 31) / 32;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)batch * ntile * DVT) return;
@@ -74,6 +77,12 @@ __global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v,
     h[pos >> 1] = hh;
     l[pos >> 1] = cvt_pk_bf16(x0 - bf_lo(hh), x1 - bf_hi(hh));
   }
+  if (tile < n_flag_tiles) {
+    unsigned any = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) any |= l[j] & 0x7fff7fffu;   // -0 counts as zero
+    if (any) atomicOr(flag, 1);
+  }
   uint4* oh = reinterpret_cast<uint4*>(vt + bt * 2 * (32 * DVT) + (size_t)dv * 32);
   uint4* ol = reinterpret_cast<uint4*>(vt + bt * 2 * (32 * DVT) + 32 * DVT + (size_t)dv * 32);
 #pragma unroll
@@ -91,6 +100,9 @@ struct W8Args {
   int batch, Lq, Lk;
   float scale;
   unsigned short *o_hi, *o_lo; int ldop;   // optional: emit the result as bf16 planes (consumer is a GEMM)
+  // key tiles [0, n_hi_tiles) have an all-zero V lo plane unless *vlo_flag != 0 (k_vt_split16): their P.V product
+  // needs two MFMA terms instead of three and no lo-plane staging.  n_hi_tiles == 0 disables the fast path.
+  int n_hi_tiles; const int* vlo_flag;
 };
 
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
@@ -108,7 +120,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   const int l15 = lane & 15, grp = lane >> 4;
   const int nqb = a.Lq / BQ, nblk = a.batch * nqb;
   int bid = blockIdx.x;
-  if (nblk % 8 == 0) bid = (bid % 8) * (nblk / 8) + bid / 8;   // whole objects per XCD (shared K/V stay in one L2)
+  {   // consecutive block ids (= the query blocks of one object) on one XCD: shared K/V stay in one L2.  Bijective
+      // for any block count (e.g. 17 objects), cdna_hip_programming.md T1.
+    const int xcd = bid % 8, qq = nblk / 8, rr = nblk % 8;
+    bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + bid / 8;
+  }
   const int b = bid / nqb, q0i = (bid % nqb) * BQ;
   const float sc = a.scale * 1.44269504088896340736f;
 
@@ -151,6 +167,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   }
 
   const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
+  // tiles below n_hi have a zero V lo plane (block-uniform; read once)
+  const int n_hi = (DV == 64 && a.n_hi_tiles > 0 && a.vlo_flag && __builtin_nontemporal_load(a.vlo_flag) == 0) ? a.n_hi_tiles : 0;
   // staging: K planes = 2 x (32 rows x 32 uint4); thread handles uint4 #(tid + 512 i), i = 0..3; V^T planes =
   // 2 x (64 rows x 4 uint4), one uint4 per thread
   const int kpart = tid & 31, krow = (tid >> 5) & 15;         // rows krow and krow+16 of each plane
@@ -170,10 +188,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     rk1 = a.k_hi[(kbase + k1_) * 32 + kpart];                                 \
     rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                                 \
     rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                                 \
-    _Pragma("unroll") for (int j = 0; j < NVLD; ++j) rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; \
+    _Pragma("unroll") for (int j = 0; j < NVLD; ++j)                          \
+      if (DV != 64 || kt_ >= n_hi || tid < 256) rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; /* DV=64: threads >= 256 stage the lo plane */ \
   }
-#define W8_STORE(BUF)                                                         \
+#define W8_STORE(BUF, STKT)                                                   \
   {                                                                           \
+    const int st_kt_ = (STKT);                                                \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso0]) = rk0;                       \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso1]) = rk1;                       \
     *reinterpret_cast<uint4*>(&Kp[BUF][1][kso0]) = rk2;                       \
@@ -181,12 +201,13 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j) {                        \
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
-      *reinterpret_cast<uint4*>(&Vp[BUF][pl_][rw_ * VROWB + pt_ * 16]) = rv[j]; \
+      if (DV != 64 || st_kt_ >= n_hi || tid < 256)                            \
+        *reinterpret_cast<uint4*>(&Vp[BUF][pl_][rw_ * VROWB + pt_ * 16]) = rv[j]; \
     }                                                                         \
   }
 
   W8_LOAD(0)
-  W8_STORE(0)
+  W8_STORE(0, 0)
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nkt; ++kt) {
@@ -257,14 +278,15 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     if constexpr (NT <= 4) {
       bf16x8 v0[NT], v1[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
-        v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+      for (int t = 0; t < NT; ++t) v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
+      if (kt >= n_hi) {   // V lo plane present: third product term
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[t], pb0[g], o[g][t], 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[t], pb0[g], o[g][t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
         }
       }
     }
-    W8_STORE(cur ^ 1)
+    W8_STORE(cur ^ 1, (kt + 1 < nkt ? kt + 1 : kt))
     __syncthreads();
     cur ^= 1;
   }
@@ -320,29 +342,33 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 
 }  // namespace
 
-int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st) {
+int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys, int* flag) {
   DS2_REQUIRE(dv == 64 || dv == 128 || dv == 256, "vt_split16: dv must be 64, 128 or 256");
   const size_t n = (size_t)batch * ((L + 31) / 32) * dv;     // one thread per (tile, dv) row
   const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
   unsigned short* out = reinterpret_cast<unsigned short*>(vt);
+  const int nft = flag ? n_exact_keys / 32 : 0;
+  if (flag) DS2_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
   if (dv == 64)
-    hipLaunchKernelGGL((k_vt_split16<64>), grid, blk, 0, st, v, ldv, batch, L, out);
+    hipLaunchKernelGGL((k_vt_split16<64>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
   else if (dv == 128)
-    hipLaunchKernelGGL((k_vt_split16<128>), grid, blk, 0, st, v, ldv, batch, L, out);
+    hipLaunchKernelGGL((k_vt_split16<128>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
   else
-    hipLaunchKernelGGL((k_vt_split16<256>), grid, blk, 0, st, v, ldv, batch, L, out);
+    hipLaunchKernelGGL((k_vt_split16<256>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
-                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop) {
+                        int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
+                        int n_exact_keys, const int* vlo_flag) {
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
   static const bool qg1 = [] { const char* e = getenv("DS2_ATTN_QG"); return e && atoi(e) == 1; }();
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
-           reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop};
+           reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
+           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag};
   DS2_REQUIRE(o || o_hi, "attention_w8: no output");
   if (dv == 64 && !qg1)
     hipLaunchKernelGGL((k_attention_w8<64, 2>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);

@@ -58,7 +58,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
   const int orig = blockIdx.x;
   const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-  const int tile_m = wg / nt, tile_n = wg % nt;
+  int tile_m = wg / nt, tile_n = wg % nt;
+  if (g.group_m > 1) {   // grouped order: the blocks an XCD runs concurrently cover group_m tile rows x few tile columns
+    const int per = g.group_m * nt, first = (wg / per) * g.group_m, in = wg % per;
+    const int gsz = mt - first < g.group_m ? mt - first : g.group_m;
+    tile_m = first + in % gsz;
+    tile_n = in / gsz;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
@@ -327,7 +333,14 @@ int heuristic_tile(const GemmSplitArgs& g) {
   return tile;
 }
 
-int launch_tile(const GemmSplitArgs& g, int tile, hipStream_t st) {
+int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
+  GemmSplitArgs g = g_in;
+  {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
+    static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
+    const int bn = (tile == 4) ? 256 : 128;
+    const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
+    g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
+  }
   if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
   if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);

@@ -38,7 +38,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
   const int orig = blockIdx.x;
   const int xcd = orig % 8, q = nwg / 8, r = nwg % 8;
   const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
-  const int tile_m = wg / nt, tile_n = wg % nt;
+  int tile_m = wg / nt, tile_n = wg % nt;
+  if (g.group_m > 1) {   // grouped order: the blocks an XCD runs concurrently cover group_m tile rows x few tile columns
+    const int per = g.group_m * nt, first = (wg / per) * g.group_m, in = wg % per;
+    const int gsz = mt - first < g.group_m ? mt - first : g.group_m;
+    tile_m = first + in % gsz;
+    tile_n = in / gsz;
+  }
   const int m0 = tile_m * RBM, n0 = tile_n * RBN;
 
   const int tid = threadIdx.x;

@@ -86,6 +86,10 @@ struct GemmSplitArgs {
   // optional axial RoPE applied to the result before it is split into planes (cross-attention keys): row m is
   // token t = m % rope_L of its batch item; tokens t < rope_n are rotated with cis[(t % rope_grid)][col/2]
   const float* rope_cis; int rope_L, rope_n, rope_grid;
+  // block -> tile order inside an XCD's share of the grid: 0/1 = row-major over n; > 1 = groups of group_m tile rows
+  // walked column-major (the ~32 blocks an XCD runs at once then share A rows AND W rows through its L2).  Set by
+  // launch_gemm_split.
+  int group_m;
 };
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 256x128 blocks, 8 waves, 3-stage LDS-DMA ring
@@ -93,10 +97,15 @@ int launch_gemm_split256(const GemmSplitArgs& g, int mf, hipStream_t st);   // 2
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);
 
 // 8-wave variant on v_mfma_f32_16x16x32_bf16 (attention_w8.hip); V^T tiles use a different key permutation
-int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st);   // dv = 64 | 128
+// n_exact_keys/flag (optional): the leading n_exact_keys keys are expected to be bf16-exact; *flag (device int) is
+// zeroed and then raised by the kernel if any of them has a non-zero lo part (see launch_attention_w8)
+int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys = 0,
+                      int* flag = nullptr);   // dv = 64 | 128
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi = nullptr,
-                        void* o_lo = nullptr, int ldop = 0);   // o_hi/o_lo: emit bf16 planes [rows, ldop] instead of fp32
+                        void* o_lo = nullptr, int ldop = 0,    // o_hi/o_lo: emit bf16 planes [rows, ldop] instead of fp32
+                        int n_exact_keys = 0, const int* vlo_flag = nullptr);   // dv = 64: keys < n_exact_keys have a zero
+                                                                                // V lo plane unless *vlo_flag != 0
 
 // producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,

@@ -173,8 +173,8 @@ bool use_w8() {
   static const bool v = [] { const char* e = getenv("DS2_ATTN_KERNEL"); return !(e && strcmp(e, "split") == 0); }();
   return v;
 }
-int vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
-  return use_w8() ? launch_vt_split16(v, ldv, batch, L, vt, 64, st) : launch_vt_split(v, ldv, batch, L, vt, st);
+int vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st, int n_exact_keys = 0, int* flag = nullptr) {
+  return use_w8() ? launch_vt_split16(v, ldv, batch, L, vt, 64, st, n_exact_keys, flag) : launch_vt_split(v, ldv, batch, L, vt, st);
 }
 int attn_split(const float* q, int ldq, const void* khi, const void* klo, const void* vt, float* o, int ldo, int batch,
                int Lq, int Lk, float scale, hipStream_t st) {
@@ -692,12 +692,19 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
   ALLOC(h, (size_t)rows * F);
   // bf16x3 mode: attention operands are split into bf16 planes once by their producers (attention_split.hip)
   void *khi = nullptr, *klo = nullptr, *vt_c = nullptr, *khi_s = nullptr, *klo_s = nullptr, *vt_s = nullptr;
+  int* vlo_flag = nullptr;
   if (split) {
     vt_c = m->alloc_bytes((size_t)B * nt_c * 8192);
     khi_s = m->alloc_bytes((size_t)rows * 512); klo_s = m->alloc_bytes((size_t)rows * 512);
     vt_s = m->alloc_bytes((size_t)4 * B * nt_s * 8192);
     if (!vt_c || !khi_s || !klo_s || !vt_s) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
-    TRY(vt_split(memory, 64, B, Nk, vt_c, st));   // V = raw memory (64-d), shared by the 4 layers
+    // V = raw memory (64-d), shared by the 4 layers.  Frame tokens of the bank are bf16 storage (lo plane == 0): the
+    // split kernel verifies that on the fly (vlo_flag) and the attention kernel then skips the lo term for those tiles.
+    vlo_flag = reinterpret_cast<int*>(m->alloc_bytes(256));
+    if (!vlo_flag) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
+    static const bool no_vlo_skip = getenv("DS2_ATTN_NO_VLO_SKIP") != nullptr;
+    if (no_vlo_skip) vlo_flag = nullptr;
+    TRY(vt_split(memory, 64, B, Nk, vt_c, st, Nk - n_ptr_tok, vlo_flag));
   }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
   TRY(launch_add_bcast(curr, 256, m->P("#vision_pos"), 256, 0, 0.1f, x1, 256, TOK, 256, st));
@@ -769,7 +776,8 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
       if (use_w8()) {
         ds2_model::ActPlanes cp;
         TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
-        TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld));
+        TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
+                                Nk - n_ptr_tok, vlo_flag));
       } else {
         TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
       }

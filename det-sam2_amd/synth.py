@@ -42,12 +42,14 @@ class SyntheticDetector:
     """Callable ``(frame_abs_idx, frame_rgb) -> list[detection dict]`` at the YOLO output contract
     (det_sam2_RT.py:228-244).  ``appear`` maps object id -> first frame on which it is detected; ``duplicates``
     maps object id -> number of EXTRA detections of that class per frame (YOLO emitting several boxes of one class:
-    every further box is a second prompt for the same object on the same frame, sam2_video_predictor.py:470-483)."""
+    every further box is a second prompt for the same object on the same frame, sam2_video_predictor.py:470-483).
+    ``class_ids[o]`` is the YOLO class id reported for object ``o`` (default: ``o``)."""
 
-    def __init__(self, num_objects: int, seed: int = 0, size: int = 1024, appear=None, duplicates=None):
+    def __init__(self, num_objects: int, seed: int = 0, size: int = 1024, appear=None, duplicates=None, class_ids=None):
         self.num_objects, self.seed, self.size = num_objects, seed, size
         self.appear = dict(appear or {})
         self.duplicates = dict(duplicates or {})
+        self.class_ids = list(class_ids) if class_ids is not None else list(range(num_objects))
 
     def __call__(self, frame_idx, frame=None):
         out = []
@@ -55,10 +57,10 @@ class SyntheticDetector:
             if frame_idx < self.appear.get(o, 0):
                 continue
             out.append({"coordinates": synthetic_box(o, frame_idx, self.seed, self.size),
-                        "class": np.array([float(o)], np.float32),
+                        "class": np.array([float(self.class_ids[o])], np.float32),
                         "confidence": np.array([0.99], np.float32)})
             for k in range(self.duplicates.get(o, 0)):   # same class, a differently jittered box
                 out.append({"coordinates": synthetic_box(o, frame_idx + 1000 * (k + 1), self.seed, self.size),
-                            "class": np.array([float(o)], np.float32),
+                            "class": np.array([float(self.class_ids[o])], np.float32),
                             "confidence": np.array([0.9], np.float32)})
         return out

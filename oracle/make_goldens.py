@@ -2,7 +2,9 @@
 the build container through oracle/_ref_shims.py).  The reference cannot travel to the GPU
 box, so its outputs are committed as small fixtures together with this script.
 
-    python -m oracle.make_goldens            # all fixtures (a few minutes of CPU)
+    python -m oracle.make_goldens            # the sam2.1_hiera_t fixtures (a few minutes of CPU)
+    python -m oracle.make_goldens l1:sam2.1_hiera_l e2e_large e2e_b16 e2e_b17 e2e_classes e2e_mask
+                                             # fixtures of the larger configs / batch sizes (tens of minutes)
 
 Fixtures are data only: seeds, boxes, and reference outputs (sub-sampled where large).
 Inputs are regenerated from seeds (det_sam2_amd.synth / det_sam2_amd.weights), never stored.
@@ -224,10 +226,129 @@ def e2e_stream2(name="sam2.1_hiera_t"):
     print("e2e_stream2", dt, "s", passes, final_keys, vp.inference_state["images_idx"])
 
 
+def _compact(out, i, low, hi_bits):
+    """Compact per-yield record for many-object fixtures: exact sign of every low-res logit (packed), the logits
+    themselves 4x decimated in fp16, and the video-res masks 4x decimated (packed)."""
+    out[f"lowbits{i}"] = np.packbits(low > 0)
+    out[f"low{i}"] = low[:, :, ::4, ::4].astype(np.float16)
+    out[f"bits{i}"] = np.packbits(hi_bits[:, :, ::4, ::4])
+
+
+LARGE_KW = dict(skip_classes=set(), frame_buffer_size=3, detect_interval=3, max_frame_num_to_track=3,
+                max_inference_state_frames=-1)
+
+
+def e2e_large(name="sam2.1_hiera_l"):
+    """The headline model end to end: sam2.1_hiera_l, 3 frames, 2 objects, one pass (the scenario of
+    tests/test_hip_e2e.py::test_hiera_large_matches_reference)."""
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 3, SyntheticDetector(2), **LARGE_KW)
+    out = {"seconds": np.float64(dt), "frames": np.array([y[1] for y in yields]),
+           "low": np.stack([y[3] for y in yields]),                      # [3,2,1,256,256] fp32 logits
+           "bits": np.stack([np.packbits(y[4]) for y in yields])}
+    np.savez_compressed(os.path.join(GOLD, "e2e_large.npz"), **out)
+    print("e2e_large", dt, "s", out["frames"], out["low"].shape, passes, final_keys)
+
+
+B16_KW = dict(skip_classes=set(), frame_buffer_size=3, detect_interval=3, max_frame_num_to_track=3,
+              max_inference_state_frames=-1)
+
+
+def e2e_b16(name="sam2.1_hiera_t"):
+    """16 objects (the batch size of BASELINE configs 3-5) end to end on the tiny model: 3 frames, one pass."""
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 3, SyntheticDetector(16), **B16_KW)
+    out = {"seconds": np.float64(dt), "frames": np.array([y[1] for y in yields]),
+           "nobj": np.array([len(y[2]) for y in yields])}
+    for i, y in enumerate(yields):
+        _compact(out, i, y[3], y[4])
+    np.savez_compressed(os.path.join(GOLD, "e2e_b16.npz"), **out)
+    print("e2e_b16", dt, "s", out["frames"], passes, final_keys)
+
+
+B17_KW = dict(skip_classes=set(), frame_buffer_size=2, detect_interval=2, max_frame_num_to_track=4,
+              max_inference_state_frames=-1)
+
+
+def e2e_b17(name="sam2.1_hiera_t"):
+    """BASELINE config 5's mid-stream new category at full batch: 16 objects from frame 0, a 17th class first
+    detected on frame 2 (second pass) => A17 re-consolidation of the cond frames from B=16 to B=17 and a reverse
+    pass over 4 frames with 17 objects."""
+    det = SyntheticDetector(17, appear={16: 2})
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 4, det, **B17_KW)
+    out = {"seconds": np.float64(dt), "pass_id": np.array([y[0] for y in yields]),
+           "frames": np.array([y[1] for y in yields]), "nobj": np.array([len(y[2]) for y in yields]),
+           "final_cond": np.array(final_keys[0]), "final_noncond": np.array(final_keys[1])}
+    for i, y in enumerate(yields):
+        _compact(out, i, y[3], y[4])
+    np.savez_compressed(os.path.join(GOLD, "e2e_b17.npz"), **out)
+    print("e2e_b17", dt, "s", out["frames"], out["nobj"], passes, final_keys)
+
+
+CLASSES_KW = dict(frame_buffer_size=2, detect_interval=1, max_frame_num_to_track=2, max_inference_state_frames=-1)
+CLASSES_IDS = [3, 11, 14, 7, 11]       # detector objects -> YOLO class ids: 11 = special (collected, not tracked), 14 skipped
+
+
+def e2e_classes(name="sam2.1_hiera_t"):
+    """A2 branches with the reference's DEFAULT skip_classes {11, 14, 15, 19} and special class 11
+    (det_sam2_RT.py:201-265,267-316): classes 3 and 7 are tracked, 14 is skipped, the two class-11 boxes are collected
+    in special_classes_detection (first on frame 0 one box - object 4 appears on frame 1, then two)."""
+    det = SyntheticDetector(5, class_ids=CLASSES_IDS, appear={4: 1})
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, 2, det, **CLASSES_KW)
+    out = {"seconds": np.float64(dt), "frames": np.array([y[1] for y in yields]),
+           "obj_ids": np.array(yields[0][2]),
+           "special": np.stack([np.asarray(b, dtype=np.float32).reshape(-1) for b in vp.special_classes_detection]),
+           "special_count": np.int64(vp.special_classes_count),
+           "low": np.stack([y[3] for y in yields]),
+           "bits": np.stack([np.packbits(y[4]) for y in yields])}
+    np.savez_compressed(os.path.join(GOLD, "e2e_classes.npz"), **out)
+    print("e2e_classes", dt, "s", out["frames"], out["obj_ids"], out["special"], out["low"].shape)
+
+
+def mask_prompts():
+    """Seeded mask prompts of e2e_mask: a disc at model resolution (no resize) and an ellipse given at 512x384
+    (exercises the antialiased resize + >= 0.5 branch, sam2_video_predictor.py:552-561)."""
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    m0 = ((xx - 300) ** 2 + (yy - 420) ** 2) < 150 ** 2
+    yy, xx = np.mgrid[0:384, 0:512]
+    m1 = (((xx - 350) / 90.0) ** 2 + ((yy - 200) / 60.0) ** 2) < 1.0
+    return m0, m1
+
+
+def e2e_mask(name="sam2.1_hiera_t"):
+    """F3: add_new_mask / _use_mask_as_output (sam2_video_predictor.py:527-616, sam2_base.py:399-448) through the
+    reference predictor: two mask-prompted objects on frame 0 (+ an all-empty mask for a third), forward propagation
+    over 4 frames."""
+    cfg = resolve_config(name)
+    sd = synthetic_state_dict(cfg, 0)
+    ref = RS.instantiate_from_yaml(f"configs/sam2.1/{name}.yaml", sd)
+    frames = [synthetic_frame(t) for t in range(4)]
+    m0, m1 = mask_prompts()
+    t0 = time.time()
+    with torch.inference_mode():
+        st = ref.init_state(frames, offload_video_to_cpu=True, offload_state_to_cpu=False)
+        prompt_out = []
+        for oid, m in ((0, m0), (1, m1), (2, np.zeros((1024, 1024), bool))):
+            _, ids, vr = ref.add_new_mask(st, 0, oid, m)
+            prompt_out.append(np.packbits((vr > 0).numpy()))
+        yields = []
+        for t, ids, logits in ref.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=4, reverse=False):
+            od = st["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            yields.append((t, list(ids), od[key][t]["pred_masks"].clone().numpy(), (logits > 0).numpy(),
+                           od[key][t]["obj_ptr"].clone().numpy(), od[key][t]["object_score_logits"].clone().numpy()))
+    dt = time.time() - t0
+    out = {"seconds": np.float64(dt), "frames": np.array([y[0] for y in yields]),
+           "low": np.stack([y[2] for y in yields]), "bits": np.stack([np.packbits(y[3]) for y in yields]),
+           "obj_ptr0": yields[0][4], "obj_score0": yields[0][5],
+           "prompt_bits2": prompt_out[2]}      # video-res masks returned by the third add_new_mask call (all 3 objects)
+    np.savez_compressed(os.path.join(GOLD, "e2e_mask.npz"), **out)
+    print("e2e_mask", dt, "s", out["frames"], out["low"].shape, out["obj_score0"].ravel())
+
+
 if __name__ == "__main__":
     assert RS.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["schema", "l1", "e2e_cfg1", "e2e_stream2", "e2e_dup", "e2e_preload"]
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("DS2_GOLDEN_THREADS", "8")))
     for w in which:
-        globals()[w]()
+        fn, _, arg = w.partition(":")
+        globals()[fn](*([arg] if arg else []))

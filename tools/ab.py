@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """A/B timing of kernel variants.  Box-to-box noise between gpurun calls is 2-3 %, so variants are compared inside ONE
 call:  build here      : python tools/ab.py build NAME [-DFLAG=1 ...]   -> det-sam2_amd/lib/ab_NAME.so
-       run on the box  : python tools/ab.py run NAME1 NAME2 ... [--rounds 3] (alternates the builds, prints fps + stages)"""
+       run on the box  : python tools/ab.py run NAME1 NAME2 ... [--rounds 3] (alternates the builds, prints fps + stages)
+       env variants    : python tools/ab.py env base name1:VAR=1 name2:VAR=2,OTHER=x ... [--rounds 3]  (default library, or
+                         det-sam2_amd/lib/ab_<name>.so when it exists; the listed variables are set for that variant)"""
 import json
 import os
 import subprocess
@@ -20,11 +22,18 @@ def build(name, flags):
     print(out)
 
 
-def run(names, rounds):
+def run(names, rounds, env_mode=False):
     import __graft_entry__ as g
     for r in range(rounds):
-        for n in names:
-            env = dict(os.environ, DS2_LIB=os.path.join(g.PKG, "lib", f"ab_{n}.so"))
+        for spec in names:
+            n, _, kv = spec.partition(":")
+            env = dict(os.environ)
+            lib = os.path.join(g.PKG, "lib", f"ab_{n}.so")
+            if not env_mode or os.path.exists(lib):
+                env["DS2_LIB"] = lib
+            for item in filter(None, kv.split(",")):
+                k, _, v = item.partition("=")
+                env[k] = v
             o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "1", "--no-cpu-baseline"],
                                env=env, capture_output=True, text=True)
             try:
@@ -44,4 +53,4 @@ if __name__ == "__main__":
             i = a.index("--rounds")
             rounds = int(a[i + 1])
             a = a[:i] + a[i + 2:]
-        run(a, rounds)
+        run(a, rounds, env_mode=(sys.argv[1] == "env"))
