@@ -30,6 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PREFILL = 15  # tracked frames needed before the 7-frame bank + 16 pointers are in steady state
+# extra frames tracked AFTER the timed region with one HIP-event bracket per GEMM (roofline_gemm): one whole encoder batch
+GEMM_PROBE = int(os.environ.get("DS2_ENCODE_BATCH", "10"))
 # MI355X_MICROARCH.md dense MFMA peaks: fp32 (v_mfma_f32_32x32x2_f32) and bf16 (v_mfma_f32_*_bf16)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
 
@@ -91,11 +93,76 @@ def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
                       f"encoder {t_enc:.1f}s + per-object {t_obj:.1f}s; value = 1/(t_enc+16*t_obj)"}
 
 
+def gemm_probe(pred, gen, st, last_tracked, table_path=None):
+    """roofline_gemm: GEMM_PROBE more tracked frames of the same generator with one HIP-event bracket per GEMM
+    (ds2_profile_enable(2), tags "gemm M N K"), outside the timed region so the brackets cannot perturb `value`.
+    Reports the shape with the largest total time: achieved = algorithmic 2*M*N*K / mean bracket time vs the dense bf16
+    MFMA peak (bf16x3 executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3), plus the whole family per frame."""
+    for t in [t for t in st["cached_features"] if t > last_tracked]:     # the probe encodes exactly one batch of new frames
+        st["cached_features"].pop(t)
+    pred.hip.profile_enable(True, gemm_shapes=True)
+    for _ in range(GEMM_PROBE):
+        next(gen)
+    torch.cuda.synchronize()
+    pred.hip.profile_enable(False)
+    rows = []
+    for tag in pred.hip.profile_tags():
+        ms, n = pred.hip.profile_read(tag)
+        if tag.startswith("gemm ") and n:
+            M, N, Kd = (int(x) for x in tag.split()[1:4])
+            rows.append({"M": M, "N": N, "K": Kd, "calls_per_frame": n / GEMM_PROBE, "ms_per_frame": ms / GEMM_PROBE,
+                         "avg_us": ms / n * 1e3, "tflops": 2.0 * M * N * Kd / (ms / n * 1e-3) / 1e12})
+    if not rows:
+        return None
+    rows.sort(key=lambda r: -r["ms_per_frame"])
+    total = sum(r["ms_per_frame"] for r in rows)
+    flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_frame"] for r in rows)
+    if table_path:
+        with open(table_path, "w") as f:
+            f.write(f"# per-shape GEMM table, HIP events, {GEMM_PROBE} tracked frames; total {total:.3f} ms/frame, "
+                    f"{flops / (total * 1e-3) / 1e12:.1f} algorithmic TFLOP/s overall\n")
+            f.write(f"{'M':>8s} {'N':>6s} {'K':>6s} {'calls/frame':>12s} {'ms/frame':>9s} {'avg_us':>9s} {'TFLOP/s':>8s}\n")
+            for r in rows:
+                f.write(f"{r['M']:8d} {r['N']:6d} {r['K']:6d} {r['calls_per_frame']:12.2f} {r['ms_per_frame']:9.3f} {r['avg_us']:9.1f} {r['tflops']:8.1f}\n")
+    top = rows[0]
+    peak = PEAK_TFLOPS[pred.hip.get_precision()]
+    return {"bound": "mfma", "kernel": "bf16x3 GEMM family (k_gemm_split*), largest-time shape", "shape": [top["M"], top["N"], top["K"]],
+            "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": top["tflops"] / peak, "avg_launch_ms": top["avg_us"] * 1e-3,
+            "calls_per_frame": top["calls_per_frame"], "family_ms_per_frame": total, "family_tflops": flops / (total * 1e-3) / 1e12,
+            "family_frac": flops / (total * 1e-3) / 1e12 / peak,
+            "note": "HIP-event bracket per GEMM (incl. its operand-split pre-pass when the producer did not emit planes), "
+                    f"{GEMM_PROBE} frames after the timed region; algorithmic FLOPs 2*M*N*K"}
+
+
+def stream_fps(pred, B, n_frames):
+    """Stream-level rate of VideoProcessor.run: Det-SAM2 defaults 30/30/60/60, B objects, HOST uint8 frames
+    (H2D copy + ds2_ingest_frames + detections->prompts + second-visit tracking + eviction + packed masks to host all
+    inside).  Every stream frame is tracked twice, so stream fps ~ tracked fps / 2."""
+    from det_sam2_amd.det_sam2_RT import VideoProcessor
+    from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
+    frames = [synthetic_frame(t, 777) for t in range(n_frames)]
+    vp = VideoProcessor(model_cfg=pred.cfg.name, detector=SyntheticDetector(B), skip_classes=set(), predictor=pred)
+    t0_tracked = pred.stats["tracked_frames"]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    segs = vp.run(frames=frames)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert sorted(segs) == list(range(n_frames)) and all(len(s) == B for s in segs.values())
+    tracked = pred.stats["tracked_frames"] - t0_tracked
+    return {"stream_fps": n_frames / dt, "frames": n_frames, "seconds": dt, "tracked_frames": tracked,
+            "tracked_fps": tracked / dt, "schedule": "frame_buffer 30 / detect 30 / track 60 / keep 60 (Det-SAM2 defaults)",
+            "input": "host uint8 RGB 1024x1024 frames; H2D + ingest + prompts + eviction + D2H of packed masks included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-stream", action="store_true", help="skip the VideoProcessor.run stream-level measurement (stream_fps)")
+    ap.add_argument("--stream-frames", type=int, default=150)
+    ap.add_argument("--gemm-table", default=None, help="write the per-shape GEMM table (HIP events) to this file")
     ap.add_argument("--model", default="sam2.1_hiera_l")
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,7 +189,7 @@ def main():
     B, K, W = a.objects, a.steps, a.warmup
     pred = SAM2VideoPredictor(cfg, synthetic_state_dict(cfg, 0), dev, max_batch=B)
     pred.hip.set_precision(a.precision)
-    n_frames = 1 + PREFILL + W + K
+    n_frames = 1 + PREFILL + W + K + GEMM_PROBE
     seed = 1000 * rank   # every rank (= its own pass shard) sees different frames
     frames = torch.from_numpy(np.stack([synthetic_frame(t, seed) for t in range(n_frames)])).to(dev)
     st = pred.init_state(frames)
@@ -171,6 +238,11 @@ def main():
     for tag in ("stage.image_encoder", "stage.memory_attention", "stage.sam_heads", "stage.memory_encoder", "kernel.self_attention"):
         ms, n = pred.hip.profile_read(tag)
         stage_ms[tag] = round(ms / max(K, 1), 3)
+    gemm = gemm_probe(pred, gen, st, PREFILL + W + K, a.gemm_table) if rank == 0 else None
+    del gen, st
+    stream = None
+    if rank == 0 and world == 1 and not a.no_stream:
+        stream = stream_fps(pred, B, a.stream_frames)
     if rank == 0:
         achieved = cross_attention_flops(B, nk) / (ca_ms / max(ca_n, 1) * 1e-3) / 1e12 if ca_n else None
         out = {
@@ -181,7 +253,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cfg.name} propagate_in_video, {B} objects, 1024x1024 uniform-noise frames, "
                                    f"7-frame memory bank + 16 object pointers (Nk={nk}), synthetic checkpoint seed 0, "
-                                   f"encoder run on every tracked frame, packed masks copied to host",
+                                   f"encoder run on every tracked frame, packed masks copied to host; frames are PRE-RESIDENT "
+                                   f"in HBM as fp16 (H2D of 3 MiB/frame + ds2_ingest_frames are outside the timed region; the "
+                                   f"stream_fps leg below starts from host uint8 frames)",
                        "objects": B, "Nk": nk, "frames_per_rank": K, "encode_batch": pred.encode_batch,
                        "parallelism": f"pass-sharded dp{world}"},
             "roofline": {"bound": "mfma",
@@ -195,6 +269,11 @@ def main():
                                  "bf16x3 executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3 by construction"},
             "ms_per_step_by_stage": stage_ms,
         }
+        if gemm is not None:
+            out["roofline_gemm"] = gemm
+        if stream is not None:
+            out["stream_fps"] = stream["stream_fps"]
+            out["stream"] = stream
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.model)
         print(json.dumps(out))

@@ -46,11 +46,14 @@ int launch_select_masks(const float* masks4, const float* iou4, const float* obj
                         float* iou_out, int B, hipStream_t st);
 int launch_ptr_gate(float* ptr, const float* obj_logits, const float* no_obj_ptr, int B, int C, hipStream_t st);
 
-// memory bank
+// memory bank.  The entry tables travel by value in the kernel arguments, at most DS2_MAX_*_ENTRIES per launch; larger
+// banks (the reference has no limit: 20 selected cond frames + EVERY preload cond frame + 6, sam2_utils.py:56-60) are
+// assembled by several launches, each writing its own slice of the [B, Nk, 64] outputs (e0 / p0 offsets).
 #define DS2_MAX_MEM_ENTRIES 40
 #define DS2_MAX_PTR_ENTRIES 40
 struct BankArgs {
-  int B, n_mem, n_ptr, tokens;             // tokens = 4096
+  int B, n_mem, n_ptr, tokens;             // entries in THIS launch; tokens = 4096
+  int Nk, n_mem_total, e0, p0;             // whole bank: Nk = n_mem_total*tokens + 4*n_ptr_total; first entry / pointer of this launch
   const uint16_t* feats[DS2_MAX_MEM_ENTRIES];  // bf16 [B, tokens, 64]
   int tpos_row[DS2_MAX_MEM_ENTRIES];           // row of maskmem_tpos_enc to add
   const float* ptrs[DS2_MAX_PTR_ENTRIES];      // fp32 [B, 256]

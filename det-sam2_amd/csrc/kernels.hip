@@ -662,13 +662,13 @@ __global__ void k_bank_mem(BankArgs a) {
   size_t r = i / 16;
   const int t = (int)(r % a.tokens); r /= a.tokens;
   const int e = (int)(r % a.n_mem), b = (int)(r / a.n_mem);
-  const int Nk = a.n_mem * a.tokens + 4 * a.n_ptr;
+  const int Nk = a.Nk;
   const uint16_t* src = a.feats[e] + ((size_t)b * a.tokens + t) * 64 + c4 * 4;
   const ushort4 h = *reinterpret_cast<const ushort4*>(src);
   const float4 m = make_float4(bf16_bits_to_f32(h.x), bf16_bits_to_f32(h.y), bf16_bits_to_f32(h.z), bf16_bits_to_f32(h.w));
   const float4 pe = *reinterpret_cast<const float4*>(a.maskmem_pos + (size_t)t * 64 + c4 * 4);
   const float4 tp = *reinterpret_cast<const float4*>(a.tpos_enc + (size_t)a.tpos_row[e] * 64 + c4 * 4);
-  const size_t o = ((size_t)b * Nk + (size_t)e * a.tokens + t) * 64 + c4 * 4;
+  const size_t o = ((size_t)b * Nk + (size_t)(a.e0 + e) * a.tokens + t) * 64 + c4 * 4;
   *reinterpret_cast<float4*>(a.mem + o) = m;
   *reinterpret_cast<float4*>(a.mem_pos + o) = make_float4(pe.x + tp.x, pe.y + tp.y, pe.z + tp.z, pe.w + tp.w);
 }
@@ -688,11 +688,11 @@ __global__ __launch_bounds__(64) void k_bank_ptr(BankArgs a, const float* dim_t)
   float tp = 0.f;
   for (int k = 0; k < 256; ++k) tp += pe[k] * a.tpos_w[c * 256 + k];
   tp += a.tpos_b[c];
-  const int Nk = a.n_mem * a.tokens + 4 * a.n_ptr;
+  const int Nk = a.Nk;
   for (int b = 0; b < a.B; ++b)
     for (int j = 0; j < 4; ++j) {
       const float m = a.ptrs[e][(size_t)b * 256 + j * 64 + c];
-      const size_t o = ((size_t)b * Nk + (size_t)a.n_mem * a.tokens + e * 4 + j) * 64 + c;
+      const size_t o = ((size_t)b * Nk + (size_t)a.n_mem_total * a.tokens + (a.p0 + e) * 4 + j) * 64 + c;
       a.mem[o] = m;
       a.mem_pos[o] = tp;
     }

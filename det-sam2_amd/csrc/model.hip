@@ -38,10 +38,12 @@ extern "C" int ds2_get_precision(void) { return g_ds2_precision; }
 namespace {
 struct ProfRec { hipEvent_t a, b; };
 bool g_prof = false;
+bool g_prof_gemm = false;   // ds2_profile_enable(2): additionally one bracket per GEMM, tagged by shape
 std::unordered_map<std::string, std::vector<ProfRec>> g_recs;
 struct ProfScope {
-  hipStream_t st; const char* tag; ProfRec r; bool on;
-  ProfScope(const char* t, hipStream_t s) : st(s), tag(t), on(g_prof) {
+  hipStream_t st; std::string tag; ProfRec r; bool on;
+  ProfScope(const char* t, hipStream_t s, bool enable = true) : st(s), on(g_prof && enable) {
+    if (on) tag = t;
     if (!on) return;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
     (void)hipEventRecord(r.a, st);
@@ -53,7 +55,17 @@ struct ProfScope {
   }
 };
 }  // namespace
-extern "C" int ds2_profile_enable(int32_t on) { g_prof = on != 0; return DS2_OK; }
+extern "C" int ds2_profile_enable(int32_t on) { g_prof = on != 0; g_prof_gemm = on == 2; return DS2_OK; }
+// newline-separated list of the tags that currently hold records (for per-shape GEMM tables: tags "gemm M N K ...")
+extern "C" int ds2_profile_tags(char* buf, int64_t cap) {
+  DS2_REQUIRE(buf && cap > 0, "ds2_profile_tags: bad argument");
+  std::string all;
+  for (auto& kv : g_recs)
+    if (!kv.second.empty()) { all += kv.first; all += '\n'; }
+  DS2_REQUIRE((int64_t)all.size() < cap, "ds2_profile_tags: buffer too small (%zu bytes needed)", all.size() + 1);
+  memcpy(buf, all.c_str(), all.size() + 1);
+  return DS2_OK;
+}
 extern "C" int ds2_profile_read(const char* tag, double* total_ms, int64_t* launches) {
   DS2_REQUIRE(tag && total_ms && launches, "ds2_profile_read: null argument");
   *total_ms = 0.0; *launches = 0;
@@ -231,6 +243,10 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     return launch_gemm(g, st);
   }
   DS2_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "gemm: K/lda/ldw must be multiples of 4");
+  // per-shape timing (ds2_profile_enable(2)): HIP events around the whole GEMM incl. any operand split pre-pass
+  char ptag[96] = "";
+  if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "gemm %d %d %d", M, N, K);
+  ProfScope _gp(ptag, st, g_prof_gemm);
   static const bool dbg_shapes = getenv("DS2_DEBUG_GEMM") != nullptr;
   if (dbg_shapes) fprintf(stderr, "GEMM %d %d %d planesA=%d planes_out=%d act=%d R=%d\n", M, N, K,
                           (int)(m && m->act_planes.count(A)), (int)planes_out, act, (int)(R != nullptr));
@@ -640,26 +656,36 @@ extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const v
                                  int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
                                  float* memory_pos, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && memory && memory_pos, "ds2_bank_assemble: bad argument");
-  DS2_REQUIRE(n_mem >= 0 && n_mem <= DS2_MAX_MEM_ENTRIES && n_ptr >= 0 && n_ptr <= DS2_MAX_PTR_ENTRIES,
-              "ds2_bank_assemble: at most %d memory frames and %d pointers (got %d, %d)", DS2_MAX_MEM_ENTRIES,
-              DS2_MAX_PTR_ENTRIES, n_mem, n_ptr);
+  DS2_REQUIRE(n_mem >= 0 && n_ptr >= 0 && (n_mem == 0 || (feats && tpos_row)) && (n_ptr == 0 || (ptrs && ptr_pos)),
+              "ds2_bank_assemble: bad entry tables (n_mem=%d, n_ptr=%d)", n_mem, n_ptr);
   hipStream_t st = (hipStream_t)stream;
-  BankArgs a{};
-  a.B = B; a.n_mem = n_mem; a.n_ptr = n_ptr; a.tokens = TOK;
   for (int e = 0; e < n_mem; ++e) {
+    DS2_REQUIRE(feats[e], "ds2_bank_assemble: null feature pointer");
     DS2_REQUIRE(tpos_row[e] >= 0 && tpos_row[e] < m->cfg.num_maskmem, "ds2_bank_assemble: bad tpos_row");
-    a.feats[e] = reinterpret_cast<const uint16_t*>(feats[e]);
-    a.tpos_row[e] = tpos_row[e];
   }
-  for (int i = 0; i < n_ptr; ++i) { a.ptrs[i] = ptrs[i]; a.ptr_pos[i] = ptr_pos[i]; }
+  BankArgs a{};
+  a.B = B; a.tokens = TOK;
+  a.Nk = n_mem * TOK + 4 * n_ptr; a.n_mem_total = n_mem;
   a.maskmem_pos = m->P("#maskmem_pos");
   a.tpos_enc = m->P("maskmem_tpos_enc");
   a.tpos_w = m->P("obj_ptr_tpos_proj.weight");
   a.tpos_b = m->P("obj_ptr_tpos_proj.bias");
   a.mem = memory; a.mem_pos = memory_pos;
   CHECK_PARAMS();
-  TRY(launch_bank_assemble(a, st));
-  TRY(launch_bank_ptr(a, m->P("#ptr_dim_t"), st));
+  // the entry tables travel in the kernel arguments, DS2_MAX_*_ENTRIES at a time (no limit on the bank size)
+  for (int e0 = 0; e0 < n_mem; e0 += DS2_MAX_MEM_ENTRIES) {
+    a.e0 = e0; a.n_mem = n_mem - e0 < DS2_MAX_MEM_ENTRIES ? n_mem - e0 : DS2_MAX_MEM_ENTRIES; a.n_ptr = 0;
+    for (int e = 0; e < a.n_mem; ++e) {
+      a.feats[e] = reinterpret_cast<const uint16_t*>(feats[e0 + e]);
+      a.tpos_row[e] = tpos_row[e0 + e];
+    }
+    TRY(launch_bank_assemble(a, st));
+  }
+  for (int p0 = 0; p0 < n_ptr; p0 += DS2_MAX_PTR_ENTRIES) {
+    a.p0 = p0; a.n_ptr = n_ptr - p0 < DS2_MAX_PTR_ENTRIES ? n_ptr - p0 : DS2_MAX_PTR_ENTRIES; a.n_mem = 0;
+    for (int i = 0; i < a.n_ptr; ++i) { a.ptrs[i] = ptrs[p0 + i]; a.ptr_pos[i] = ptr_pos[p0 + i]; }
+    TRY(launch_bank_ptr(a, m->P("#ptr_dim_t"), st));
+  }
   return DS2_OK;
 }
 

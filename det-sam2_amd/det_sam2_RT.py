@@ -11,11 +11,40 @@ from __future__ import annotations
 
 import os
 import pickle
+from collections.abc import Mapping
 
 import numpy as np
 import torch
 
+from . import bank_io
 from .build_sam import build_sam2_video_predictor
+
+
+class PackedMasks(Mapping):
+    """``{obj_id: bool[1,Hv,Wv]}`` of one frame (the reference's ``video_segments[frame]`` value, det_sam2_RT.py:396-399)
+    held as the bit-packed rows that left the GPU (``numpy.packbits`` semantics, 8 px/byte): an object's mask is
+    unpacked when it is read, so a 16-object 1080p frame costs 4 MiB on the host instead of 32 MiB and the stream loop
+    never unpacks masks nobody looks at.  Behaves like the reference's dict for readers (``[]``, ``in``, iteration,
+    ``items()``); ``to_dict()`` gives the plain dict (used for the pickled output, :612-615)."""
+
+    __slots__ = ("packed", "obj_ids", "width", "_pos")
+
+    def __init__(self, packed, obj_ids, width):
+        self.packed, self.obj_ids, self.width = packed, list(obj_ids), int(width)   # packed: uint8 [B,Hv,ceil(Wv/8)]
+        self._pos = {oid: i for i, oid in enumerate(self.obj_ids)}
+
+    def __getitem__(self, oid):
+        row = self.packed[self._pos[oid]]
+        return np.unpackbits(row, axis=-1)[:, : self.width].astype(bool)[None]
+
+    def __iter__(self):
+        return iter(self.obj_ids)
+
+    def __len__(self):
+        return len(self.obj_ids)
+
+    def to_dict(self):
+        return {oid: self[oid] for oid in self.obj_ids}
 
 
 class VideoProcessor:
@@ -127,13 +156,13 @@ class VideoProcessor:
             self._yielded.append(t)
             if t >= self.pre_frames:
                 packed.append((t, list(obj_ids), bits))
-        # one device->host transfer per pass, then unpack to the reference's {obj_id: bool[1,Hv,Wv]} format
-        hv, wv = self.inference_state["video_height"], self.inference_state["video_width"]
+        # one device->host transfer per pass; each frame's masks stay bit-packed behind the reference's
+        # {obj_id: bool[1,Hv,Wv]} mapping interface (PackedMasks)
+        wv = self.inference_state["video_width"]
         if packed:
             host = torch.stack([b for _, _, b in packed]).cpu().numpy()
             for (t, ids, _), pb in zip(packed, host):
-                m = np.unpackbits(pb, axis=-1)[..., :wv].reshape(len(ids), 1, hv, wv).astype(bool)
-                self.video_segments[t] = {oid: m[i] for i, oid in enumerate(ids)}
+                self.video_segments[t] = PackedMasks(pb, ids, wv)
 
     def _release(self, frame_idx):
         """det_sam2_RT.py:404-411."""
@@ -157,29 +186,26 @@ class VideoProcessor:
 
     # ------------------------------------------------------------------ A18 (preload bank)
     def save_inference_state(self, save_path):
-        """det_sam2_RT.py:489-497 (pickle of the whole state; tensors are moved to host first)."""
+        """det_sam2_RT.py:489-497.  The reference pickles the whole state (frames, devices, views); here the bank goes
+        into a versioned tensor file (bank_io.DS2BANK: cond / non-cond entries + object table + the level-2 feature of
+        every conditioning frame; no pickle, no frames)."""
         os.makedirs(os.path.dirname(save_path) or ".", exist_ok=True)
+        st = self.inference_state
 
-        def to_host(x):
-            if isinstance(x, torch.Tensor):
-                return x.cpu()
-            if isinstance(x, dict):
-                return type(x)((k, to_host(v)) for k, v in x.items())
-            if isinstance(x, (list, tuple)):
-                return type(x)(to_host(v) for v in x)
-            if isinstance(x, torch.device):
-                return str(x)
-            return x
+        def fpn2_of(t):
+            if t in st.get("preload_fpn2", {}):
+                return st["preload_fpn2"][t]
+            if t in st["images_idx"] or t in st["cached_features"]:
+                return self.predictor._get_image_feature(st, t)[2]
+            return None
 
-        st = {k: v for k, v in self.inference_state.items() if k not in ("cached_features", "_encode_order")}
-        st["cached_features"] = {}
-        with open(save_path, "wb") as f:
-            pickle.dump(to_host(st), f)
+        bank_io.save_bank(save_path, st, self.predictor.cfg.name, fpn2_of)
 
     def load_inference_state(self, load_path):
-        """det_sam2_RT.py:499-503."""
-        with open(load_path, "rb") as f:
-            return pickle.load(f)
+        """det_sam2_RT.py:499-503: DS2BANK files, and inference-state pickles written by the reference (read through a
+        restricted unpickler and converted to the token-major layout).  Returns a host-resident state;
+        ``init_preloading_state`` moves it to the GPU."""
+        return bank_io.load_bank(load_path)
 
     def run(self, video_path=None, frame_dir=None, output_video_segments_pkl_path=None,
             output_special_classes_detection_pkl_path=None, frames=None):
@@ -202,9 +228,9 @@ class VideoProcessor:
             self.Detect_and_SAM2_inference(frame_idx=self.pre_frames + idx - 1)
             self.frame_buffer.clear()
         self.video_segments = {t - self.pre_frames: s for t, s in self.video_segments.items() if t >= self.pre_frames}
-        if output_video_segments_pkl_path:
+        if output_video_segments_pkl_path:    # plain {frame: {obj_id: bool[1,Hv,Wv]}} as the reference writes it (:612-615)
             with open(output_video_segments_pkl_path, "wb") as f:
-                pickle.dump(self.video_segments, f)
+                pickle.dump({t: (s.to_dict() if isinstance(s, PackedMasks) else s) for t, s in self.video_segments.items()}, f)
         if output_special_classes_detection_pkl_path and self.special_classes_detection is not None:
             with open(output_special_classes_detection_pkl_path, "wb") as f:
                 pickle.dump(self.special_classes_detection, f)

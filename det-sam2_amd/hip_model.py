@@ -50,14 +50,20 @@ class HipOps:
         return ["fp32", "bf16x3"][self.lib.ds2_get_precision()]
 
     # ------------------------------------------------------------------ measurement
-    def profile_enable(self, on=True):
-        _capi.check(self.lib.ds2_profile_enable(int(on)), "ds2_profile_enable")
+    def profile_enable(self, on=True, gemm_shapes=False):
+        """HIP-event brackets around the stages / dominant kernels; gemm_shapes: also one bracket per GEMM ("gemm M N K")."""
+        _capi.check(self.lib.ds2_profile_enable(2 if (on and gemm_shapes) else int(bool(on))), "ds2_profile_enable")
 
     def profile_read(self, tag):
         """-> (total_ms, launches) of the HIP-event brackets recorded under ``tag`` since the last read."""
         ms, n = C.c_double(0), C.c_int64(0)
         _capi.check(self.lib.ds2_profile_read(tag.encode(), C.byref(ms), C.byref(n)), "ds2_profile_read")
         return ms.value, n.value
+
+    def profile_tags(self):
+        buf = C.create_string_buffer(1 << 16)
+        _capi.check(self.lib.ds2_profile_tags(buf, len(buf)), "ds2_profile_tags")
+        return [t for t in buf.value.decode().split("\n") if t]
 
     # ------------------------------------------------------------------ primitives (tests)
     def op_gemm(self, A, W, bias=None, act=0, gamma=None, R=None, r_mod=0):

@@ -103,26 +103,48 @@ class SAM2VideoPredictor:
         st = inference_state
         new, vh, vw = self._load_frames(video_path)
         assert vh == st["video_height"] and vw == st["video_width"], "new frames must match the video size"
-        last = st["images_idx"][-1]
+        # a preloaded DS2BANK state holds no frames: numbering continues after the bank (num_frames), as it does in the
+        # reference where the bank's frames are still in `images`
+        last = st["images_idx"][-1] if st["images_idx"] else st["num_frames"] - 1
         st["images_idx"].extend(range(last + 1, last + 1 + len(new)))
-        st["images"] = torch.cat((st["images"], new), dim=0)
+        st["images"] = torch.cat((st["images"], new), dim=0) if len(st["images"]) else new
         st["num_frames"] += len(new)
         return st
 
     def init_preloading_state(self, inference_state, offload_video_to_cpu=True, offload_state_to_cpu=True):
-        """init_preloading_state (sam2_video_predictor.py:123-156): in the reference this moves the preload
-        bank to the storage device; here the bank is already resident - just make sure it is on this GPU."""
+        """init_preloading_state (sam2_video_predictor.py:123-156): in the reference this moves the preload bank to the
+        storage device; here the bank (loaded by bank_io.load_bank: DS2BANK file or a reference pickle, both already
+        converted to the token-major layout) is moved into HBM and the per-object views are rebuilt."""
         st = inference_state
         st["storage_device"] = st["device"] = self.device
         st["images"] = st["images"].to(self.device)
+        B = len(st["obj_ids"])
         for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
-            for out in st["output_dict"][key].values():
+            for t, out in st["output_dict"][key].items():
+                f = out.get("maskmem_features")
+                if f is not None and f.dim() == 4:       # a reference-layout state handed over directly (not via load_bank)
+                    f = f.flatten(2).transpose(1, 2).contiguous().to(torch.bfloat16)
+                if f is not None and tuple(f.shape[1:]) != (4096, 64):
+                    raise ValueError(f"preload bank entry of frame {t}: maskmem_features has shape {tuple(f.shape)}, expected "
+                                     "token-major [B,4096,64] or the reference's [B,64,64,64]")
+                out["maskmem_features"] = f
+                out["maskmem_pos_enc"] = None
                 for k in ("maskmem_features", "pred_masks", "obj_ptr", "object_score_logits"):
                     if out.get(k) is not None:
-                        out[k] = out[k].to(self.device)
-        for t, out in st["output_dict"]["cond_frame_outputs"].items():
-            self._add_output_per_object(st, t, out, "cond_frame_outputs")
+                        out[k] = out[k].to(self.device).contiguous()
+        st["output_dict_per_obj"] = {i: {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}} for i in range(B)}
+        for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+            for t, out in st["output_dict"][key].items():
+                self._add_output_per_object(st, t, out, key)
+        # level-2 features of the bank's conditioning frames (DS2BANK carries them instead of frames): pinned in the
+        # feature cache for the online new-object re-consolidation (A17), which only runs the memory encoder on them
         st["cached_features"] = {}
+        st["_pinned_features"] = set()
+        for t, f2 in (st.get("preload_fpn2") or {}).items():
+            f2 = f2.to(self.device).contiguous()
+            st["preload_fpn2"][t] = f2
+            st["cached_features"][t] = (None, None, f2)
+            st["_pinned_features"].add(t)
 
     # ------------------------------------------------------------------ features (A4/A5)
     def _get_image_feature(self, st, frame_idx):
@@ -147,10 +169,26 @@ class SAM2VideoPredictor:
                 feats = self.hip.image_encoder_batch(st["images"].index_select(0, pos))
             for t, ft in zip(todo, feats):
                 cache[t] = ft
+            self._trim_feature_cache(st, keep=set(todo))
             self.stats["encoder_runs"] += len(todo)
             self.stats["encoder_launches"] += 1
             f = cache[frame_idx]
         return f
+
+    def _trim_feature_cache(self, st, keep=()):
+        """The cache holds 16 MiB per frame; whatever the release policy is (max_inference_state_frames = -1 never
+        releases), keep at most the frames of the current propagation window + one encode batch, evicting the oldest
+        insertions first.  Pinned entries (preload-bank features without frames) are never evicted."""
+        cache = st["cached_features"]
+        cap = max(len(st.get("_encode_order") or ()), 1) + self.encode_batch + 1
+        pinned = st.get("_pinned_features") or ()
+        if len(cache) - len(pinned) <= cap:
+            return
+        for t in list(cache):
+            if len(cache) - len(pinned) <= cap:
+                break
+            if t not in pinned and t not in keep:
+                cache.pop(t)
 
     # ------------------------------------------------------------------ object table (A17)
     def _new_slot(self, st, obj_id):

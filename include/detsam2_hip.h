@@ -156,6 +156,9 @@ int ds2_get_precision(void);
  * summed duration and launch count since the last read, and clears them. */
 int ds2_profile_enable(int32_t on);
 int ds2_profile_read(const char* tag, double* total_ms, int64_t* launches);
+/* Newline-separated list of the tags that hold records (HOST buffer).  ds2_profile_enable(2) additionally brackets
+ * every GEMM under the tag "gemm M N K" (the per-shape table behind bench.py's roofline_gemm). */
+int ds2_profile_tags(char* buf, int64_t cap);
 
 /* ---- primitive ops (exported for unit tests and for integrators who want a single op) */
 int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,

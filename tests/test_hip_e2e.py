@@ -100,6 +100,35 @@ def test_preload_bank_matches_reference(golden_dir, prec, tmp_path):
     assert worst_iou <= 1e-3 and worst_logit <= (5e-3 if prec == "fp32" else 5e-2), (worst_iou, worst_logit)
 
 
+def test_preload_bank_written_by_the_reference_layout(golden_dir, tmp_path):
+    """A bank in the REFERENCE's on-disk form - pickle of the whole state with channel-major maskmem_features
+    [B,64,64,64], maskmem_pos_enc lists and the frames (det_sam2_RT.py:489-497), produced here by the oracle's
+    VideoProcessor - is loaded through load_inference_state_path, converted, and tracks the 4 new frames to the masks of
+    the reference's own preload run (golden e2e_preload)."""
+    import torch
+    from oracle.make_goldens import PRELOAD_A, PRELOAD_B
+    from oracle.video_processor import OracleVideoProcessor
+    g = np.load(os.path.join(golden_dir, "e2e_preload.npz"))
+    cfg = resolve_config(TINY)
+    bank = str(tmp_path / "reference_layout_bank.pkl")
+    a = OracleVideoProcessor(synthetic_state_dict(cfg, 0), cfg, SyntheticDetector(2), **PRELOAD_A)
+    with torch.inference_mode():
+        for t in range(3):
+            a.process_frame(t, synthetic_frame(t))
+    a.save_inference_state(bank)
+    b = _vp(SyntheticDetector(2), "bf16x3", load_inference_state_path=bank, **{k: v for k, v in PRELOAD_B.items() if k != "skip_classes"})
+    segs = b.run(frames=[synthetic_frame(100 + i) for i in range(4)])
+    assert b.pre_frames == 3 and sorted(segs) == [0, 1, 2, 3]
+    assert b.pass_log[0][1] == list(g["frames"])
+    worst = 0.0
+    for i, t in enumerate(g["frames"]):
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            worst = max(worst, 1.0 - _iou(segs[int(t) - 3][o], ref[o]))
+    record("e2e_preload_reference_layout", one_minus_iou=worst)
+    assert worst <= 1e-3, worst
+
+
 def test_stream2_matches_reference(golden_dir, prec):
     """Two passes, release_old_frames with image release, online new object (A17)."""
     g = np.load(os.path.join(golden_dir, "e2e_stream2.npz"))

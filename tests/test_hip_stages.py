@@ -115,6 +115,28 @@ def test_memory_attention_and_bank(prec):
     assert e_mem == 0.0 and e_pos < 1e-5 and e < TOL[prec], (e_mem, e_pos, e)
 
 
+def test_bank_assemble_beyond_40_entries():
+    """The reference puts 20 selected + EVERY preload conditioning frame + 6 into the bank (sam2_utils.py:56-60): no
+    limit.  45 memory frames and 47 pointers (more than one kernel-argument table holds) against the bank formulas."""
+    cfg, sd, hm = model("sam2.1_hiera_t", "bf16x3")
+    g = torch.Generator().manual_seed(3)
+    B, NF, NP = 2, 45, 47
+    d = hm.device
+    feats = [torch.randn(B, 4096, 64, generator=g).to(torch.bfloat16) for _ in range(NF)]
+    ptrs = [torch.randn(B, 256, generator=g) for _ in range(NP)]
+    rows = [i % 7 for i in range(NF)]
+    ptr_pos = [float(i - 20) for i in range(NP)]
+    pos2 = M.sine_pos_2d(64, 64, 64).flatten(1).T                                  # [4096, 64]
+    memory = torch.cat([f.float() for f in feats] + [torch.stack(ptrs, 1).reshape(B, NP * 4, 64)], 1)
+    mpos = torch.cat([(pos2 + sd["maskmem_tpos_enc"][r].reshape(1, 64))[None].expand(B, -1, -1) for r in rows], 1)
+    op = M.linear(sd, "obj_ptr_tpos_proj", M.sine_pe_1d(torch.tensor(ptr_pos) / 15.0, 256))    # [NP, 64]
+    mpos = torch.cat([mpos, op.repeat_interleave(4, dim=0)[None].expand(B, -1, -1)], 1)
+    mem_d, pos_d = hm.bank_assemble(B, [(f.to(d), r) for f, r in zip(feats, rows)], [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)])
+    torch.cuda.synchronize()
+    assert mem_d.shape == (B, NF * 4096 + 4 * NP, 64)
+    assert rel_err(mem_d, memory) == 0.0 and rel_err(pos_d, mpos) < 1e-5
+
+
 def test_memory_attention_at_bench_size():
     """The measured configuration's dominant stage at FULL size: 16 objects, 7-frame bank + 16 object pointers
     (Nk = 28736), bf16x3 arithmetic, against the oracle (about 40 s of host time on the GPU box)."""
