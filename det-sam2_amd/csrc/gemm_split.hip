@@ -330,6 +330,10 @@ int heuristic_tile(const GemmSplitArgs& g) {
   int tile = 1;
   if (cr3 < c128 && cr3 <= c256) tile = 3;
   if (c256 < c128 && c256 < cr3) tile = 4;
+  // the LDS-DMA 256x256 kernel replaces the register-staged one (DS2_GEMM_D256=0 keeps the old kernel for A/B runs);
+  // its 32-bit DMA offsets need the operand planes to stay below 4 GiB
+  static const bool d256 = [] { const char* e = getenv("DS2_GEMM_D256"); return !(e && atoi(e) == 0); }();
+  if (tile == 4 && d256 && (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) tile = 5;
   return tile;
 }
 
@@ -337,10 +341,11 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   GemmSplitArgs g = g_in;
   {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
     static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
-    const int bn = (tile == 4) ? 256 : 128;
+    const int bn = (tile == 4 || tile == 5) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
     g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
   }
+  if (tile == 5) return launch_gemm_split_d256(g, st);
   if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
   if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
