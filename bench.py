@@ -207,6 +207,9 @@ def main():
     # the K timed frames is encoded inside the timed region (exactly K encoder runs are asserted below)
     for t in [t for t in st["cached_features"] if t > PREFILL + W]:
         st["cached_features"].pop(t)
+    # ... and keep the batched encoder from running ahead into the GEMM-probe frames that follow the timed ones
+    full_order = st["_encode_order"]
+    st["_encode_order"] = [t for t in full_order if t <= PREFILL + W + K]
     enc0 = pred.stats["encoder_runs"]
     nk = 4096 * 7 + 4 * 16
     assert pred.trace is None
@@ -238,6 +241,7 @@ def main():
     for tag in ("stage.image_encoder", "stage.memory_attention", "stage.sam_heads", "stage.memory_encoder", "kernel.self_attention"):
         ms, n = pred.hip.profile_read(tag)
         stage_ms[tag] = round(ms / max(K, 1), 3)
+    st["_encode_order"] = full_order
     gemm = gemm_probe(pred, gen, st, PREFILL + W + K, a.gemm_table) if rank == 0 else None
     del gen, st
     stream = None

@@ -119,8 +119,36 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                           \
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.X[tm], F.Y[tn], acc[tm][tn], 0, 0, 0);
 
+  // L2 prefetch of the A operand (activations: first touch comes from HBM / Infinity Cache, ~3 us under load, while only
+  // ONE 64 KiB tile of LDS-DMA can be in flight): every step each wave "touches" one dword of the 64 cache lines that
+  // hold its 32 rows x 2 planes of K tile kt + g.prefetch, so that by the time the DMA of that tile is issued it hits
+  // in L2.  The loads are inline asm (invisible to hipcc's waitcnt bookkeeping); the step's wait is vmcnt(1): the
+  // eight DMA pieces of tile kt+1 are older than the newest touch and have landed, the touch itself may still fly.
+  const int pf = g.prefetch;
+  const char* tbase = (lane >> 5 ? bAl : bAh);
+  unsigned toff;
+  {
+    int mr = m0 + wave * 32 + (lane & 31);
+    mr = mr < g.M ? mr : g.M - 1;
+    toff = (unsigned)mr * (unsigned)g.lda * 2u;
+  }
+  unsigned junk = 0;
+#define D2_TOUCH(kt)                                                                           \
+  if (pf > 0) {                                                                                \
+    const int kk_ = (kt) + pf < last ? (kt) + pf : last;                                       \
+    const char* p_ = tbase + (toff + (unsigned)kk_ * (BK * 2));                                \
+    asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(p_) : "memory");           \
+  }
+
   FragsD F0, F1;
   int s0 = 0, s1 = STAGE;       // stage offsets of tiles t, t+1
+  if (pf > 0) {   // prime the L2 for the first tiles (one line holds two K tiles of a row)
+    for (int t = 2; t < 2 + pf && t <= last; t += 2) {
+      const char* p_ = tbase + (toff + (unsigned)t * (BK * 2));
+      asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(p_) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keeps the vmcnt arithmetic below simple; ~one HBM latency per block
+  }
   D2_FILL(0, s0)
   D2_FILL(1, s1)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (this wave's pieces) ...
@@ -140,10 +168,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     __builtin_amdgcn_sched_barrier(0);
     // F1 landed => this wave no longer reads stage s0; its own pieces of tile kt+1 landed.  After the barrier: stage s0
     // is free for tile kt+2 and tile kt+1 is visible to everyone.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (pf > 0) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     D2_FILL(kt + 2, s0)
+    D2_TOUCH(kt + 2)
     __builtin_amdgcn_sched_barrier(0);
     D2_MFMA_TERM(F1, al, bh)
     __builtin_amdgcn_sched_barrier(0);
@@ -153,6 +183,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     D2_MFMA_TERM(F1, ah, bh)
     const int t_ = s0; s0 = s1; s1 = t_;
   }
+  asm volatile("" ::"v"(junk));
 
   // ---- epilogue: each wave parks one 32 x 64 slab of its tile in LDS at a time and re-reads it row-wise (4 consecutive
   // columns per lane: 16-byte bias/residual loads and fp32 stores, 8-byte plane stores); same arithmetic as

@@ -93,6 +93,8 @@ struct GemmSplitArgs {
   // walked column-major (the ~32 blocks an XCD runs at once then share A rows AND W rows through its L2).  Set by
   // launch_gemm_split.
   int group_m;
+  // k_gemm_split_d256: L2 prefetch distance of the A operand in K tiles (0 = off).  Set by launch_gemm_split.
+  int prefetch;
 };
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 256x128 blocks, 8 waves, 3-stage LDS-DMA ring

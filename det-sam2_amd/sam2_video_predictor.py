@@ -30,13 +30,15 @@ NO_OBJ_SCORE = -1024.0  # sam2_base.py:21
 
 
 class SAM2VideoPredictor:
-    def __init__(self, cfg, state_dict, device="cuda:0", max_batch=16, fill_hole_area=0):
+    def __init__(self, cfg, state_dict, device="cuda:0", max_batch=16, fill_hole_area=0, hip=None):
+        """``hip``: an object with HipSam2's stage interface (tests of the host logic inject a CPU stand-in; the product
+        path always builds HipSam2, which raises without the HIP library or a GPU)."""
         self.cfg = resolve_config(cfg)
         # sam2_video_predictor.py:26,37: class default 0; build_sam2_video_predictor passes 8 (build_sam.py:134).
         # The reference applies it only when its CUDA extension is present (misc.py:389-391: the CPU reference, and
         # therefore the committed goldens, skip it) - here it is always applied when > 0 (HIP kernel, A14).
         self.fill_hole_area = int(fill_hole_area)
-        self.hip = HipSam2(self.cfg, state_dict, device, max_batch)
+        self.hip = hip if hip is not None else HipSam2(self.cfg, state_dict, device, max_batch)
         self.device = self.hip.device
         self.image_size = self.cfg.image_size
         self.hidden_dim, self.mem_dim, self.num_maskmem = self.cfg.d_model, self.cfg.mem_dim, self.cfg.num_maskmem
@@ -65,9 +67,11 @@ class SAM2VideoPredictor:
         return images, h, w
 
     @torch.inference_mode()
-    def init_state(self, video_path, offload_video_to_cpu=True, offload_state_to_cpu=False, async_loading_frames=False):
+    def init_state(self, video_path, offload_video_to_cpu=True, offload_state_to_cpu=False, async_loading_frames=False,
+                   warm_up_first_frame=True):
         """init_state (sam2_video_predictor.py:44-120).  The offload flags are accepted for signature
-        compatibility; state always lives in HBM here."""
+        compatibility; state always lives in HBM here.  ``warm_up_first_frame=False`` skips the reference's encoder
+        warm-up on frame 0 (:118; ranks of a sharded stream that do not own the first pass never need that feature)."""
         images, vh, vw = self._load_frames(video_path)
         st = {}
         st["images"] = images
@@ -94,7 +98,8 @@ class SAM2VideoPredictor:
         st["preloading_memory_cond_frame_idx"] = None
         st["preloading_memory_non_cond_frames_idx"] = None
         st["max_update_length_for_new_obj_id"] = 100
-        self._get_image_feature(st, 0)
+        if warm_up_first_frame:
+            self._get_image_feature(st, 0)
         return st
 
     @torch.inference_mode()
@@ -175,12 +180,38 @@ class SAM2VideoPredictor:
             f = cache[frame_idx]
         return f
 
+    def encode_frames(self, st, frame_indices):
+        """Encode the given retained frames now (batches of encode_batch) and return their pyramids in order; frames that
+        are already cached are not encoded again.  Used by the pass-sharded driver, which encodes a buffer up front."""
+        cache = st["cached_features"]
+        todo = [t for t in frame_indices if t not in cache]
+        for i in range(0, len(todo), max(self.encode_batch, 1)):
+            chunk = todo[i:i + max(self.encode_batch, 1)]
+            if len(chunk) == 1:
+                feats = [self.hip.image_encoder(st["images"][st["images_idx"].index(chunk[0])])]
+            else:
+                pos = torch.tensor([st["images_idx"].index(t) for t in chunk], device=st["images"].device)
+                feats = self.hip.image_encoder_batch(st["images"].index_select(0, pos))
+            for t, ft in zip(chunk, feats):
+                cache[t] = ft
+            self.stats["encoder_runs"] += len(chunk)
+            self.stats["encoder_launches"] += 1
+        return [cache[t] for t in frame_indices]
+
+    def feature_shapes(self):
+        """Per-frame pyramid (fpn0, fpn1, fpn2), token-major fp32."""
+        return [(65536, 32), (16384, 64), (4096, 256)]
+
+    def entry_dims(self):
+        """Shapes of a bank entry / level-2 feature (what a peer rank allocates before receiving one)."""
+        return dict(tokens=4096, mem_dim=self.mem_dim, ptr_dim=self.hidden_dim, mask_side=256, feat_dim=self.hidden_dim)
+
     def _trim_feature_cache(self, st, keep=()):
         """The cache holds 16 MiB per frame; whatever the release policy is (max_inference_state_frames = -1 never
         releases), keep at most the frames of the current propagation window + one encode batch, evicting the oldest
         insertions first.  Pinned entries (preload-bank features without frames) are never evicted."""
         cache = st["cached_features"]
-        cap = max(len(st.get("_encode_order") or ()), 1) + self.encode_batch + 1
+        cap = max(max(len(st.get("_encode_order") or ()), 1) + self.encode_batch + 1, st.get("_feature_cache_cap", 0))
         pinned = st.get("_pinned_features") or ()
         if len(cache) - len(pinned) <= cap:
             return
@@ -505,6 +536,8 @@ class SAM2VideoPredictor:
                 o["cond_frame_outputs"].pop(t, None)
         for t in [t for t in st["cached_features"] if pre_frames - 1 < t <= oldest]:
             st["cached_features"].pop(t, None)
+            if st.get("_pinned_features"):
+                st["_pinned_features"].discard(t)
         if release_images:
             old = [t for t in st["images_idx"] if pre_frames - 1 < t <= oldest]
             rm = {st["images_idx"].index(t) for t in old}

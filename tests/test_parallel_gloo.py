@@ -62,43 +62,69 @@ def test_pack_unpack_roundtrip_single_process():
     assert P.allgather_cond_entries(e)[0] is e
 
 
-def _bworker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, n_frames, appear):
+    """One rank of a 2-process gloo job: the real ShardedVideoProcessor + real predictor state machine over the CPU
+    stand-in for the HIP stages, every collective of the round (all_gather_object, all_gather, batch_isend_irecv ring
+    shift) through torch.distributed."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _fake_hip import fake_predictor
+    from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ok = True
-    for src in range(world):        # every rank is the owner of some pass
-        payload = None
-        if rank == src:
-            payload = {"obj_ids": [3, 7, 9], "entries": {10 * src: _entry(src), 10 * src + 5: _entry(src + 10, B=2)}}
-        got = P.broadcast_cond_entries(payload, src, "cpu")
-        ok &= got["obj_ids"] == [3, 7, 9] and sorted(got["entries"]) == [10 * src, 10 * src + 5]
-        for t, ref in ((10 * src, _entry(src)), (10 * src + 5, _entry(src + 10, B=2))):
-            for k in P.ENTRY_FIELDS:
-                ok &= bool(torch.equal(got["entries"][t][k], ref[k])) and got["entries"][t][k].dtype == ref[k].dtype
-    q.put((rank, ok))
-    dist.destroy_process_group()
+    try:
+        vp = P.ShardedVideoProcessor(model_cfg="sam2.1_hiera_t", detector=SyntheticDetector(3, size=32, appear=appear),
+                                     skip_classes=set(), predictor=fake_predictor(), frame_buffer_size=3, detect_interval=3,
+                                     max_frame_num_to_track=6, max_inference_state_frames=6)
+        assert (vp.rank, vp.world) == (rank, world) and isinstance(vp.comm, P.TorchDistComm)
+        segs = vp.run(frames=[synthetic_frame(t, size=32) for t in range(n_frames)])
+        q.put((rank, {t: s.to_dict() for t, s in segs.items()}, vp.owned_passes, vp.predictor.stats["encoder_runs"],
+               [(r, op) for r, op, _ in vp.comm_log]))
+    finally:
+        dist.destroy_process_group()
 
 
-def test_broadcast_cond_entries_gloo_world2():
-    """The exchange of the pass-sharded stream (owner -> everyone, ragged object counts) under gloo."""
+def test_sharded_stream_through_gloo_world2_equals_sequential():
+    """ADVICE/VERDICT round 1: the sharded driver had only run with an in-process mailbox.  Here two processes run one
+    17-frame stream (6 passes, the last one partial; a new class appears in pass 2) through torch.distributed."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import numpy as np
+    from _fake_hip import fake_predictor
+    from det_sam2_amd.det_sam2_RT import VideoProcessor
+    from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
+    n, appear = 17, {2: 6}
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_bworker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, n, appear)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in ps)
+    res = sorted((q.get(timeout=180) for _ in ps), key=lambda x: x[0])
     for p in ps:
         p.join(timeout=60)
-    assert res == [(0, True), (1, True)]
+    seq = VideoProcessor(model_cfg="sam2.1_hiera_t", detector=SyntheticDetector(3, size=32, appear=appear), skip_classes=set(),
+                         predictor=fake_predictor(), frame_buffer_size=3, detect_interval=3, max_frame_num_to_track=6,
+                         max_inference_state_frames=6)
+    ref = seq.run(frames=[synthetic_frame(t, size=32) for t in range(n)])
+    assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3, 5]
+    merged = P.merge_segments([res[0][1], res[1][1]], 3, 6, 6, 2, n)
+    assert sorted(merged) == sorted(ref) == list(range(n))
+    for t in ref:
+        assert sorted(merged[t]) == sorted(ref[t])
+        for o in ref[t]:
+            assert np.array_equal(merged[t][o], ref[t][o]), (t, o)
+    assert n <= res[0][3] + res[1][3] <= n + 2                      # frames encoded once (hand-off), not once per pass
+    assert ("ring_shift" in {op for _, op in res[0][4]}) and ("all_gather_bytes" in {op for _, op in res[0][4]})
 
 
 def test_merge_segments_rule():
     segs = [{t: {0: ("r0", t)} for t in range(90)}, {t: {0: ("r1", t)} for t in range(90)}]
     m = P.merge_segments(segs, 30, 60, 3, 2)
+    assert P.merge_segments(segs, 30, 60, 3, 2, 90) == m
     assert m[0][0][0] == "r1" and m[29][0][0] == "r1"       # buffer 0: passes 0 (rank 0) and 1 (rank 1) -> pass 1
     assert m[30][0][0] == "r0" and m[59][0][0] == "r0"      # buffer 1: passes 1 and 2 -> pass 2 (rank 0)
     assert m[60][0][0] == "r0" and m[89][0][0] == "r0"      # buffer 2: only pass 2 so far

@@ -34,11 +34,13 @@ def run(names, rounds, env_mode=False):
             for item in filter(None, kv.split(",")):
                 k, _, v = item.partition("=")
                 env[k] = v
-            o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "1", "--no-cpu-baseline"],
+            o = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "1", "--no-cpu-baseline", "--no-stream"],
                                env=env, capture_output=True, text=True)
             try:
                 d = json.loads(o.stdout.strip().splitlines()[-1])
-                print(f"{n:12s} fps {d['value']:.2f} cross {d['roofline']['avg_launch_ms']:.3f} ms  {d['ms_per_step_by_stage']}", flush=True)
+                gm = d.get("roofline_gemm") or {}
+                print(f"{n:12s} fps {d['value']:.2f} cross {d['roofline']['avg_launch_ms']:.3f} ms  gemm {gm.get('family_ms_per_frame', 0):.3f} ms/frame "
+                      f"(top {gm.get('shape')} {gm.get('achieved', 0):.0f} TF)  {d['ms_per_step_by_stage']}", flush=True)
             except Exception:
                 print(n, "FAILED", o.stderr[-400:])
 
