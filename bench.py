@@ -155,6 +155,92 @@ def stream_fps(pred, B, n_frames):
             "input": "host uint8 RGB 1024x1024 frames; H2D + ingest + prompts + eviction + D2H of packed masks included"}
 
 
+def bench_sharded(a, pred, cfg, world, rank, dev):
+    """N > 1 (default): ONE Det-SAM2 stream whose propagate passes are sharded over the ranks (BASELINE config 4,
+    det_sam2_amd.parallel.ShardedVideoProcessor).  The reference's 30/30/60/60 schedule scaled so that one pass tracks
+    exactly K frames: frame_buffer = detect_interval = K/2, max_frame_num_to_track = max_inference_state_frames = K.
+    Untimed: round 0 (passes 0..N-1, bank fill-up) [+ more rounds until W tracked frames per rank have run]; timed: ONE
+    round = every rank ingests the round's N*K/2 host frames, encodes its own buffer, hands the pyramids to its ring
+    neighbour (RCCL send/recv), all-gathers detections and the new conditioning entries (RCCL all-gather), and tracks its
+    pass of K frames; masks packed and copied to the host.  value = N*K tracked frames / max-over-ranks time."""
+    import torch.distributed as dist
+    from det_sam2_amd.parallel import ShardedVideoProcessor
+    from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
+    B, K, W = a.objects, a.steps, a.warmup
+    b = max(K // 2, 1)
+    K = 2 * b
+    warm_rounds = 1 + (max(W - b, 0) + K - 1) // K
+    vp = ShardedVideoProcessor(model_cfg=cfg.name, detector=SyntheticDetector(B), skip_classes=set(), predictor=pred,
+                               frame_buffer_size=b, detect_interval=b, max_frame_num_to_track=K, max_inference_state_frames=K)
+    per_round = world * b
+    frames = [synthetic_frame(t, 4242) for t in range((warm_rounds + 1) * per_round)]       # host uint8, same on every rank
+    t = 0
+    for _ in range(warm_rounds * per_round):
+        vp.process_frame(t, frames[t])
+        t += 1
+    torch.cuda.synchronize()
+    tracked0, enc0 = pred.stats["tracked_frames"], pred.stats["encoder_runs"]
+    pred.trace = []
+    pred.hip.profile_enable(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(per_round):
+        vp.process_frame(t, frames[t])
+        t += 1
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    pred.hip.profile_enable(False)
+    tracked = pred.stats["tracked_frames"] - tracked0
+    cond_yield = K - tracked          # conditioning frames inside the window are yielded without tracking
+    stats = torch.tensor([dt, tracked, pred.stats["encoder_runs"] - enc0], dtype=torch.float64,
+                         device=dev if dist.get_backend() == "nccl" else "cpu")
+    tmax = stats.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = stats.clone()
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    dt = float(tmax[0].item())
+    ca_ms, ca_n = pred.hip.profile_read("kernel.cross_attention")
+    stage_ms = {}
+    for tag in ("stage.image_encoder", "stage.memory_attention", "stage.sam_heads", "stage.memory_encoder", "kernel.self_attention"):
+        ms, n = pred.hip.profile_read(tag)
+        stage_ms[tag] = round(ms / max(K, 1), 3)
+    if rank == 0:
+        nks = [tr["nk"] for tr in pred.trace]
+        flops = sum(cross_attention_flops(B, nk) for nk in nks) * cfg.mem_attn_layers
+        achieved = flops / (ca_ms * 1e-3) / 1e12 if ca_n else None
+        comm = {}
+        for _, op, nbytes in vp.comm_log[-8:]:
+            comm[op] = nbytes
+        total_tracked = float(tsum[1].item())
+        out = {
+            "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
+            "value": total_tracked / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "fp32" else "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg.name}, ONE stream of 1024x1024 frames, {B} objects, propagate passes sharded over {world} GPUs "
+                                   f"(pass k -> rank k mod {world}); Det-SAM2 schedule scaled to buffer/detect {b}, track/keep {K}; one timed round "
+                                   f"= {per_round} new stream frames from HOST uint8 (H2D + ingest on every rank), {K} frames visited per rank of which "
+                                   f"{K - cond_yield} tracked and {cond_yield} conditioning; value counts tracked frames; bank of up to 3 conditioning + 6 "
+                                   f"non-conditioning frames (Nk {min(nks) if nks else 0}..{max(nks) if nks else 0}); synthetic checkpoint seed 0",
+                       "objects": B, "Nk_max": max(nks) if nks else 0, "frames_per_rank": K, "encode_batch": pred.encode_batch,
+                       "parallelism": f"one stream, pass-sharded over {world} ranks; RCCL: all_gather_object(detections), all_gather(cond entries), "
+                                      f"ring send/recv(feature pyramids)",
+                       "comm_bytes_per_round": comm,
+                       "encoder_runs_per_round_all_ranks": float(tsum[2].item()), "new_frames_per_round": per_round},
+            "stream_fps": per_round / dt,
+            "roofline": {"bound": "mfma", "kernel": "memory cross-attention (k_attention_w8), 1 launch/layer, per-frame Nk from the bank trace",
+                         "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
+                         "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision], "traffic": None,
+                         "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
+                         "note": "rank 0; achieved = sum over tracked frames of 4 * 2*B*4096*Nk*(256+64) / summed HIP-event time"},
+            "ms_per_step_by_stage": stage_ms,
+        }
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,16 +253,26 @@ def main():
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: N independent streams, one per GPU (BASELINE config 5) instead of ONE stream sharded by pass (config 4)")
     a = ap.parse_args()
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # DS2_BENCH_BACKEND=gloo + DS2_BENCH_ONE_DEVICE=1: dry run of the multi-rank code path on a single-GPU box (all
+    # ranks on cuda:0, collectives staged through the host) - a functional check, not a measurement
+    backend = os.environ.get("DS2_BENCH_BACKEND", "nccl")
+    if os.environ.get("DS2_BENCH_ONE_DEVICE"):
+        local = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     dev = f"cuda:{local}"
 
     from det_sam2_amd.config import resolve_config
@@ -189,6 +285,10 @@ def main():
     B, K, W = a.objects, a.steps, a.warmup
     pred = SAM2VideoPredictor(cfg, synthetic_state_dict(cfg, 0), dev, max_batch=B)
     pred.hip.set_precision(a.precision)
+    if world > 1 and not a.replicas:
+        bench_sharded(a, pred, cfg, world, rank, dev)
+        dist.destroy_process_group()
+        return
     n_frames = 1 + PREFILL + W + K + GEMM_PROBE
     seed = 1000 * rank   # every rank (= its own pass shard) sees different frames
     frames = torch.from_numpy(np.stack([synthetic_frame(t, seed) for t in range(n_frames)])).to(dev)
@@ -232,7 +332,7 @@ def main():
     assert all(tr["nk"] == nk for tr in pred.trace), [tr["nk"] for tr in pred.trace]
     assert pred.stats["encoder_runs"] - enc0 == K, (pred.stats, enc0, K)   # every timed frame was encoded in the timed region
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -261,7 +361,7 @@ def main():
                                    f"in HBM as fp16 (H2D of 3 MiB/frame + ds2_ingest_frames are outside the timed region; the "
                                    f"stream_fps leg below starts from host uint8 frames)",
                        "objects": B, "Nk": nk, "frames_per_rank": K, "encode_batch": pred.encode_batch,
-                       "parallelism": f"pass-sharded dp{world}"},
+                       "parallelism": "single GPU" if world == 1 else f"{world} independent replica streams (BASELINE config 5) + one RCCL all-gather of a cond entry"},
             "roofline": {"bound": "mfma",
                          "kernel": "memory cross-attention (k_attention_w8 in bf16x3 mode, k_attention<256,64> in fp32 mode), 1 launch/layer",
                          "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",

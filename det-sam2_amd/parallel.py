@@ -114,9 +114,16 @@ def install_cond_entry(predictor, inference_state, frame_idx: int, entry: Dict[s
 #   ("ring_shift", (send tensors, recv tensors))        -> recv tensors filled by rank-1's send tensors (to rank+1)
 # ------------------------------------------------------------------------------------------------------------------
 class TorchDistComm:
+    """torch.distributed back end.  "nccl" (= RCCL on ROCm) moves device tensors directly over xGMI; under "gloo" (CPU
+    tests, and single-GPU dry runs of the multi-rank code path) device tensors are staged through the host."""
+
     def __init__(self, group=None, device=None):
         self.group, self.device = group, device
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.host_staged = dist.get_backend(group) == "gloo"
+
+    def _out(self, t):
+        return t.cpu() if (self.host_staged and t.is_cuda) else t
 
     def execute(self, req):
         op, payload = req
@@ -125,17 +132,23 @@ class TorchDistComm:
             dist.all_gather_object(out, payload, group=self.group)
             return out
         if op == "all_gather_bytes":
-            bufs = [torch.empty_like(payload) for _ in range(self.world)]
-            dist.all_gather(bufs, payload, group=self.group)
-            return bufs
+            src = self._out(payload)
+            bufs = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(bufs, src, group=self.group)
+            return [b.to(payload.device) for b in bufs]
         if op == "ring_shift":
             send, recv = payload
             nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
-            ops = [dist.P2POp(dist.isend, t, nxt, group=self.group) for t in send if t.numel()]
-            ops += [dist.P2POp(dist.irecv, t, prv, group=self.group) for t in recv if t.numel()]
+            s_ = [self._out(t) for t in send]
+            r_ = [torch.empty(t.shape, dtype=t.dtype) if (self.host_staged and t.is_cuda) else t for t in recv]
+            ops = [dist.P2POp(dist.isend, t, nxt, group=self.group) for t in s_ if t.numel()]
+            ops += [dist.P2POp(dist.irecv, t, prv, group=self.group) for t in r_ if t.numel()]
             if ops:
                 for w in dist.batch_isend_irecv(ops):      # one ncclGroup: every rank sends and receives together
                     w.wait()
+            for dst, got in zip(recv, r_):
+                if dst is not got and dst.numel():
+                    dst.copy_(got)
             return recv
         raise ValueError(op)
 

@@ -327,6 +327,27 @@ class OraclePredictor:
         cons = self.consolidate(st, frame_idx, True, False, True)
         return frame_idx, st["obj_ids"], self.video_res(st, cons["pred_masks_video_res"])
 
+    def add_new_mask(self, st, frame_idx, obj_id, mask):
+        """add_new_mask (sam2_video_predictor.py:527-616) on a not-yet-tracked frame: the mask (resized with antialiasing
+        to the model resolution and re-binarised at 0.5 when its size differs, :552-561) IS the output
+        (_use_mask_as_output, sam2_base.py:399-448); the SAM heads only supply the object pointer."""
+        obj_idx = self.obj_id_to_idx(st, obj_id)
+        mask = torch.as_tensor(mask, dtype=torch.bool)
+        assert mask.dim() == 2
+        m = mask[None, None].float()
+        if m.shape[-2:] != (self.image_size, self.image_size):
+            m = F.interpolate(m, size=(self.image_size, self.image_size), align_corners=False, mode="bilinear", antialias=True)
+            m = (m >= 0.5).float()
+        st["mask_inputs_per_obj"][obj_idx][frame_idx] = m
+        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        is_init = frame_idx not in st["frames_already_tracked"]
+        assert is_init, "oracle covers prompts on not-yet-tracked frames only (Det-SAM2 usage)"
+        obj_out, obj_tmp = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
+        cur, _ = self.single_frame(st, obj_out, frame_idx, 1, True, None, m, False, False)
+        obj_tmp["cond_frame_outputs"][frame_idx] = cur
+        cons = self.consolidate(st, frame_idx, True, False, True)
+        return frame_idx, st["obj_ids"], self.video_res(st, cons["pred_masks_video_res"])
+
     def video_res(self, st, masks):
         """_get_orig_video_res_output (sam2_video_predictor.py:618-642)."""
         hw = (st["video_height"], st["video_width"])

@@ -31,24 +31,13 @@ def test_pass_sharded_stream_equals_sequential(appear):
     seq = VideoProcessor(detector=SyntheticDetector(3, appear=appear), predictor=_pred(), **kw)
     for t, f in enumerate(frames):
         seq.process_frame(t, f)
-
-    box = {}
-
-    def exchange(k, owner, payload):
-        if payload is not None:
-            box[k] = payload
-        return box[k]
-
     world = 2
-    vps = [P.ShardedVideoProcessor(detector=SyntheticDetector(3, appear=appear), predictor=_pred(), rank=r, world_size=world,
-                                   exchange=exchange, **kw) for r in range(world)]
-    for t, f in enumerate(frames):
-        owner = P.pass_owner(t // buf, world)
-        for r in [owner] + [x for x in range(world) if x != owner]:     # the owner's flush fills the mailbox first
-            vps[r].process_frame(t, f)
+    vps = [P.ShardedVideoProcessor(detector=SyntheticDetector(3, appear=appear), predictor=_pred(), rank=r, world_size=world, **kw)
+           for r in range(world)]
+    P.drive_lockstep(vps, frames)          # the round generators of both ranks, collectives answered in process
     num_passes = n // buf
     assert sorted(vps[0].owned_passes + vps[1].owned_passes) == list(range(num_passes))
-    merged = P.merge_segments([v.video_segments for v in vps], buf, track, num_passes, world)
+    merged = P.merge_segments([v.video_segments for v in vps], buf, track, num_passes, world, n)
     assert sorted(merged) == sorted(seq.video_segments) == list(range(n))
     worst, differing = 0.0, 0
     for t in range(n):
@@ -59,6 +48,9 @@ def test_pass_sharded_stream_equals_sequential(appear):
             u = (a | b).sum()
             worst = max(worst, 1.0 - ((a & b).sum() / u if u else 1.0))
     record("sharded_vs_sequential", appear=str(appear), one_minus_iou=worst, differing_pixels=differing)
-    assert differing == 0, (worst, differing)      # same kernels, same inputs: bit-identical masks
-    # each rank ran only its own passes' encoders / trackers
+    assert differing == 0, (worst, differing)      # same kernels, same inputs, same key order: bit-identical masks
+    # each rank tracked only its own passes; the pyramid hand-off means every frame was encoded exactly once
     assert vps[0].predictor.stats["tracked_frames"] + vps[1].predictor.stats["tracked_frames"] == seq.predictor.stats["tracked_frames"]
+    assert vps[0].predictor.stats["encoder_runs"] + vps[1].predictor.stats["encoder_runs"] == n == seq.predictor.stats["encoder_runs"]
+    ring = sum(b for v in vps for _, op, b in v.comm_log if op == "ring_shift")
+    assert ring == n * 16 * 2 ** 20             # every buffer travels once to the owner of the next pass: 16 MiB of pyramids per frame

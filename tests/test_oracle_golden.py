@@ -317,3 +317,32 @@ def test_e2e_17th_object_online_matches_reference_golden(tiny, golden_dir):
     od = vp.inference_state["output_dict"]
     assert sorted(od["cond_frame_outputs"]) == list(g["final_cond"])
     assert sorted(od["non_cond_frame_outputs"]) == list(g["final_noncond"])
+
+
+def test_e2e_mask_prompts_match_reference_golden(tiny, golden_dir):
+    """F3: add_new_mask / _use_mask_as_output through the reference predictor (golden e2e_mask): two mask-prompted
+    objects (one given at 384x512, resized with antialiasing) + an all-empty mask, forward propagation over 4 frames."""
+    from oracle.make_goldens import mask_prompts
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_mask.npz"))
+    op = OraclePredictor(sd, cfg)
+    m0, m1 = mask_prompts()
+    with torch.inference_mode():
+        st = op.init_state([synthetic_frame(t) for t in range(4)])
+        for oid, m in ((0, m0), (1, m1), (2, np.zeros((1024, 1024), bool))):
+            _, ids, vr = op.add_new_mask(st, 0, oid, m)
+        assert np.array_equal(np.packbits((vr > 0).numpy()), g["prompt_bits2"])
+        ys = []
+        for t, ids, logits in op.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=4, reverse=False):
+            od = st["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            ys.append((t, od[key][t], (logits > 0).numpy()))
+    assert [y[0] for y in ys] == list(g["frames"])
+    assert np.abs(ys[0][1]["obj_ptr"].numpy() - g["obj_ptr0"]).max() <= 2e-5
+    assert np.array_equal(ys[0][1]["object_score_logits"].numpy(), g["obj_score0"])        # +10, +10, -10 exactly
+    for i, (t, out, bits) in enumerate(ys):
+        low = out["pred_masks"].numpy()
+        assert np.abs(low - g["low"][i]).max() <= (0.0 if i == 0 else 1e-3)                # the prompted frame is exact
+        ref = np.unpackbits(g["bits"][i]).reshape(3, 1, 1024, 1024).astype(bool)
+        for o in range(3):
+            assert 1.0 - _iou(bits[o], ref[o]) <= 1e-3
