@@ -344,7 +344,7 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
     const int bn = (tile == 4 || tile == 5) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
     g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
-    static const int pf_env = [] { const char* e = getenv("DS2_GEMM_PF"); return e ? atoi(e) : 6; }();
+    static const int pf_env = [] { const char* e = getenv("DS2_GEMM_PF"); return e ? atoi(e) : 4; }();
     g.prefetch = pf_env;
   }
   if (tile == 5) return launch_gemm_split_d256(g, st);

@@ -66,15 +66,17 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // DMA sources: wave w stages rows [32w, 32w+32) of every plane, two 16-row pieces each (8 pieces per wave and tile)
+  // Roles: waves 0-3 issue ALL LDS-DMA pieces of a tile (rows [64w, 64w+64) of each of the four planes: 16 pieces per
+  // wave); waves 4-7 issue no DMA - they run the L2 prefetch instead (see below).  Both kinds of wave compute alike.
+  const bool loader = wave < 4;
   const int lc = (lane & 3) ^ ((lane >> 4) & 3);               // logical 16-byte chunk this lane fetches
-  unsigned oa[2], ob[2];
+  unsigned oa[4], ob[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int ma = m0 + wave * 32 + 16 * j + (lane >> 2);
+  for (int j = 0; j < 4; ++j) {
+    int ma = m0 + (wave & 3) * 64 + 16 * j + (lane >> 2);
     ma = ma < g.M ? ma : g.M - 1;   // clamp: rows beyond M/N are computed but never stored
     oa[j] = ((unsigned)ma * (unsigned)g.lda + lc * 8) * 2u;
-    int nb = n0 + wave * 32 + 16 * j + (lane >> 2);
+    int nb = n0 + (wave & 3) * 64 + 16 * j + (lane >> 2);
     nb = nb < g.N ? nb : g.N - 1;
     ob[j] = ((unsigned)nb * (unsigned)g.ldw + lc * 8) * 2u;
   }
@@ -87,17 +89,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   const int last = nk - 1;
 #define D2_DMA(src, dstoff) __builtin_amdgcn_global_load_lds((src), (lds_ptr)(lds + (dstoff)), 16, 0, 0);
 #define D2_FILL(kt, so)                                                                        \
-  {                                                                                            \
+  if (loader) {                                                                                \
     const unsigned ko = (unsigned)((kt) < last ? (kt) : last) * (BK * 2);                      \
-    const int ro = (wave * 32) * ROWB;                                                         \
-    D2_DMA(bAh + (oa[0] + ko), (so) + ro)                                                      \
-    D2_DMA(bAh + (oa[1] + ko), (so) + ro + 16 * ROWB)                                          \
-    D2_DMA(bAl + (oa[0] + ko), (so) + PL + ro)                                                 \
-    D2_DMA(bAl + (oa[1] + ko), (so) + PL + ro + 16 * ROWB)                                     \
-    D2_DMA(bWh + (ob[0] + ko), (so) + 2 * PL + ro)                                             \
-    D2_DMA(bWh + (ob[1] + ko), (so) + 2 * PL + ro + 16 * ROWB)                                 \
-    D2_DMA(bWl + (ob[0] + ko), (so) + 3 * PL + ro)                                             \
-    D2_DMA(bWl + (ob[1] + ko), (so) + 3 * PL + ro + 16 * ROWB)                                 \
+    const int ro = (wave * 64) * ROWB;                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                            \
+      D2_DMA(bAh + (oa[j] + ko), (so) + ro + j * 16 * ROWB)                                    \
+      D2_DMA(bAl + (oa[j] + ko), (so) + PL + ro + j * 16 * ROWB)                               \
+      D2_DMA(bWh + (ob[j] + ko), (so) + 2 * PL + ro + j * 16 * ROWB)                           \
+      D2_DMA(bWl + (ob[j] + ko), (so) + 3 * PL + ro + j * 16 * ROWB)                           \
+    }                                                                                          \
   }
   const int sw = (l31 >> 2) & 3;
   const int fra = (wm * 128 + l31) * ROWB, frb = 2 * PL + (wn * 64 + l31) * ROWB;
@@ -119,39 +119,40 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                           \
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.X[tm], F.Y[tn], acc[tm][tn], 0, 0, 0);
 
-  // L2 prefetch of the A operand (activations: first touch comes from HBM / Infinity Cache, ~3 us under load, while only
-  // ONE 64 KiB tile of LDS-DMA can be in flight): every step each wave "touches" one dword of the 64 cache lines that
-  // hold its 32 rows x 2 planes of K tile kt + g.prefetch, so that by the time the DMA of that tile is issued it hits
-  // in L2.  The loads are inline asm (invisible to hipcc's waitcnt bookkeeping); the step's wait is vmcnt(1): the
-  // eight DMA pieces of tile kt+1 are older than the newest touch and have landed, the touch itself may still fly.
+  // L2 prefetch.  A K tile is published by ONE barrier, so its latency is that of its slowest cache line - and some
+  // lines always miss L2 (activations come from HBM / Infinity Cache on first touch; a weight matrix of several MiB
+  // does not stay in the 4 MiB L2 while the activations stream through).  PMC: the waves spend ~40 % of their cycles in
+  // s_waitcnt / s_barrier.  Waves 4-7 therefore "touch" one dword of every 64-byte row segment of K tile kt + g.prefetch
+  // (64 rows x {A hi, A lo, W hi, W lo} per wave = 4 loads per step) so that the DMA of that tile, issued g.prefetch
+  // steps later by waves 0-3, hits in L2.  The touches are fire-and-forget: these waves never wait on vmcnt, and the
+  // loaders' vmcnt only counts their own DMA pieces (the memory counter is in-order per wave, which is why the touches
+  // cannot ride in the loaders).
   const int pf = g.prefetch;
-  const char* tbase = (lane >> 5 ? bAl : bAh);
-  unsigned toff;
+  unsigned ta, tw;
   {
-    int mr = m0 + wave * 32 + (lane & 31);
+    int mr = m0 + (wave & 3) * 64 + lane;
     mr = mr < g.M ? mr : g.M - 1;
-    toff = (unsigned)mr * (unsigned)g.lda * 2u;
+    ta = (unsigned)mr * (unsigned)g.lda * 2u;
+    int nr = n0 + (wave & 3) * 64 + lane;
+    nr = nr < g.N ? nr : g.N - 1;
+    tw = (unsigned)nr * (unsigned)g.ldw * 2u;
   }
   unsigned junk = 0;
 #define D2_TOUCH(kt)                                                                           \
-  if (pf > 0) {                                                                                \
-    const int kk_ = (kt) + pf < last ? (kt) + pf : last;                                       \
-    const char* p_ = tbase + (toff + (unsigned)kk_ * (BK * 2));                                \
-    asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(p_) : "memory");           \
+  if (!loader && pf > 0 && (kt) + pf <= last) {                                                \
+    const unsigned ko_ = (unsigned)((kt) + pf) * (BK * 2);                                     \
+    const char *p0_ = bAh + (ta + ko_), *p1_ = bAl + (ta + ko_), *p2_ = bWh + (tw + ko_), *p3_ = bWl + (tw + ko_); \
+    asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %2, off\n\t"          \
+                 "global_load_dword %0, %3, off\n\tglobal_load_dword %0, %4, off"              \
+                 : "=&v"(junk) : "v"(p0_), "v"(p1_), "v"(p2_), "v"(p3_) : "memory");           \
   }
 
   FragsD F0, F1;
   int s0 = 0, s1 = STAGE;       // stage offsets of tiles t, t+1
-  if (pf > 0) {   // prime the L2 for the first tiles (one line holds two K tiles of a row)
-    for (int t = 2; t < 2 + pf && t <= last; t += 2) {
-      const char* p_ = tbase + (toff + (unsigned)t * (BK * 2));
-      asm volatile("global_load_dword %0, %1, off" : "=v"(junk) : "v"(p_) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // keeps the vmcnt arithmetic below simple; ~one HBM latency per block
-  }
+  for (int t = 2 - pf; t < 2; ++t) D2_TOUCH(t)          // tiles 2 .. pf+1 (tiles 0 and 1 are fetched right away)
   D2_FILL(0, s0)
   D2_FILL(1, s1)
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0 landed (this wave's pieces) ...
+  if (loader) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 landed (this wave's pieces) ...
   __builtin_amdgcn_s_barrier();                      // ... and everybody else's
   D2_READ(F0, s0, 0)
   for (int kt = 0; kt < nk; ++kt) {
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     __builtin_amdgcn_sched_barrier(0);
     // F1 landed => this wave no longer reads stage s0; its own pieces of tile kt+1 landed.  After the barrier: stage s0
     // is free for tile kt+2 and tile kt+1 is visible to everyone.
-    if (pf > 0) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (loader) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     D2_FILL(kt + 2, s0)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   // ---- epilogue: each wave parks one 32 x 64 slab of its tile in LDS at a time and re-reads it row-wise (4 consecutive
   // columns per lane: 16-byte bias/residual loads and fp32 stores, 8-byte plane stores); same arithmetic as
   // k_gemm_split's epilogue.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (redundant) tail prefetch before LDS is reused
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (redundant) tail DMA / touches before LDS is reused
   __syncthreads();
   constexpr int EPLD = 68;
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPLD);

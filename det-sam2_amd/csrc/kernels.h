@@ -46,6 +46,12 @@ int launch_select_masks(const float* masks4, const float* iou4, const float* obj
                         float* iou_out, int B, hipStream_t st);
 int launch_ptr_gate(float* ptr, const float* obj_logits, const float* no_obj_ptr, int B, int C, hipStream_t st);
 
+// mask prompts (add_new_mask): antialiased bilinear resize (work: [B,Hin,Wout] floats) and the mask_downsample conv
+int launch_resize_aa(const float* in, float* work, float* out, int B, int Hin, int Win, int Hout, int Wout, float in_scale,
+                     float in_bias, float thresh /* INFINITY = none */, hipStream_t st);
+int launch_mask_downsample4(const float* mask, const float* w16, const float* bias, float* out, int* any /*[B]*/,
+                            float* obj_logits /*[B]*/, int B, int S, hipStream_t st);
+
 // memory bank.  The entry tables travel by value in the kernel arguments, at most DS2_MAX_*_ENTRIES per launch; larger
 // banks (the reference has no limit: 20 selected cond frames + EVERY preload cond frame + 6, sam2_utils.py:56-60) are
 // assembled by several launches, each writing its own slice of the [B, Nk, 64] outputs (e0 / p0 offsets).

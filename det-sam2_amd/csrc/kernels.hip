@@ -653,6 +653,78 @@ __global__ void k_ptr_gate(float* ptr, const float* obj_logits, const float* no_
   ptr[i] = lam * ptr[i] + (1.f - lam) * no_obj_ptr[c];
 }
 
+// ------------------------------------------------------------------ mask prompts (F3: add_new_mask)
+// F.interpolate(mode="bilinear", antialias=True, align_corners=False) as ATen computes it on the CPU
+// (UpSampleKernel.cpp, HelperInterpLinear::aa + the separable loops: last dimension first): per output index
+//   scale = in / out (float); support = scale >= 1 ? scale : 1; center = scale * (i + 0.5);
+//   xmin = max(int(center - support + 0.5), 0); xsize = min(int(center + support + 0.5), in) - xmin;
+//   w_j = tri((j + xmin - center + 0.5) * (scale >= 1 ? 1/scale : 1)), normalised by their sum; out = sum_j src[xmin+j] * w_j
+// accumulated in tap order in fp32.  `along_w`: 1 = resize the last dimension (rows of `in` are [rows, n_in]), 0 = the
+// first one of a [n_in, cols] image.  v = in * in_scale + in_bias is applied to the source first; thresh < inf turns
+// the output into (out >= thresh) ? 1 : 0.
+__global__ void k_resize_aa_1d(const float* in, float* out, int B, int n_in, int n_out, int other, int along_w, float in_scale,
+                               float in_bias, float thresh) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * n_out * other) return;
+  int o, r;            // o: output index along the resized dimension, r: index along the other one
+  size_t b;
+  if (along_w) { o = (int)(i % n_out); r = (int)((i / n_out) % other); b = i / ((size_t)n_out * other); }
+  else { r = (int)(i % other); o = (int)((i / other) % n_out); b = i / ((size_t)n_out * other); }
+  const float scale = (float)n_in / (float)n_out;
+  const float support = scale >= 1.f ? scale : 1.f;
+  const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  const float center = scale * ((float)o + 0.5f);
+  int xmin = (int)(center - support + 0.5f);
+  xmin = xmin > 0 ? xmin : 0;
+  int xmax = (int)(center + support + 0.5f);
+  xmax = xmax < n_in ? xmax : n_in;
+  const int xsize = xmax - xmin;
+  float total = 0.f;
+  for (int j = 0; j < xsize; ++j) {
+    float x = fabsf(((float)(j + xmin) - center + 0.5f) * invscale);
+    total += x < 1.f ? 1.f - x : 0.f;
+  }
+  const float* src = along_w ? in + (b * other + r) * (size_t)n_in : in + b * (size_t)n_in * other + r;
+  const size_t stride = along_w ? 1 : (size_t)other;
+  float t = 0.f;
+  for (int j = 0; j < xsize; ++j) {
+    float x = fabsf(((float)(j + xmin) - center + 0.5f) * invscale);
+    float w = x < 1.f ? 1.f - x : 0.f;
+    if (total != 0.f) w = w / total;
+    const float v = src[(size_t)(xmin + j) * stride] * in_scale + in_bias;
+    t = j == 0 ? __fmul_rn(v, w) : __fadd_rn(t, __fmul_rn(v, w));
+  }
+  if (thresh < INFINITY) t = t >= thresh ? 1.f : 0.f;
+  out[i] = t;
+}
+
+// mask_downsample (Conv2d(1, 1, kernel 4, stride 4), sam2_base.py:180-183) of a 0/1 mask [B,S,S] -> [B,S/4,S/4], and
+// is_obj_appearing = any(mask > 0) -> object_score_logits = +-10 (sam2_base.py:436-440).  any[] must be zeroed before.
+__global__ void k_mask_downsample4(const float* mask, const float* w16, const float* bias, float* out, int* any, int B, int S) {
+  const int So = S / 4;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * So * So) return;
+  const int x = (int)(i % So), y = (int)((i / So) % So);
+  const size_t b = i / ((size_t)So * So);
+  const float* m = mask + (b * S + 4 * y) * (size_t)S + 4 * x;
+  float acc = 0.f;
+  bool pos = false;
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const float v = m[(size_t)ky * S + kx];
+      acc += v * w16[ky * 4 + kx];
+      pos |= v > 0.f;
+    }
+  out[i] = acc + bias[0];
+  if (pos) atomicOr(any + b, 1);
+}
+__global__ void k_any_to_logits(const int* any, float* obj_logits, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) obj_logits[b] = any[b] ? 10.f : -10.f;
+}
+
 // ------------------------------------------------------------------ memory bank assembly (sam2_base.py:565-648)
 __global__ void k_bank_mem(BankArgs a) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B * n_mem * tokens * 16 (float4 granules)
@@ -948,6 +1020,26 @@ int launch_select_masks(const float* masks4, const float* iou4, const float* obj
 }
 int launch_ptr_gate(float* ptr, const float* obj_logits, const float* no_obj_ptr, int B, int C, hipStream_t st) {
   hipLaunchKernelGGL(k_ptr_gate, grid1((size_t)B * C), dim3(256), 0, st, ptr, obj_logits, no_obj_ptr, B, C);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_resize_aa(const float* in, float* work, float* out, int B, int Hin, int Win, int Hout, int Wout, float in_scale,
+                     float in_bias, float thresh, hipStream_t st) {
+  // last dimension first, as ATen's separable CPU path; the affine map of the source is applied in the first pass only
+  hipLaunchKernelGGL(k_resize_aa_1d, grid1((size_t)B * Hin * Wout), dim3(256), 0, st, in, work, B, Win, Wout, Hin, 1, in_scale,
+                     in_bias, INFINITY);
+  DS2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_resize_aa_1d, grid1((size_t)B * Hout * Wout), dim3(256), 0, st, work, out, B, Hin, Hout, Wout, 0, 1.f, 0.f,
+                     thresh);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_mask_downsample4(const float* mask, const float* w16, const float* bias, float* out, int* any, float* obj_logits,
+                            int B, int S, hipStream_t st) {
+  DS2_CHECK_HIP(hipMemsetAsync(any, 0, (size_t)B * sizeof(int), st));
+  hipLaunchKernelGGL(k_mask_downsample4, grid1((size_t)B * (S / 4) * (S / 4)), dim3(256), 0, st, mask, w16, bias, out, any, B, S);
+  DS2_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_any_to_logits, grid1((size_t)B), dim3(256), 0, st, any, obj_logits, B);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

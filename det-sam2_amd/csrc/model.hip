@@ -1071,6 +1071,29 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   return DS2_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ F3 (mask prompts)
+extern "C" int ds2_resize_aa(const float* in, int32_t B, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, float in_scale,
+                             float in_bias, float threshold, float* work, float* out, void* stream) {
+  DS2_REQUIRE(in && work && out && B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "ds2_resize_aa: bad argument");
+  return launch_resize_aa(in, work, out, B, Hin, Win, Hout, Wout, in_scale, in_bias, threshold, (hipStream_t)stream);
+}
+
+extern "C" int ds2_mask_prompt_prepare(ds2_model* m, int32_t B, const float* mask, float* mask_ds, float* obj_logits,
+                                       int32_t* work, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && mask && mask_ds && obj_logits && work, "ds2_mask_prompt_prepare: bad argument");
+  const float* w = m->P("mask_downsample.weight");
+  const float* b = m->P("mask_downsample.bias");
+  CHECK_PARAMS();
+  return launch_mask_downsample4(mask, w, b, mask_ds, work, obj_logits, B, m->cfg.image_size, (hipStream_t)stream);
+}
+
+extern "C" int ds2_obj_ptr_gate(ds2_model* m, int32_t B, float* obj_ptr, const float* obj_logits, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && obj_ptr && obj_logits, "ds2_obj_ptr_gate: bad argument");
+  const float* no = m->P("no_obj_ptr");
+  CHECK_PARAMS();
+  return launch_ptr_gate(obj_ptr, obj_logits, no, B, 256, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------------ A15
 extern "C" int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
                                uint8_t* packed, void* stream) {

@@ -209,6 +209,31 @@ class HipSam2(HipOps):
                     "ds2_sam_heads_mask")
         return low, ptr, obj, iou
 
+    def resize_aa(self, x, hout, wout, in_scale=1.0, in_bias=0.0, threshold=float("inf")):
+        """F.interpolate(bilinear, antialias=True, align_corners=False) of fp32 [B,Hin,Win] -> [B,hout,wout]."""
+        assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and x.dim() == 3
+        B, hin, win = x.shape
+        work, out = self._empty(B, hin, wout), self._empty(B, hout, wout)
+        _capi.check(self.lib.ds2_resize_aa(_p(x), B, hin, win, hout, wout, in_scale, in_bias, threshold, _p(work), _p(out),
+                                           self._stream()), "ds2_resize_aa")
+        return out
+
+    def use_mask_as_output(self, B, fpn2, fpn0, fpn1, mask):
+        """SAM2Base._use_mask_as_output (sam2_base.py:399-448): mask fp32 0/1 [B,S,S] ->
+        (low_res logits [B,256,256], obj_ptr [B,256], obj_logits [B]).  fpn2 is the frame's raw level-2 feature
+        (no memory, no no_mem_embed: track_step :873-879)."""
+        S = self.cfg.image_size
+        assert mask.dtype == torch.float32 and tuple(mask.shape) == (B, S, S) and mask.is_contiguous()
+        low = self.resize_aa(mask, S // 4, S // 4, 20.0, -10.0)                        # (mask*20-10) -> 256^2, antialiased
+        ds, obj = self._empty(B, S // 4, S // 4), self._empty(B)
+        work = self._empty(B, dtype=torch.int32)
+        _capi.check(self.lib.ds2_mask_prompt_prepare(self.h, B, _p(mask), _p(ds), _p(obj), _p(work), self._stream()),
+                    "ds2_mask_prompt_prepare")
+        _, ptr, _, _ = self.sam_heads(B, fpn2, fpn0, fpn1, None, None, multimask=False, pix_bcast=True, add_no_mem_embed=False,
+                                      mask_inputs=ds)                                  # gated by the decoder's own object score
+        _capi.check(self.lib.ds2_obj_ptr_gate(self.h, B, _p(ptr), _p(obj), self._stream()), "ds2_obj_ptr_gate")  # ... then by the mask's
+        return low, ptr, obj
+
     def memory_encoder(self, B, fpn2, low_res, obj_logits, binarize):
         """-> maskmem bf16 [B,4096,64] (A13)."""
         out = self._empty(B, TOK, 64, dtype=torch.bfloat16)

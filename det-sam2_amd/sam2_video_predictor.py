@@ -319,9 +319,34 @@ class SAM2VideoPredictor:
     def add_new_points(self, *a, **k):
         return self.add_new_points_or_box(*a, **k)
 
-    def add_new_mask(self, *a, **k):
-        raise NotImplementedError("add_new_mask (user-drawn mask prompts) is not part of the Det-SAM2 hot path "
-                                  "(det_sam2_RT.py only issues box prompts, :297-302)")
+    @torch.inference_mode()
+    def add_new_mask(self, inference_state, frame_idx, obj_id, mask):
+        """add_new_mask (sam2_video_predictor.py:527-616): a user mask for one object on one frame.  The mask itself
+        becomes the output (SAM2Base._use_mask_as_output): low-res logits = antialiased downsample of mask*20-10, the SAM
+        heads (fed mask_downsample(mask) as mask prompt) only supply the object pointer, objectness = the mask is
+        non-empty.  A mask of another size is resized to the model resolution (bilinear, antialias) and re-binarised at
+        0.5 (:552-561)."""
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        if not isinstance(mask, torch.Tensor):
+            mask = torch.tensor(np.asarray(mask), dtype=torch.bool)
+        assert mask.dim() == 2
+        S = self.image_size
+        m = mask.to(self.device).to(torch.float32)[None].contiguous()
+        if tuple(m.shape[-2:]) != (S, S):
+            m = self.hip.resize_aa(m, S, S, threshold=0.5)
+        st["mask_inputs_per_obj"][obj_idx][frame_idx] = m[None]
+        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        if frame_idx in st["frames_already_tracked"]:
+            raise NotImplementedError("correction masks on already-tracked frames are outside the Det-SAM2 hot path")
+        f0, f1, f2 = self._get_image_feature(st, frame_idx)
+        low, ptr, obj = self.hip.use_mask_as_output(1, f2, f0, f1, m)
+        low = self._fill_holes(low)
+        st["temp_output_dict_per_obj"][obj_idx]["cond_frame_outputs"][frame_idx] = {
+            "maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1), "obj_ptr": ptr,
+            "object_score_logits": obj.unsqueeze(1)}
+        cons = self._consolidate(st, frame_idx, True, False)
+        return frame_idx, st["obj_ids"], self._video_res(st, cons["pred_masks"])
 
     def _video_res(self, st, low, packed=False):
         """_get_orig_video_res_output (sam2_video_predictor.py:618-642)."""

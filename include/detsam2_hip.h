@@ -137,6 +137,23 @@ int ds2_connected_components(const uint8_t* mask, int32_t N, int32_t H, int32_t 
  * work: int32 scratch of 3*N*H*W elements.  max_area <= 0 is an error (misc.py:371). */
 int ds2_fill_holes(float* logits, int32_t N, int32_t H, int32_t W, int32_t max_area, int32_t* work, void* stream);
 
+/* ---- F3: mask prompts = add_new_mask (sam2/sam2_video_predictor.py:527-616) -> SAM2Base._use_mask_as_output
+ * (sam2/modeling/sam2_base.py:399-448).  Three small ops the host composes with ds2_sam_heads_mask:
+ *  ds2_resize_aa: F.interpolate(mode="bilinear", antialias=True, align_corners=False) of fp32 [B,Hin,Win] ->
+ *    [B,Hout,Wout] (ATen's separable CPU algorithm, last dimension first); the source is mapped through
+ *    in*in_scale + in_bias first; threshold < INFINITY binarises the result (out >= threshold ? 1 : 0).  Used for
+ *    (i) a prompt mask given at another resolution -> 1024^2, >= 0.5 (sam2_video_predictor.py:552-561) and (ii) the
+ *    low-res output logits: (mask*20-10) at 1024^2 -> 256^2 (sam2_base.py:407-415).  work: B*Hin*Wout floats.
+ *  ds2_mask_prompt_prepare: mask_downsample Conv2d(1,1,4,stride 4) of the 0/1 mask [B,1024,1024] -> mask_ds [B,256,256]
+ *    (the mask input of the SAM heads, sam2_base.py:425-429) and object_score_logits = any(mask > 0) ? +10 : -10
+ *    (:436-440) -> obj_logits [B].  work: B int32.
+ *  ds2_obj_ptr_gate: obj_ptr = lam*obj_ptr + (1-lam)*no_obj_ptr, lam = obj_logits > 0, in place on [B,256] (:441-444). */
+int ds2_resize_aa(const float* in, int32_t B, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout, float in_scale,
+                  float in_bias, float threshold, float* work, float* out, void* stream);
+int ds2_mask_prompt_prepare(ds2_model* m, int32_t B, const float* mask, float* mask_ds, float* obj_logits, int32_t* work,
+                            void* stream);
+int ds2_obj_ptr_gate(ds2_model* m, int32_t B, float* obj_ptr, const float* obj_logits, void* stream);
+
 /* ---- A15: _get_orig_video_res_output (sam2_video_predictor.py:618-642) + `> 0` (det_sam2_RT.py:396-399):
  * low_res [B,256,256] -> logits fp32 [B,Hv,Wv] (may be NULL) and/or masks packed 8 px/byte, MSB first
  * (numpy.packbits rows, last byte zero-padded) [B,Hv,ceil(Wv/8)] (may be NULL). */
