@@ -47,6 +47,9 @@ SIGNATURES = {
     "ds2_memory_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
     "ds2_connected_components": (C.c_int, [c_vp, i32, i32, i32, c_vp, c_vp, c_vp, c_vp]),
     "ds2_fill_holes": (C.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
+    "ds2_image_encoder_f32": (C.c_int, [c_vp, c_vp, i32, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_memory_attention_ex": (C.c_int, [c_vp, i32, c_vp, i32, c_vp, i32, c_vp, c_vp, i32, i32, c_vp, c_vp]),
+    "ds2_memory_encoder_ex": (C.c_int, [c_vp, i32, c_vp, i32, c_vp, i32, c_vp, c_vp]),
     "ds2_resize_aa": (C.c_int, [c_vp, i32, i32, i32, i32, i32, C.c_float, C.c_float, C.c_float, c_vp, c_vp, c_vp]),
     "ds2_mask_prompt_prepare": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ds2_obj_ptr_gate": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp]),

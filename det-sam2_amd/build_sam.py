@@ -27,11 +27,64 @@ def _load_state_dict(cfg, ckpt_path):
     return torch.load(ckpt_path, map_location="cpu")["model"]
 
 
+# Hydra override keys (the reference's plugin mechanism, build_sam.py:121-141) that map onto ModelCfg fields.  Keys that
+# select what this library IS (the predictor class, the five post-processing overrides at their reference values) are
+# accepted when they ask for exactly that; anything that would need a different model raises.
+_CFG_KEYS = {
+    "model.fill_hole_area": ("fill_hole_area", int),
+    "model.binarize_mask_from_pts_for_mem_enc": ("binarize_mask_from_pts_for_mem_enc", "bool"),
+    "model.sam_mask_decoder_extra_args.dynamic_multimask_stability_delta": ("dynamic_multimask_stability_delta", float),
+    "model.sam_mask_decoder_extra_args.dynamic_multimask_stability_thresh": ("dynamic_multimask_stability_thresh", float),
+    "model.max_cond_frames_in_attn": ("max_cond_frames_in_attn", int),
+    "model.max_obj_ptrs_in_encoder": ("max_obj_ptrs_in_encoder", int),
+    "model.sigmoid_scale_for_mem_enc": ("sigmoid_scale_for_mem_enc", float),
+    "model.sigmoid_bias_for_mem_enc": ("sigmoid_bias_for_mem_enc", float),
+    "model.multimask_min_pt_num": ("multimask_min_pt_num", int),
+    "model.multimask_max_pt_num": ("multimask_max_pt_num", int),
+}
+_FIXED = {   # accepted only with the value the reference's video-predictor build uses
+    "model._target_": "sam2.sam2_video_predictor.SAM2VideoPredictor",
+    "model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability": True,
+    "model.image_size": 1024, "model.num_maskmem": 7,
+}
+
+
+def _parse_scalar(v):
+    t = v.strip()
+    if t.lower() in ("true", "false"):
+        return t.lower() == "true"
+    for cast in (int, float):
+        try:
+            return cast(t)
+        except ValueError:
+            pass
+    return t.strip("'\"")
+
+
+def apply_hydra_overrides(cfg, overrides):
+    """``["++model.fill_hole_area=0", ...]`` -> ModelCfg with those fields replaced (dataclasses.replace)."""
+    import dataclasses
+    changes = {}
+    for ov in overrides or []:
+        key, sep, val = str(ov).lstrip("+~").partition("=")
+        if not sep:
+            raise ValueError(f"malformed hydra override {ov!r} (expected key=value)")
+        key, val = key.strip(), _parse_scalar(val)
+        if key in _CFG_KEYS:
+            name, cast = _CFG_KEYS[key]
+            changes[name] = bool(val) if cast == "bool" else cast(val)
+        elif key in _FIXED:
+            if val != _FIXED[key]:
+                raise NotImplementedError(f"hydra override {ov!r}: only {key}={_FIXED[key]} is built")
+        else:
+            raise NotImplementedError(f"hydra override {ov!r} does not map onto det_sam2_amd.config.ModelCfg "
+                                      f"(known keys: {sorted(list(_CFG_KEYS) + list(_FIXED))})")
+    return dataclasses.replace(cfg, **changes) if changes else cfg
+
+
 def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode="eval", hydra_overrides_extra=[],
                                apply_postprocessing=True, **kwargs):
-    cfg = resolve_config(config_file)
-    if hydra_overrides_extra:
-        raise NotImplementedError("hydra overrides are not interpreted; edit det_sam2_amd.config.ModelCfg instead")
+    cfg = apply_hydra_overrides(resolve_config(config_file), hydra_overrides_extra)
     if not apply_postprocessing:
         raise NotImplementedError("apply_postprocessing=False (no dynamic multimask / binarised prompt masks) is not built")
     if mode != "eval":

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   // (64 rows x {A hi, A lo, W hi, W lo} per wave = 4 loads per step) so that the DMA of that tile, issued g.prefetch
   // steps later by waves 0-3, hits in L2.  The touches are fire-and-forget: these waves never wait on vmcnt, and the
   // loaders' vmcnt only counts their own DMA pieces (the memory counter is in-order per wave, which is why the touches
-  // cannot ride in the loaders).
+  // cannot ride in the loaders).  `junk` is read-write in every asm so that its register stays reserved from the first
+  // touch to the end of the loop: a dead destination register would be re-allocated while loads into it are in flight.
   const int pf = g.prefetch;
   unsigned ta, tw;
   {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     const char *p0_ = bAh + (ta + ko_), *p1_ = bAl + (ta + ko_), *p2_ = bWh + (tw + ko_), *p3_ = bWl + (tw + ko_); \
     asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %2, off\n\t"          \
                  "global_load_dword %0, %3, off\n\tglobal_load_dword %0, %4, off"              \
-                 : "=&v"(junk) : "v"(p0_), "v"(p1_), "v"(p2_), "v"(p3_) : "memory");           \
+                 : "+v"(junk) : "v"(p0_), "v"(p1_), "v"(p2_), "v"(p3_) : "memory");            \
   }
 
   FragsD F0, F1;

@@ -10,6 +10,7 @@ int launch_maxpool2x2(const float* in, int ld_in, float* out, int ld_out, int H,
 int launch_up2_add(const float* lat, const float* coarse, float* out, int H, int W, int C, hipStream_t st);
 int launch_rope(float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens, hipStream_t st);
 int launch_im2col_patch(const uint16_t* frame_f16, float* out, int S, hipStream_t st);  // [3,S,S] fp16 -> [(S/4)^2,148]
+int launch_im2col_patch_f32(const float* frame_f32, float* out, int S, hipStream_t st);
 int launch_ingest_u8(const uint8_t* rgb, const uint16_t* lut, uint16_t* out, int n, int S, hipStream_t st);
 int launch_ingest_resize_u8(const uint8_t* rgb, const int* tab, const uint16_t* lut, uint16_t* out, int n, int H, int W, int S,
                             hipStream_t st);

@@ -283,6 +283,20 @@ __global__ void k_rope(float* x, int ldx, const float* cis, int batch, int L, in
 // PatchEmbed 7x7 / stride 4 / pad 3 as im2col (backbones/utils.py:69-96): frame fp16 [3,S,S]
 // (the reference's stored frame, .float()'ed at sam2_video_predictor.py:1186) -> [(S/4)^2, 148] fp32,
 // column = c*49 + ky*7 + kx (the flattened conv weight order), column 147 = 0.
+__global__ void k_im2col_patch_f32(const float* frame, float* out, int S) {   // same, fp32 frame (module-level entry)
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = S / 4;
+  if (i >= (size_t)G * G * 148) return;
+  const int col = (int)(i % 148);
+  const int p = (int)(i / 148), ox = p % G, oy = p / G;
+  float v = 0.f;
+  if (col < 147) {
+    const int c = col / 49, r = col % 49, ky = r / 7, kx = r % 7;
+    const int iy = oy * 4 - 3 + ky, ix = ox * 4 - 3 + kx;
+    if (iy >= 0 && iy < S && ix >= 0 && ix < S) v = frame[((size_t)c * S + iy) * S + ix];
+  }
+  out[i] = v;
+}
 __global__ void k_im2col_patch(const uint16_t* frame, float* out, int S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int G = S / 4;
@@ -915,6 +929,11 @@ int launch_up2_add(const float* lat, const float* coarse, float* out, int H, int
 int launch_rope(float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens, hipStream_t st) {
   if (n_rope <= 0) return DS2_OK;
   hipLaunchKernelGGL(k_rope, grid1((size_t)batch * n_rope * 128), dim3(256), 0, st, x, ldx, cis, batch, L, n_rope, grid_tokens);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_im2col_patch_f32(const float* frame_f32, float* out, int S, hipStream_t st) {
+  hipLaunchKernelGGL(k_im2col_patch_f32, grid1((size_t)(S / 4) * (S / 4) * 148), dim3(256), 0, st, frame_f32, out, S);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

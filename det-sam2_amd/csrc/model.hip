@@ -99,8 +99,49 @@ constexpr int TOK = 4096;  // 64x64 tokens at stride 16
 
 }  // namespace
 
+// bf16x3 operand planes of weights (split once, cached) and the scratch for activation planes that no producer emitted:
+// owned by the model (two predictors in one process - other GPUs, other streams - must not share them); the primitive
+// ops (ds2_op_gemm), which have no model, use one process-wide context.
+struct GemmPlanes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
+struct GemmCtx {
+  std::unordered_map<const float*, GemmPlanes> wcache;
+  char* scratch = nullptr;
+  size_t scratch_cap = 0;
+  int require(size_t bytes, hipStream_t st) {
+    if (bytes <= scratch_cap) return DS2_OK;
+    DS2_CHECK_HIP(hipStreamSynchronize(st));
+    if (scratch) DS2_CHECK_HIP(hipFree(scratch));
+    scratch = nullptr; scratch_cap = 0;
+    const size_t want = bytes + bytes / 4 + (16u << 20);
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), want));
+    scratch_cap = want;
+    return DS2_OK;
+  }
+  void release() {
+    for (auto& kv : wcache) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    wcache.clear();
+    if (scratch) (void)hipFree(scratch);
+    scratch = nullptr; scratch_cap = 0;
+  }
+};
+static GemmCtx g_gemm_ctx;   // primitives only
+
+// Every model entry point runs with the model's device current (allocations, launches) and restores the caller's.
+struct DeviceGuard {
+  int prev = -1, dev;
+  explicit DeviceGuard(int d) : dev(d) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+  }
+};
+
 struct ds2_model {
   ds2_config cfg;
+  int device = 0;              // the device that was current at ds2_model_create
+  GemmCtx gctx;
   std::vector<BlockCfg> blocks;
   std::vector<int> stage_ends;
   std::unordered_map<std::string, Blob> params;
@@ -193,20 +234,6 @@ int attn_split(const float* q, int ldq, const void* khi, const void* klo, const 
   return use_w8() ? launch_attention_w8(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, 64, st)
                   : launch_attention_split(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, st);
 }
-struct Planes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
-std::unordered_map<const float*, Planes> g_wcache;
-char* g_scratch = nullptr;
-size_t g_scratch_cap = 0;
-int scratch_require(size_t bytes, hipStream_t st) {
-  if (bytes <= g_scratch_cap) return DS2_OK;
-  DS2_CHECK_HIP(hipStreamSynchronize(st));
-  if (g_scratch) DS2_CHECK_HIP(hipFree(g_scratch));
-  g_scratch = nullptr; g_scratch_cap = 0;
-  const size_t want = bytes + bytes / 4 + (16u << 20);
-  DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_scratch), want));
-  g_scratch_cap = want;
-  return DS2_OK;
-}
 inline int round32(int k) { return (k + 31) / 32 * 32; }
 }  // namespace
 
@@ -259,27 +286,28 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     if (ia != m->act_planes.end() && ia->second.ld == Kp) { ahi = ia->second.hi; alo = ia->second.lo; }
   }
   const size_t a_bytes = ahi ? 0 : (size_t)M * Kp * 2;
-  Planes wp;
-  auto it = w_static ? g_wcache.find(W) : g_wcache.end();
-  if (it != g_wcache.end()) {
+  GemmCtx& ctx = m ? m->gctx : g_gemm_ctx;
+  GemmPlanes wp;
+  auto it = w_static ? ctx.wcache.find(W) : ctx.wcache.end();
+  if (it != ctx.wcache.end()) {
     wp = it->second;
-    TRY(scratch_require(2 * a_bytes + 512, st));
+    TRY(ctx.require(2 * a_bytes + 512, st));
   } else if (w_static) {
     DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.hi), w_bytes));
     DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), w_bytes));
     wp.ld = Kp;
     TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
-    g_wcache[W] = wp;
-    TRY(scratch_require(2 * a_bytes + 512, st));
+    ctx.wcache[W] = wp;
+    TRY(ctx.require(2 * a_bytes + 512, st));
   } else {
-    TRY(scratch_require(2 * a_bytes + 2 * w_bytes + 1024, st));
-    wp.hi = reinterpret_cast<unsigned short*>(g_scratch + ((2 * a_bytes + 255) & ~(size_t)255));
+    TRY(ctx.require(2 * a_bytes + 2 * w_bytes + 1024, st));
+    wp.hi = reinterpret_cast<unsigned short*>(ctx.scratch + ((2 * a_bytes + 255) & ~(size_t)255));
     wp.lo = wp.hi + (size_t)N * Kp;
     wp.ld = Kp;
     TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
   }
   if (!ahi) {
-    unsigned short* sh = reinterpret_cast<unsigned short*>(g_scratch);
+    unsigned short* sh = reinterpret_cast<unsigned short*>(ctx.scratch);
     unsigned short* sl = sh + (size_t)M * Kp;
     TRY(launch_split_rows(A, lda, M, K, sh, sl, Kp, st));
     ahi = sh; alo = sl;
@@ -331,6 +359,7 @@ extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
               "ds2_model_create: only image_size=1024, d_model=256, mem_dim=64 are supported");
   ds2_model* m = new ds2_model();
   m->cfg = *cfg;
+  DS2_CHECK_HIP(hipGetDevice(&m->device));
   // per-block geometry: Hiera.__init__ loop (hieradet.py:236-267)
   int depth = 0;
   for (int s = 0; s < 4; ++s) { depth += cfg->stages[s]; m->stage_ends.push_back(depth - 1); }
@@ -353,17 +382,17 @@ extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
 
 extern "C" void ds2_model_destroy(ds2_model* m) {
   if (!m) return;
-  for (auto& kv : m->params) {
-    auto it = g_wcache.find(reinterpret_cast<const float*>(kv.second.ptr));
-    if (it != g_wcache.end()) { (void)hipFree(it->second.hi); (void)hipFree(it->second.lo); g_wcache.erase(it); }
+  DeviceGuard _dg(m->device);
+  m->gctx.release();
+  for (auto& kv : m->params)
     if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-  }
   if (m->ws) (void)hipFree(m->ws);
   delete m;
 }
 
 extern "C" int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_t nbytes) {
   DS2_REQUIRE(m && name && data && nbytes > 0, "ds2_model_set_param: bad argument");
+  DeviceGuard _dg(m->device);
   DS2_REQUIRE(!m->finalized, "ds2_model_set_param: model already finalized");
   Blob b;
   b.bytes = (size_t)nbytes;
@@ -387,6 +416,7 @@ static int expect(ds2_model* m, const std::string& name, size_t n_floats) {
 
 extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
   DS2_REQUIRE(m, "ds2_model_finalize: null model");
+  DeviceGuard _dg(m->device);
   hipStream_t st = (hipStream_t)stream;
   const int C0 = m->cfg.embed_dim, D = 256;
   // ---- strict presence / size check of everything the stages read
@@ -500,6 +530,7 @@ static void resize_tables(int dst, int src, bool clamp_weights, int* ofs, int* w
 extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t height, int32_t width,
                                  uint16_t* frames_f16, void* stream) {
   DS2_REQUIRE(m && m->finalized && rgb_u8 && frames_f16 && n > 0 && height > 0 && width > 0, "ds2_ingest_frames: bad argument");
+  DeviceGuard _dg(m->device);
   const int S = m->cfg.image_size;
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* lut = reinterpret_cast<const uint16_t*>(m->P("#ingest_lut"));
@@ -520,9 +551,21 @@ extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n,
 }
 
 // ------------------------------------------------------------------------------------------------ A4 + A5
+static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32, int32_t n, float* fpn0, float* fpn1, float* fpn2,
+                              void* stream);
 extern "C" int ds2_image_encoder_batch(ds2_model* m, const uint16_t* frames_f16, int32_t n, float* fpn0, float* fpn1, float* fpn2,
                                        void* stream) {
+  return image_encoder_impl(m, frames_f16, false, n, fpn0, fpn1, fpn2, stream);
+}
+extern "C" int ds2_image_encoder_f32(ds2_model* m, const float* frames_f32, int32_t n, float* fpn0, float* fpn1, float* fpn2,
+                                     void* stream) {
+  return image_encoder_impl(m, frames_f32, true, n, fpn0, fpn1, fpn2, stream);
+}
+static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32, int32_t n, float* fpn0, float* fpn1, float* fpn2,
+                              void* stream) {
+  const uint16_t* frames_f16 = reinterpret_cast<const uint16_t*>(frames);
   DS2_REQUIRE(m && m->finalized && frames_f16 && fpn0 && fpn1 && fpn2 && n >= 1 && n <= 16, "ds2_image_encoder_batch: bad argument");
+  DeviceGuard _dg(m->device);
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.image_encoder", st);
   const int C0 = m->cfg.embed_dim;
@@ -545,11 +588,15 @@ extern "C" int ds2_image_encoder_batch(ds2_model* m, const uint16_t* frames_f16,
 
   // PatchEmbed (backbones/utils.py:93-96) + pos embed (hieradet.py:273-281), fused as GEMM epilogue
   ALLOC(col, (size_t)n * 65536 * 148);
-  for (int i = 0; i < n; ++i)
-    TRY(launch_im2col_patch(frames_f16 + (size_t)i * 3 * 1024 * 1024, col + (size_t)i * 65536 * 148, 1024, st));
+  for (int i = 0; i < n; ++i) {
+    if (frames_f32)
+      TRY(launch_im2col_patch_f32(reinterpret_cast<const float*>(frames) + (size_t)i * 3 * 1024 * 1024, col + (size_t)i * 65536 * 148, 1024, st));
+    else
+      TRY(launch_im2col_patch(frames_f16 + (size_t)i * 3 * 1024 * 1024, col + (size_t)i * 65536 * 148, 1024, st));
+  }
   ALLOC(x0, (size_t)n * 65536 * C0);
   TRY(gemm(st, n * 65536, C0, 148, col, 148, m->P("@patch_w"), 148, m->P("image_encoder.trunk.patch_embed.proj.bias"), x0, C0,
-           DS2_ACT_NONE, m->P("#pos_embed"), C0, 65536, nullptr, true));
+           DS2_ACT_NONE, m->P("#pos_embed"), C0, 65536, nullptr, true, m));
   const float* x = x0;
   int side = 256;
   const float* stage_out[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -656,6 +703,7 @@ extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const v
                                  int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
                                  float* memory_pos, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && memory && memory_pos, "ds2_bank_assemble: bad argument");
+  DeviceGuard _dg(m->device);
   DS2_REQUIRE(n_mem >= 0 && n_ptr >= 0 && (n_mem == 0 || (feats && tpos_row)) && (n_ptr == 0 || (ptrs && ptr_pos)),
               "ds2_bank_assemble: bad entry tables (n_mem=%d, n_ptr=%d)", n_mem, n_ptr);
   hipStream_t st = (hipStream_t)stream;
@@ -690,10 +738,26 @@ extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const v
 }
 
 // ------------------------------------------------------------------------------------------------ A12
+static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, bool curr_shared, const float* curr_pos,
+                                 bool pos_shared, const float* memory, const float* memory_pos, int32_t Nk, int32_t n_ptr_tok,
+                                 float* out, void* stream);
 extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, const float* memory, const float* memory_pos,
                                     int32_t Nk, int32_t n_ptr_tok, float* out, void* stream) {
+  return memory_attention_impl(m, B, curr, true, nullptr, true, memory, memory_pos, Nk, n_ptr_tok, out, stream);
+}
+extern "C" int ds2_memory_attention_ex(ds2_model* m, int32_t B, const float* curr, int32_t curr_shared, const float* curr_pos,
+                                       int32_t pos_shared, const float* memory, const float* memory_pos, int32_t Nk,
+                                       int32_t n_ptr_tok, float* out, void* stream) {
+  return memory_attention_impl(m, B, curr, curr_shared != 0, curr_pos, pos_shared != 0, memory, memory_pos, Nk, n_ptr_tok, out, stream);
+}
+static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, bool curr_shared, const float* curr_pos,
+                                 bool pos_shared, const float* memory, const float* memory_pos, int32_t Nk, int32_t n_ptr_tok,
+                                 float* out, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && curr && memory && memory_pos && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
               "ds2_memory_attention: bad argument");
+  DeviceGuard _dg(m->device);
+  // the layer-0 self-attention is shared by the B objects only when they all see the same tokens AND positions
+  const bool shared0 = curr_shared && (curr_pos == nullptr || pos_shared);
   DS2_REQUIRE((Nk - n_ptr_tok) % TOK == 0, "ds2_memory_attention: Nk - num_obj_ptr_tokens must be a multiple of 4096");
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_attention", st);
@@ -732,8 +796,17 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     if (no_vlo_skip) vlo_flag = nullptr;
     TRY(vt_split(memory, 64, B, Nk, vt_c, st, Nk - n_ptr_tok, vlo_flag));
   }
-  // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object
-  TRY(launch_add_bcast(curr, 256, m->P("#vision_pos"), 256, 0, 0.1f, x1, 256, TOK, 256, st));
+  // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object in the tracking loop
+  // (curr is the frame's feature, curr_pos the model constant); the general form takes per-object tokens / positions
+  const float* cpos = curr_pos ? curr_pos : m->P("#vision_pos");
+  if (shared0) {
+    TRY(launch_add_bcast(curr, 256, cpos, 256, 0, 0.1f, x1, 256, TOK, 256, st));
+  } else {
+    for (int b = 0; b < B; ++b)
+      TRY(launch_add_bcast(curr + (curr_shared ? 0 : (size_t)b * TOK * 256), 256,
+                           cpos + ((curr_pos && !pos_shared) ? (size_t)b * TOK * 256 : 0), 256, 0, 0.1f, x + (size_t)b * TOK * 256, 256,
+                           TOK, 256, st));
+  }
   // k input of the cross attention: memory + memory_pos (pos_enc_at_cross_attn_keys, memory_attention.py:79)
   if (split) {   // emitted directly as the k_proj GEMM's operand planes
     ds2_model::ActPlanes kp;
@@ -749,8 +822,9 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
     const size_t layer_mark = m->ws_top;   // operand planes emitted inside a layer die with it
     m->act_planes.erase(a);
     // -- self attention (RoPE on q,k).  Layer 0 sees the same input for all B objects: computed once.
-    const int Bs = (l == 0) ? 1 : B;
-    const float* xin = (l == 0) ? x1 : x;
+    const bool once = (l == 0) && shared0;
+    const int Bs = once ? 1 : B;
+    const float* xin = once ? x1 : x;
     TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
     TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
@@ -778,7 +852,7 @@ extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, 
       ProfScope _p("kernel.self_attention", st);
       TRY(launch_attention(sa, st));
     }
-    if (l == 0) {
+    if (once) {
       TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
       for (int b = 0; b < B; ++b)
         DS2_CHECK_HIP(hipMemcpyAsync(x + (size_t)b * TOK * 256, x1, (size_t)TOK * 256 * 4, hipMemcpyDeviceToDevice, st));
@@ -904,6 +978,7 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
                                   float* low_res, float* obj_ptr, float* obj_logits, float* ious, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && pix_feat && fpn0 && fpn1 && low_res && obj_ptr && obj_logits,
               "ds2_sam_heads: bad argument");
+  DeviceGuard _dg(m->device);
   DS2_REQUIRE(P >= 0 && P <= 8 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.sam_heads", st);
@@ -993,11 +1068,11 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   TRY(layernorm(m, st, tr + ".norm_final_attn", tmpq, hs, BT, 256, 1e-5f));
   // upscaling + hypernetworks (mask_decoder.py:216-235)
   float* g1 = tmpk;  // [rows,256]
-  TRY(gemm(st, rows, 256, 256, keys, 256, m->P("@up1_w"), 256, m->P("@up1_b"), g1, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
+  TRY(gemm(st, rows, 256, 256, keys, 256, m->P("@up1_w"), 256, m->P("@up1_b"), g1, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(u1, (size_t)B * 16384 * 64);
   TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st));
   ALLOC(g2, (size_t)B * 16384 * 128);
-  TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
+  TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(hyper, (size_t)B * 128);
   for (int i = 0; i < 4; ++i)
     TRY(mlp3(m, st, md + ".output_hypernetworks_mlps." + std::to_string(i), B, hs + (2 + i) * 256, T * 256, 256, 32,
@@ -1018,9 +1093,28 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
 }
 
 // ------------------------------------------------------------------------------------------------ A13
+// mask source: low-res logits (upsampled + sigmoid|binarize, *scale+bias: the tracking loop) or full-resolution masks
+// (optionally through a plain sigmoid: MemoryEncoder.forward's own contract); pix_feat shared by the objects or one per
+// object; output bf16 with no_obj_embed_spatial (tracking loop) or the module's raw fp32 features.
+static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool pix_shared, const float* low_res,
+                               const float* masks_hi, int hi_sigmoid, const float* obj_logits, int32_t binarize,
+                               uint16_t* maskmem_bf16, float* out_f32, void* stream);
 extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, const float* low_res, const float* obj_logits,
                                   int32_t binarize, uint16_t* maskmem_bf16, void* stream) {
-  DS2_REQUIRE(m && m->finalized && B > 0 && fpn2 && low_res && obj_logits && maskmem_bf16, "ds2_memory_encoder: bad argument");
+  DS2_REQUIRE(low_res && obj_logits && maskmem_bf16, "ds2_memory_encoder: bad argument");
+  return memory_encoder_impl(m, B, fpn2, true, low_res, nullptr, 0, obj_logits, binarize, maskmem_bf16, nullptr, stream);
+}
+extern "C" int ds2_memory_encoder_ex(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_shared, const float* masks,
+                                     int32_t skip_mask_sigmoid, float* vision_features, void* stream) {
+  DS2_REQUIRE(masks && vision_features, "ds2_memory_encoder_ex: bad argument");
+  return memory_encoder_impl(m, B, pix_feat, pix_shared != 0, nullptr, masks, skip_mask_sigmoid ? 0 : 1, nullptr, 0, nullptr,
+                             vision_features, stream);
+}
+static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool pix_shared, const float* low_res,
+                               const float* masks_hi, int hi_sigmoid, const float* obj_logits, int32_t binarize,
+                               uint16_t* maskmem_bf16, float* out_f32, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && fpn2, "ds2_memory_encoder: bad argument");
+  DeviceGuard _dg(m->device);
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_encoder", st);
   const int rows = B * TOK;
@@ -1028,8 +1122,14 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   TRY(m->require(need, st));
   const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
   ALLOC(high, (size_t)B * 1048576);
-  TRY(launch_mask_upsample_transform(low_res, high, B, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc,
-                                     m->cfg.sigmoid_bias_for_mem_enc, st));
+  if (masks_hi && !hi_sigmoid) {
+    DS2_CHECK_HIP(hipMemcpyAsync(high, masks_hi, (size_t)B * 1048576 * 4, hipMemcpyDeviceToDevice, st));
+  } else if (masks_hi) {   // identity resample + sigmoid (memory_encoder.py:166-167)
+    TRY(launch_mask_upsample_transform(masks_hi, high, B, 1024, 1024, 0, 1.f, 0.f, st));
+  } else {
+    TRY(launch_mask_upsample_transform(low_res, high, B, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc,
+                                       m->cfg.sigmoid_bias_for_mem_enc, st));
+  }
   ALLOC(c1, (size_t)B * 262144 * 4);
   TRY(launch_conv3x3s2_small(high, m->P(ds + "0.weight"), m->P(ds + "0.bias"), m->P(ds + "1.weight"), m->P(ds + "1.bias"), c1,
                              B, 1024, 1, 4, st));
@@ -1039,20 +1139,21 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
   ALLOC(col3, (size_t)B * 16384 * 144);
   TRY(launch_im2col3x3s2(c2, col3, B, 256, 16, st));
   ALLOC(g3, (size_t)B * 16384 * 64);
-  TRY(gemm(st, B * 16384, 64, 144, col3, 144, m->P("@mds6_w"), 144, m->P(ds + "6.bias"), g3, 64, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
+  TRY(gemm(st, B * 16384, 64, 144, col3, 144, m->P("@mds6_w"), 144, m->P(ds + "6.bias"), g3, 64, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(c3, (size_t)B * 16384 * 64);
   TRY(layernorm(m, st, ds + "7", g3, c3, B * 16384, 64, 1e-6f, DS2_ACT_GELU));
   ALLOC(col4, (size_t)rows * 576);
   TRY(launch_im2col3x3s2(c3, col4, B, 128, 64, st));
   ALLOC(g4, (size_t)rows * 256);
-  TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true));
+  TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(c4, (size_t)rows * 256);
   TRY(layernorm(m, st, ds + "10", g4, c4, rows, 256, 1e-6f, DS2_ACT_GELU, true));   // consumer: encoder.12 GEMM
   // x = pix_feat_proj(pix_feat) + mask_downsampler(masks)   (memory_encoder.py:172-175); pix_feat is shared by all objects
-  ALLOC(pf, (size_t)TOK * 256);
-  TRY(linear(m, st, me + ".pix_feat_proj", TOK, 256, 256, fpn2, 256, pf, 256));
+  const int pf_rows = pix_shared ? TOK : rows;
+  ALLOC(pf, (size_t)pf_rows * 256);
+  TRY(linear(m, st, me + ".pix_feat_proj", pf_rows, 256, 256, fpn2, 256, pf, 256));
   ALLOC(x, (size_t)rows * 256);
-  TRY(linear(m, st, ds + "12", rows, 256, 256, c4, 256, x, 256, DS2_ACT_NONE, pf, 256, TOK));
+  TRY(linear(m, st, ds + "12", rows, 256, 256, c4, 256, x, 256, DS2_ACT_NONE, pf, 256, pix_shared ? TOK : 0));
   // Fuser: 2 x CXBlock (memory_encoder.py:104-117)
   ALLOC(d, (size_t)rows * 256);
   ALLOC(t, (size_t)rows * 256);
@@ -1064,9 +1165,13 @@ extern "C" int ds2_memory_encoder(ds2_model* m, int32_t B, const float* fpn2, co
     TRY(linear(m, st, p + ".pwconv1", rows, 1024, 256, t, 256, h, 1024, DS2_ACT_GELU, nullptr, 0, 0, nullptr, true));
     TRY(linear(m, st, p + ".pwconv2", rows, 256, 1024, h, 1024, x, 256, DS2_ACT_NONE, x, 256, 0, m->P(p + ".gamma")));
   }
-  ALLOC(o, (size_t)rows * 64);
-  TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, o, 64));
-  TRY(launch_memfeat_finish(o, obj_logits, m->P("no_obj_embed_spatial"), maskmem_bf16, B, TOK, 64, st));
+  if (out_f32) {      // MemoryEncoder.forward's own output (no no_obj_embed_spatial, no bf16 storage rounding)
+    TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, out_f32, 64));
+  } else {
+    ALLOC(o, (size_t)rows * 64);
+    TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, o, 64));
+    TRY(launch_memfeat_finish(o, obj_logits, m->P("no_obj_embed_spatial"), maskmem_bf16, B, TOK, 64, st));
+  }
   CHECK_PARAMS();
   return DS2_OK;
 }
@@ -1081,6 +1186,7 @@ extern "C" int ds2_resize_aa(const float* in, int32_t B, int32_t Hin, int32_t Wi
 extern "C" int ds2_mask_prompt_prepare(ds2_model* m, int32_t B, const float* mask, float* mask_ds, float* obj_logits,
                                        int32_t* work, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && mask && mask_ds && obj_logits && work, "ds2_mask_prompt_prepare: bad argument");
+  DeviceGuard _dg(m->device);
   const float* w = m->P("mask_downsample.weight");
   const float* b = m->P("mask_downsample.bias");
   CHECK_PARAMS();
@@ -1089,6 +1195,7 @@ extern "C" int ds2_mask_prompt_prepare(ds2_model* m, int32_t B, const float* mas
 
 extern "C" int ds2_obj_ptr_gate(ds2_model* m, int32_t B, float* obj_ptr, const float* obj_logits, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && obj_ptr && obj_logits, "ds2_obj_ptr_gate: bad argument");
+  DeviceGuard _dg(m->device);
   const float* no = m->P("no_obj_ptr");
   CHECK_PARAMS();
   return launch_ptr_gate(obj_ptr, obj_logits, no, B, 256, (hipStream_t)stream);

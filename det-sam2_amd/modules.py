@@ -1,0 +1,159 @@
+"""Module-level drop-ins: ``nn.Module``s with the SIGNATURES AND LAYOUTS of the reference's Hydra ``_target_`` modules
+(SURVEY.md 8b "Module-level signatures a replacement must honour"), each backed by one C-ABI stage of libdetsam2_hip.
+
+    HipImageEncoder   ~ SAM2Base.forward_image            (sam2/modeling/sam2_base.py:450-461; backbones/image_encoder.py:30-43)
+    HipMemoryAttention~ MemoryAttention.forward           (sam2/modeling/memory_attention.py:119-176)
+    HipMemoryEncoder  ~ MemoryEncoder.forward             (sam2/modeling/memory_encoder.py:158-181)
+    HipSamHeads       ~ SAM2Base._forward_sam_heads       (sam2/modeling/sam2_base.py:254-397) = PromptEncoder + MaskDecoder
+
+They take and return the reference's tensors - ``[B,C,H,W]`` feature maps, ``(HW,B,C)`` token sequences - and convert to
+the library's token-major layout at the boundary (permute + contiguous: PyTorch is plumbing here, every number comes
+from the HIP kernels).  ``build_modules(cfg, state_dict)`` gives all four over ONE ``ds2_model``; a maintainer of the
+reference assigns them over ``SAM2Base.image_encoder / memory_attention / memory_encoder``.
+``tests/test_hip_modules.py`` feeds the seeded inputs of ``oracle/make_goldens.py:l1_inputs`` and compares with the
+reference's own outputs (tests/golden/l1_*.npz) - HIP against the reference fixture, no oracle in between.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _capi
+from .constants import sine_pos_2d
+from .hip_model import TOK, HipSam2, _p
+
+
+def _tok(x):          # [B,C,H,W] -> token-major [B,H*W,C]
+    return x.flatten(2).transpose(1, 2).contiguous()
+
+
+def _map(x, h, w):    # token-major [B,H*W,C] -> [B,C,H,W]
+    return x.transpose(1, 2).reshape(x.shape[0], x.shape[2], h, w)
+
+
+class HipImageEncoder(nn.Module):
+    """``forward(img_batch fp32 [N,3,1024,1024]) -> {"vision_features", "vision_pos_enc": [3], "backbone_fpn": [3]}`` with
+    conv_s0 / conv_s1 already applied to levels 0 / 1, exactly what ``SAM2Base.forward_image`` returns."""
+
+    def __init__(self, hip: HipSam2):
+        super().__init__()
+        self.hip = hip
+        self._pos = None
+
+    def _pos_enc(self, n):
+        if self._pos is None:   # PositionEmbeddingSine is a constant of the geometry (position_encoding.py:79-112)
+            self._pos = [_map(torch.from_numpy(sine_pos_2d(256, s, s)).to(self.hip.device)[None], s, s) for s in (256, 128, 64)]
+        return [p.expand(n, -1, -1, -1) for p in self._pos]
+
+    @torch.inference_mode()
+    def forward(self, img_batch):
+        h = self.hip
+        x = img_batch.to(h.device, torch.float32).contiguous()
+        n = x.shape[0]
+        assert tuple(x.shape[1:]) == (3, h.cfg.image_size, h.cfg.image_size)
+        f0, f1, f2 = h._empty(n, 65536, 32), h._empty(n, 16384, 64), h._empty(n, TOK, 256)
+        _capi.check(h.lib.ds2_image_encoder_f32(h.h, _p(x), n, _p(f0), _p(f1), _p(f2), h._stream()), "ds2_image_encoder_f32")
+        fpn = [_map(f0, 256, 256), _map(f1, 128, 128), _map(f2, 64, 64)]
+        return {"vision_features": fpn[-1], "vision_pos_enc": self._pos_enc(n), "backbone_fpn": fpn}
+
+
+class HipMemoryAttention(nn.Module):
+    """``forward(curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0) -> (HW,B,C)`` (sequence-first, as the
+    reference passes them: sam2_base.py:676-683).  ``curr`` / ``curr_pos`` may be single-element lists."""
+
+    def __init__(self, hip: HipSam2):
+        super().__init__()
+        self.hip = hip
+        self.d_model = hip.cfg.d_model          # read by SAM2Base.__init__ (sam2_base.py:121)
+
+    @torch.inference_mode()
+    def forward(self, curr, memory, curr_pos=None, memory_pos=None, num_obj_ptr_tokens=0):
+        h = self.hip
+        if isinstance(curr, (list, tuple)):
+            assert len(curr) == 1
+            curr, curr_pos = curr[0], (curr_pos[0] if curr_pos is not None else None)
+        assert curr.shape[0] == TOK and curr.shape[2] == 256 and memory.shape[2] == 64
+        B, nk = curr.shape[1], memory.shape[0]
+        c = curr.to(h.device, torch.float32).transpose(0, 1).contiguous()                 # [B,4096,256]
+        cp = None if curr_pos is None else curr_pos.to(h.device, torch.float32).transpose(0, 1).contiguous()
+        mem = memory.to(h.device, torch.float32).transpose(0, 1).contiguous()             # [B,Nk,64]
+        mp = (torch.zeros_like(mem) if memory_pos is None else
+              memory_pos.to(h.device, torch.float32).transpose(0, 1).contiguous())
+        out = h._empty(B, TOK, 256)
+        zero_pos = h._empty(TOK, 256).zero_() if cp is None else None                     # pos_enc_at_input with no positions
+        _capi.check(h.lib.ds2_memory_attention_ex(h.h, B, _p(c), 0, _p(cp if cp is not None else zero_pos),
+                                                  0 if cp is not None else 1, _p(mem), _p(mp), nk, int(num_obj_ptr_tokens),
+                                                  _p(out), h._stream()), "ds2_memory_attention_ex")
+        return out.transpose(0, 1)
+
+
+class HipMemoryEncoder(nn.Module):
+    """``forward(pix_feat [B,256,64,64], masks [B,1,1024,1024], skip_mask_sigmoid=False) ->
+    {"vision_features": [B,64,64,64], "vision_pos_enc": [pos]}``."""
+
+    def __init__(self, hip: HipSam2):
+        super().__init__()
+        self.hip = hip
+        self._pos = None
+
+    @torch.inference_mode()
+    def forward(self, pix_feat, masks, skip_mask_sigmoid=False):
+        h = self.hip
+        B = pix_feat.shape[0]
+        pf = _tok(pix_feat.to(h.device, torch.float32))
+        m = masks.to(h.device, torch.float32).reshape(B, h.cfg.image_size, h.cfg.image_size).contiguous()
+        out = h._empty(B, TOK, 64)
+        _capi.check(h.lib.ds2_memory_encoder_ex(h.h, B, _p(pf), 0, _p(m), int(bool(skip_mask_sigmoid)), _p(out), h._stream()),
+                    "ds2_memory_encoder_ex")
+        if self._pos is None:
+            self._pos = _map(torch.from_numpy(sine_pos_2d(64, 64, 64)).to(h.device)[None], 64, 64)
+        return {"vision_features": _map(out, 64, 64), "vision_pos_enc": [self._pos.expand(B, -1, -1, -1)]}
+
+
+class HipSamHeads(nn.Module):
+    """``forward(backbone_features [B,256,64,64], point_inputs=None, mask_inputs=None, high_res_features=None,
+    multimask_output=False)`` -> the 7-tuple of ``_forward_sam_heads``.  The kernels select the output mask on the GPU, so
+    the two multimask entries (low_res_multimasks, high_res_multimasks) hold the SELECTED mask only."""
+
+    def __init__(self, hip: HipSam2):
+        super().__init__()
+        self.hip = hip
+
+    @torch.inference_mode()
+    def forward(self, backbone_features, point_inputs=None, mask_inputs=None, high_res_features=None, multimask_output=False):
+        h = self.hip
+        B = backbone_features.shape[0]
+        pix = _tok(backbone_features.to(h.device, torch.float32))
+        assert high_res_features is not None and len(high_res_features) == 2, "use_high_res_features_in_sam is on in SAM 2.1"
+        # the stage shares the frame's high-res features between objects (they are .expand()-ed in the reference)
+        f0 = _tok(high_res_features[0].to(h.device, torch.float32))
+        f1 = _tok(high_res_features[1].to(h.device, torch.float32))
+        coords = labels = None
+        if point_inputs is not None:
+            coords = point_inputs["point_coords"].to(h.device, torch.float32)
+            labels = point_inputs["point_labels"].to(h.device, torch.int32)
+        mi = None
+        if mask_inputs is not None:
+            mi = mask_inputs.to(h.device, torch.float32)
+            if tuple(mi.shape[-2:]) != (256, 256):     # sam2_base.py:305-314
+                mi = h.resize_aa(mi.reshape(B, *mi.shape[-2:]).contiguous(), 256, 256)
+            mi = mi.reshape(B, 256, 256)
+        lows, ptrs, objs, ious = [], [], [], []
+        for b in range(B):        # per-object high-res features: one call per object (the tracking loop passes shared ones)
+            low, ptr, obj, iou = h.sam_heads(1, pix[b:b + 1], f0[b], f1[b], None if coords is None else coords[b:b + 1],
+                                             None if labels is None else labels[b:b + 1], bool(multimask_output),
+                                             mask_inputs=None if mi is None else mi[b:b + 1])
+            lows.append(low), ptrs.append(ptr), objs.append(obj), ious.append(iou)
+        low = torch.cat(lows)[:, None]
+        high, _ = h.mask_output(low[:, 0].contiguous(), h.cfg.image_size, h.cfg.image_size, want_logits=True, want_packed=False)
+        obj = torch.cat(objs)[:, None]
+        return low, high, torch.cat(ious)[:, None], low, high, torch.cat(ptrs), obj
+
+
+def build_modules(cfg, state_dict, device="cuda:0", max_batch=16):
+    """-> dict(image_encoder, memory_attention, memory_encoder, sam_heads, hip) over one shared ``ds2_model``."""
+    hip = HipSam2(cfg, state_dict, device, max_batch)
+    return {"hip": hip, "image_encoder": HipImageEncoder(hip), "memory_attention": HipMemoryAttention(hip),
+            "memory_encoder": HipMemoryEncoder(hip), "sam_heads": HipSamHeads(hip)}

@@ -137,6 +137,23 @@ int ds2_connected_components(const uint8_t* mask, int32_t N, int32_t H, int32_t 
  * work: int32 scratch of 3*N*H*W elements.  max_area <= 0 is an error (misc.py:371). */
 int ds2_fill_holes(float* logits, int32_t N, int32_t H, int32_t W, int32_t max_area, int32_t* work, void* stream);
 
+/* ---- module-level forms (det_sam2_amd/modules.py: nn.Modules with the reference's signatures).  Same
+ * kernels as the stage entry points above, without the tracking loop's sharing assumptions:
+ *  ds2_image_encoder_f32: forward_image on fp32 frames [n,3,S,S] (the reference feeds `.float()`-ed frames,
+ *    sam2_video_predictor.py:1186).
+ *  ds2_memory_attention_ex: MemoryAttention.forward (memory_attention.py:119-176) with per-object tokens curr
+ *    [B,4096,256] (curr_shared == 0) and an explicit curr_pos ([B,4096,256], or [4096,256] with pos_shared != 0; NULL =
+ *    the model's "#vision_pos").
+ *  ds2_memory_encoder_ex: MemoryEncoder.forward (memory_encoder.py:158-181): pix_feat [B,4096,256] (or shared
+ *    [4096,256]), masks fp32 [B,1024,1024] (sigmoid applied unless skip_mask_sigmoid) -> vision_features fp32
+ *    [B,4096,64] (token-major; no no_obj_embed_spatial, no bf16 rounding - those belong to _encode_new_memory). */
+int ds2_image_encoder_f32(ds2_model* m, const float* frames_f32, int32_t n, float* fpn0, float* fpn1, float* fpn2, void* stream);
+int ds2_memory_attention_ex(ds2_model* m, int32_t B, const float* curr, int32_t curr_shared, const float* curr_pos,
+                            int32_t pos_shared, const float* memory, const float* memory_pos, int32_t Nk,
+                            int32_t num_obj_ptr_tokens, float* out, void* stream);
+int ds2_memory_encoder_ex(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_shared, const float* masks,
+                          int32_t skip_mask_sigmoid, float* vision_features, void* stream);
+
 /* ---- F3: mask prompts = add_new_mask (sam2/sam2_video_predictor.py:527-616) -> SAM2Base._use_mask_as_output
  * (sam2/modeling/sam2_base.py:399-448).  Three small ops the host composes with ds2_sam_heads_mask:
  *  ds2_resize_aa: F.interpolate(mode="bilinear", antialias=True, align_corners=False) of fp32 [B,Hin,Win] ->

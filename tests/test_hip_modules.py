@@ -1,0 +1,70 @@
+"""Module-level boundary (det_sam2_amd.modules: nn.Modules with the reference's signatures and layouts) against the
+REFERENCE'S OWN outputs: the seeded inputs of oracle/make_goldens.py:l1_inputs go in, tests/golden/l1_<config>.npz (written
+by the reference modules on those inputs) is the expectation - no oracle in between.  All four SAM 2.1 configs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import record
+from det_sam2_amd.config import resolve_config
+from det_sam2_amd.weights import synthetic_state_dict
+from oracle.make_goldens import l1_inputs
+
+pytestmark = pytest.mark.gpu
+CONFIGS = ["sam2.1_hiera_t", "sam2.1_hiera_s", "sam2.1_hiera_b+", "sam2.1_hiera_l"]
+TOL = {"fp32": 2e-5, "bf16x3": 1e-3}
+
+
+def _rel(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+
+
+@pytest.fixture(scope="module", params=CONFIGS)
+def mods(request):
+    from det_sam2_amd.modules import build_modules
+    cfg = resolve_config(request.param)
+    return request.param, build_modules(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=2)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_modules_match_reference_fixtures(mods, prec, golden_dir):
+    name, m = mods
+    if prec == "fp32" and name not in ("sam2.1_hiera_t", "sam2.1_hiera_l"):
+        pytest.skip("fp32 mode is covered on the smallest and the largest config")
+    m["hip"].set_precision(prec)
+    g = np.load(os.path.join(golden_dir, f"l1_{name}.npz"))
+    x = l1_inputs()
+    tol = TOL[prec]
+    errs = {}
+    # ---- SAM2Base.forward_image
+    out = m["image_encoder"](x["img"])
+    assert set(out) == {"vision_features", "vision_pos_enc", "backbone_fpn"}
+    assert [tuple(f.shape) for f in out["backbone_fpn"]] == [(1, 32, 256, 256), (1, 64, 128, 128), (1, 256, 64, 64)]
+    for i, f in enumerate(out["backbone_fpn"]):
+        errs[f"fpn{i}"] = _rel(f[0, ::4, ::8, ::8].cpu(), g[f"fpn{i}"])
+    errs["pos2"] = _rel(out["vision_pos_enc"][2][0, ::8, ::8, ::8].cpu(), g["pos2"])
+    # ---- MemoryAttention.forward  (sequence-first tensors, per-object tokens, explicit positions)
+    ma = m["memory_attention"](curr=[x["curr"]], curr_pos=[x["curr_pos"]], memory=x["mem"], memory_pos=x["mem_pos"],
+                               num_obj_ptr_tokens=8)
+    assert tuple(ma.shape) == (4096, 2, 256)
+    errs["memattn"] = _rel(ma[::32, :, ::4].cpu(), g["memattn"])
+    # ---- MemoryEncoder.forward
+    me = m["memory_encoder"](x["pix"], x["masks"], skip_mask_sigmoid=True)
+    assert tuple(me["vision_features"].shape) == (2, 64, 64, 64)
+    errs["memenc"] = _rel(me["vision_features"][:, ::2, ::4, ::4].cpu(), g["memenc"])
+    errs["memenc_pos"] = _rel(me["vision_pos_enc"][0][0, :, ::8, ::8].cpu(), g["memenc_pos"])
+    # ---- SAM2Base._forward_sam_heads (prompt encoder + mask decoder + selection + pointer)
+    fs = m["sam_heads"](backbone_features=x["emb"], point_inputs=None, mask_inputs=None, high_res_features=[x["hr0"], x["hr1"]],
+                        multimask_output=True)
+    errs["heads_low"] = _rel(fs[3][:, :, ::4, ::4].cpu(), g["heads_low"])
+    errs["heads_high"] = _rel(fs[4][:, :, ::16, ::16].cpu(), g["heads_high"])
+    errs["heads_ptr"] = _rel(fs[5].cpu(), g["heads_ptr"])
+    errs["heads_obj"] = _rel(fs[6].cpu(), g["heads_obj"])
+    record("modules_vs_reference", config=name, prec=prec, **errs)
+    for k, e in errs.items():
+        bound = 1e-6 if k in ("pos2", "memenc_pos") else (tol * (3 if k.startswith("fpn") or k.startswith("heads") else 1))
+        assert e <= bound, (name, prec, k, e, errs)
