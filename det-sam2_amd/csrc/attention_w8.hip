@@ -226,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
+        if (DS2_EXP_QK2) break;     // precision experiment only: drop the k_lo . q_hi term
         s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[g][ks], s0[g], 0, 0, 0);
         s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[g][ks], s1[g], 0, 0, 0);
       }

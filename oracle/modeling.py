@@ -3,8 +3,9 @@ modules of the Det-SAM2 hot
 
 Written functionally over a flat ``state_dict`` (``sd``) instead of nn.Modules.  Each
 function cites the reference ``file:line`` it restates.  Pinned against the reference
-itself (imported in the build container through ``oracle/_ref_shims.py``) by
-``tests/test_oracle_vs_reference.py`` and against the committed goldens in ``tests/golden``.
+itself: ``oracle/make_goldens.py`` imports the reference in the build container (through
+``oracle/_ref_shims.py``) and commits its outputs under ``tests/golden``; ``tests/test_oracle_golden.py``
+compares this file with them (all four configs).
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg import this.
 """

@@ -13,6 +13,8 @@ def record(name, **kw):
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "metrics.jsonl"), "a") as f:
             row = {k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in kw.items()}
+            if os.environ.get("DS2_VARIANT"):
+                row["variant"] = os.environ["DS2_VARIANT"]
             f.write(json.dumps({"test": name, **row}) + "\n")
     except Exception:
         pass

@@ -1,4 +1,12 @@
-// bf16x3 GEMM over pre-split operands: 256x256 block tile, 8 waves (wave tile 128x64), TWO-stage LDS-DMA pipeline with
+# generate gemm_split_d256.hip from the r3 kernel's verified pieces (epilogue identical to k_gemm_split256<4>)
+src256 = open('/root/repo/det-sam2_amd/csrc/gemm_split256.hip').read()
+ep_start = src256.index('  // ---- epilogue: each wave parks one 32 x 64 slab')
+ep_end = src256.index('}  // namespace')
+epilogue = src256[ep_start:ep_end]
+epilogue = epilogue.replace('MF', '4').replace('BM2', 'DBM')
+# r3-style tail: drain DMA before LDS reuse
+epilogue = epilogue.replace('  __syncthreads();\n  constexpr int EPLD = 68;', '  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (redundant) tail DMA / touches before LDS is reused\n  __syncthreads();\n  constexpr int EPLD = 68;', 1)
+head = r'''// bf16x3 GEMM over pre-split operands: 256x256 block tile, 8 waves (wave tile 128x64), TWO-stage LDS-DMA pipeline with
 // double-buffered operand fragments and ONE barrier per 32-deep K tile.
 //
 // Why (round 2): tools/ubench/glds_path.hip measures 46-57 B/clk/CU through the L2 -> LDS path (global_load_lds and
@@ -199,90 +207,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   }
   asm volatile("" ::"v"(junk));
 
-  // ---- epilogue: each wave parks one 32 x 64 slab of its tile in LDS at a time and re-reads it row-wise (4 consecutive
-  // columns per lane: 16-byte bias/residual loads and fp32 stores, 8-byte plane stores); same arithmetic as
-  // k_gemm_split's epilogue.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (redundant) tail DMA / touches before LDS is reused
-  __syncthreads();
-  constexpr int EPLD = 68;
-  float* ep = reinterpret_cast<float*>(lds) + wave * (32 * EPLD);
-  const int c4 = lane & 15, r0 = lane >> 4;
-  const int n = n0 + wn * 64 + c4 * 4;
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
-  {
-    float* bp = reinterpret_cast<float*>(&bias4);
-    float* gp = reinterpret_cast<float*>(&gam4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (g.bias && n + j < g.N) bp[j] = g.bias[n + j];
-      if (g.gamma && n + j < g.N) gp[j] = g.gamma[n + j];
-    }
-  }
-  const bool vec_ok = (n + 3 < g.N);
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ep[mfma32_row(e, half) * EPLD + tn * 32 + l31] = acc[tm][tn][e];
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < 8; ++it) {
-      const int rr = it * 4 + r0;
-      const int m = m0 + wm * (4 * 32) + tm * 32 + rr;
-      if (m >= g.M) continue;
-      const float4 a4 = *reinterpret_cast<const float4*>(&ep[rr * EPLD + c4 * 4]);
-      float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
-                    ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
-      if (g.R) {
-        const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
-        const float* rp = g.R + (size_t)rm * g.ldr + n;
-        if (vec_ok && (g.ldr & 3) == 0) {
-          const float4 r4 = *reinterpret_cast<const float4*>(rp);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (n + j < g.N) v[j] += rp[j];
-        }
-      }
-      if (g.C) {
-        float* cp = g.C + (size_t)m * g.ldc + n;
-        if (vec_ok && (g.ldc & 3) == 0) {
-          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (n + j < g.N) cp[j] = v[j];
-        }
-      }
-      if (g.C_hi && n < g.ldcp) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n + j >= g.N) v[j] = 0.f;
-        if (g.rope_cis) {   // apply_rotary_enc (position_encoding.py:196-220) on the complex pairs (n, n+1), (n+2, n+3)
-          const int t = m % g.rope_L;
-          if (t < g.rope_n) {
-            const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
-            const float a0 = v[0] * c.x - v[1] * c.y, a1 = v[0] * c.y + v[1] * c.x;
-            const float a2 = v[2] * c.z - v[3] * c.w, a3 = v[2] * c.w + v[3] * c.z;
-            v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
-          }
-        }
-        uint2 h, l;
-        h.x = cvt_pk_bf16(v[0], v[1]);
-        h.y = cvt_pk_bf16(v[2], v[3]);
-        l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
-        l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
-        *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
-        *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-}  // namespace
+'''
+tail = r'''}  // namespace
 
 int launch_gemm_split_d256(const GemmSplitArgs& g, hipStream_t st) {
   const int ncols = g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N;
@@ -291,3 +217,5 @@ int launch_gemm_split_d256(const GemmSplitArgs& g, hipStream_t st) {
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
+'''
+open('/root/repo/det-sam2_amd/csrc/gemm_split_d256.hip','w').write(head + epilogue + tail)

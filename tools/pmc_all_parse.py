@@ -1,5 +1,6 @@
 #!/usr/bin/env python
 """Per-(kernel, grid) means of the PMC counters of one rocprofv3 pass (rocpd sqlite)."""
+import re
 import sqlite3
 import sys
 from collections import defaultdict
@@ -19,7 +20,8 @@ cnt = defaultdict(int)
 dur = defaultdict(float)
 for did, vals in per.items():
     kn, grid, du = meta[did]
-    key = (kn.split("(")[0][-60:], grid)
+    mo = re.search(r"(k_\w+(?:<[^>]*>)?|__amd_\w+|at::native::\w+)", kn)
+    key = ((mo.group(1) if mo else kn)[:60], grid)
     cnt[key] += 1
     dur[key] += du
     for cn, v in vals.items():
