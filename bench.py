@@ -33,7 +33,11 @@ PREFILL = 15  # tracked frames needed before the 7-frame bank + 16 pointers are 
 # extra frames tracked AFTER the timed region with one HIP-event bracket per GEMM (roofline_gemm): one whole encoder batch
 GEMM_PROBE = int(os.environ.get("DS2_ENCODE_BATCH", "10"))
 # MI355X_MICROARCH.md dense MFMA peaks: fp32 (v_mfma_f32_32x32x2_f32) and bf16 (v_mfma_f32_*_bf16)
-PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0}
+PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3k": 2500.0}
+DTYPE = {"fp32": "f32",
+         "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
+         "bf16x3k": "bf16x3k (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product - 2 for the memory-attention scores, "
+                    "whose keys are one bf16 plane; fp32 accumulate/softmax/storage)"}
 
 
 def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
@@ -42,9 +46,12 @@ def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
     return 2.0 * B * tokens * Nk * (d + dv)
 
 
-def cross_attention_bytes(B, Nk, tokens=4096, d=256, dv=64):
-    """Algorithmic HBM bytes of one cross-attention launch in bf16x3 mode: Q fp32 + K planes (2 x bf16) + V^T planes
-    (2 x bf16) read once, output planes written once."""
+def cross_attention_bytes(B, Nk, tokens=4096, d=256, dv=64, precision="bf16x3", n_ptr_tok=64):
+    """Algorithmic HBM bytes of one cross-attention launch: Q fp32 + K planes + V^T planes read once, output planes
+    written once.  bf16x3: K and V^T as two bf16 planes each; bf16x3k: K as one plane, and the V^T lo plane only for the
+    pointer tokens (the frame tokens are bf16 storage: their lo plane is zero and is not staged)."""
+    if precision == "bf16x3k":
+        return B * (4.0 * tokens * d + 2.0 * Nk * d + 2.0 * Nk * dv + 2.0 * n_ptr_tok * dv + 4.0 * tokens * dv)
     return 4.0 * B * (tokens * d + Nk * d + Nk * dv + tokens * dv)
 
 
@@ -52,8 +59,8 @@ def pmc_traffic(B, nk, precision):
     """HBM bytes per cross-attention launch from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE, separate runs of this same bench command; PMC cannot be collected from inside the
     timed run).  None if the file does not match this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_cross_attention.json")
-    if precision != "bf16x3" or B != 16 or nk != 28736 or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", {"bf16x3": "r01_pmc_cross_attention.json", "bf16x3k": "r02_pmc_cross_attention.json"}.get(precision, "-"))
+    if B != 16 or nk != 28736 or not os.path.exists(path):
         return None
     with open(path) as f:
         return float(json.load(f)["traffic_bytes_per_launch"])
@@ -218,7 +225,7 @@ def bench_sharded(a, pred, cfg, world, rank, dev):
             "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
             "value": total_tracked / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
+            "dtype": DTYPE[a.precision],
             "data": "synthetic",
             "config": {"workload": f"{cfg.name}, ONE stream of 1024x1024 frames, {B} objects, propagate passes sharded over {world} GPUs "
                                    f"(pass k -> rank k mod {world}); Det-SAM2 schedule scaled to buffer/detect {b}, track/keep {K}; one timed round "
@@ -252,7 +259,7 @@ def main():
     ap.add_argument("--model", default="sam2.1_hiera_l")
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16x3k", choices=["fp32", "bf16x3", "bf16x3k"])
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: N independent streams, one per GPU (BASELINE config 5) instead of ONE stream sharded by pass (config 4)")
     a = ap.parse_args()
@@ -353,7 +360,7 @@ def main():
             "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
+            "dtype": DTYPE[a.precision],
             "data": "synthetic",
             "config": {"workload": f"{cfg.name} propagate_in_video, {B} objects, 1024x1024 uniform-noise frames, "
                                    f"7-frame memory bank + 16 object pointers (Nk={nk}), synthetic checkpoint seed 0, "
@@ -367,10 +374,11 @@ def main():
                          "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
                          "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision],
                          "traffic": pmc_traffic(B, nk, a.precision), "traffic_unit": "bytes/launch",
-                         "algorithmic_bytes": cross_attention_bytes(B, nk),
+                         "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
                          "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
                          "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time; "
-                                 "bf16x3 executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3 by construction"},
+                                 "executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 (frac <= 1/3), bf16x3k 2.0 (two-term scores, "
+                                 "two-term P.V on the bf16-stored frame tokens; frac <= 1/2)"},
             "ms_per_step_by_stage": stage_ms,
         }
         if gemm is not None:

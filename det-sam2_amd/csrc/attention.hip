@@ -252,8 +252,8 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
 #ifndef DS2_SMALLWIN
 #define DS2_SMALLWIN 1
 #endif
-  if (DS2_SMALLWIN && g_ds2_precision == DS2_PREC_BF16X3 && attention_smallwin_supported(a)) return launch_attention_smallwin(a, st);
-  if (g_ds2_precision == DS2_PREC_BF16X3) {
+  if (DS2_SMALLWIN && ds2_split_mode() && attention_smallwin_supported(a)) return launch_attention_smallwin(a, st);
+  if (ds2_split_mode()) {
     const int rc = launch_attention_bf16x3(a, st);
     if (rc != DS2_ERR_UNSUPPORTED) return rc;
   }

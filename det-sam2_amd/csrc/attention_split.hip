@@ -64,7 +64,7 @@ __global__ void k_rope_split(const float* x, int ldx, const float* cis, int batc
   l.x = cvt_pk_bf16(v.x - bf_lo(h.x), v.y - bf_hi(h.x));
   l.y = cvt_pk_bf16(v.z - bf_lo(h.y), v.w - bf_hi(h.y));
   hi[i] = h;
-  lo[i] = l;
+  if (lo) lo[i] = l;      // bf16x3k mode: the keys of the scores carry no lo plane
 }
 
 // ---- producer 2: V^T tiles.  vt[b][tile][plane][dv 0..63][pos 0..31] (bf16); keys >= L are zero.

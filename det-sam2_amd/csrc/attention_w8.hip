@@ -108,12 +108,15 @@ struct W8Args {
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
 // (32 queries per wave, 256 per block): LDS traffic per MFMA halves - with QG = 1 the LDS pipe is about as busy as
 // the matrix pipe - at the price of 128 VGPRs of Q planes.
-template <int DV, int QG>
+// KLO = false ("bf16x3k" arithmetic mode): the scores use the keys' hi plane only (K rounded to bf16, the query keeps both
+// planes): 2 MFMA terms instead of 3 in Q.K^T, no K lo plane in HBM / LDS - which also brings the block's LDS below 80 KiB so
+// that TWO blocks share a CU.  Accepted by the precision gate of DESIGN.md (all reference goldens <= 5e-4).
+template <int DV, int QG, bool KLO>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int BQ = 128 * QG;
   constexpr int VROWB = DV >= 256 ? VROWB_NARROW : VROWB_WIDE;
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
-  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][2][KPLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][KLO ? 2 : 1][KPLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -186,8 +189,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     k1_ = k1_ < a.Lk ? k1_ : a.Lk - 1;                                        \
     rk0 = a.k_hi[(kbase + k0_) * 32 + kpart];                                 \
     rk1 = a.k_hi[(kbase + k1_) * 32 + kpart];                                 \
-    rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                                 \
-    rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                                 \
+    if (KLO) {                                                                \
+      rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                               \
+      rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                               \
+    }                                                                         \
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j)                          \
       if (DV != 64 || kt_ >= n_hi || tid < 256) rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; /* DV=64: threads >= 256 stage the lo plane */ \
   }
@@ -196,8 +201,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     const int st_kt_ = (STKT);                                                \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso0]) = rk0;                       \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso1]) = rk1;                       \
-    *reinterpret_cast<uint4*>(&Kp[BUF][1][kso0]) = rk2;                       \
-    *reinterpret_cast<uint4*>(&Kp[BUF][1][kso1]) = rk3;                       \
+    if (KLO) {                                                                \
+      *reinterpret_cast<uint4*>(&Kp[BUF][KLO ? 1 : 0][kso0]) = rk2;           \
+      *reinterpret_cast<uint4*>(&Kp[BUF][KLO ? 1 : 0][kso1]) = rk3;           \
+    }                                                                         \
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j) {                        \
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
@@ -217,18 +224,19 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #pragma unroll
     for (int g = 0; g < QG; ++g) { s0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const unsigned char* kp0 = &Kp[cur][0][l15 * KROWB + grp * 16];
-    const unsigned char* kp1 = &Kp[cur][1][l15 * KROWB + grp * 16];
+    const unsigned char* kp1 = &Kp[cur][KLO ? 1 : 0][l15 * KROWB + grp * 16];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + ks * 64);
-      const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + ks * 64);
       const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + ks * 64);
-      const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
+      if constexpr (KLO) {
+        const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + ks * 64);
+        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
 #pragma unroll
-      for (int g = 0; g < QG; ++g) {
-        if (DS2_EXP_QK2) break;     // precision experiment only: drop the k_lo . q_hi term
-        s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[g][ks], s0[g], 0, 0, 0);
-        s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[g][ks], s1[g], 0, 0, 0);
+        for (int g = 0; g < QG; ++g) {
+          s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[g][ks], s0[g], 0, 0, 0);
+          s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[g][ks], s1[g], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
@@ -363,6 +371,7 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
                         int n_exact_keys, const int* vlo_flag) {
+  const bool klo = g_ds2_precision != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
   static const bool qg1 = [] { const char* e = getenv("DS2_ATTN_QG"); return e && atoi(e) == 1; }();
@@ -371,14 +380,19 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
            (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag};
   DS2_REQUIRE(o || o_hi, "attention_w8: no output");
-  if (dv == 64 && !qg1)
-    hipLaunchKernelGGL((k_attention_w8<64, 2>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
-  else if (dv == 64)
-    hipLaunchKernelGGL((k_attention_w8<64, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
-  else if (dv == 128)
-    hipLaunchKernelGGL((k_attention_w8<128, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
-  else   // self-attention in one pass: 16 dv blocks (64 accumulator registers), 150 KB of LDS
-    hipLaunchKernelGGL((k_attention_w8<256, 1>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+  DS2_REQUIRE(klo ? (k_lo != nullptr) : true, "attention_w8: the K lo plane is required in bf16x3 mode");
+  if (dv == 64 && !qg1) {
+    if (klo) hipLaunchKernelGGL((k_attention_w8<64, 2, true>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attention_w8<64, 2, false>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
+  } else if (dv == 64) {
+    if (klo) hipLaunchKernelGGL((k_attention_w8<64, 1, true>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attention_w8<64, 1, false>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+  } else if (dv == 128) {
+    hipLaunchKernelGGL((k_attention_w8<128, 1, true>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+  } else {   // self-attention in one pass: 16 dv blocks (64 accumulator registers), 150 KB of LDS (116 KB without K lo)
+    if (klo) hipLaunchKernelGGL((k_attention_w8<256, 1, true>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attention_w8<256, 1, false>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+  }
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

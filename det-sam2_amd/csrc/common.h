@@ -81,8 +81,11 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& g, hipStream_t st);          // exact fp32 MFMA
 
 // arithmetic mode of the matrix-core kernels (ds2_set_precision)
-enum { DS2_PREC_FP32 = 0, DS2_PREC_BF16X3 = 1 };
+// BF16X3K = BF16X3 everywhere except the scores of the memory attention (cross + self), whose KEYS are carried as one
+// bf16 plane (the queries keep both): 2 of the 3 product terms - see DESIGN.md "precision margin"
+enum { DS2_PREC_FP32 = 0, DS2_PREC_BF16X3 = 1, DS2_PREC_BF16X3K = 2 };
 extern int g_ds2_precision;
+static inline bool ds2_split_mode() { return g_ds2_precision != DS2_PREC_FP32; }
 
 int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
                      float eps, int act, hipStream_t st);

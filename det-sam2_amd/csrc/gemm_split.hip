@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
       l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
       l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
       *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
-      *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
+      if (g.C_lo) *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
     }
   }
 }

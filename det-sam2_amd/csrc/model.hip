@@ -24,9 +24,10 @@ void ds2_set_error(const char* fmt, ...) {
 extern "C" const char* ds2_last_error(void) { return g_err; }
 extern "C" int ds2_abi_version(void) { return DS2_ABI_VERSION; }
 
-int g_ds2_precision = DS2_PREC_BF16X3;
+int g_ds2_precision = DS2_PREC_BF16X3K;
 extern "C" int ds2_set_precision(int32_t mode) {
-  DS2_REQUIRE(mode == DS2_PREC_FP32 || mode == DS2_PREC_BF16X3, "ds2_set_precision: mode must be 0 (fp32) or 1 (bf16x3)");
+  DS2_REQUIRE(mode == DS2_PREC_FP32 || mode == DS2_PREC_BF16X3 || mode == DS2_PREC_BF16X3K,
+              "ds2_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3k)");
   g_ds2_precision = mode;
   return DS2_OK;
 }
@@ -260,12 +261,12 @@ static int new_act_planes(ds2_model* m, const void* key, int rows, int cols, ds2
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
                 const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false,
-                const float* rope_cis = nullptr, int rope_L = 0, int rope_n = 0, int rope_grid = 0) {
+                const float* rope_cis = nullptr, int rope_L = 0, int rope_n = 0, int rope_grid = 0, bool out_hi_only = false) {
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
   }
-  if (g_ds2_precision != DS2_PREC_BF16X3) {
+  if (!ds2_split_mode()) {
     GemmArgs g{M, N, K, A, lda, W, ldw, bias, C, ldc, act, gamma, R, ldr, r_mod};
     return launch_gemm(g, st);
   }
@@ -320,7 +321,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   if (planes_out && m) {
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, C, M, N, &op, st));
-    g.C = nullptr; g.C_hi = op.hi; g.C_lo = op.lo; g.ldcp = op.ld;
+    g.C = nullptr; g.C_hi = op.hi; g.C_lo = out_hi_only ? nullptr : op.lo; g.ldcp = op.ld;
     g.rope_cis = rope_cis; g.rope_L = rope_L; g.rope_n = rope_n; g.rope_grid = rope_grid;
   }
   return launch_gemm_split(g, st);
@@ -339,7 +340,7 @@ static int layernorm(ds2_model* m, hipStream_t st, const std::string& p, const f
   const float* w = m->P(p + ".weight");
   const float* b = m->P(p + ".bias");
   if (!w || !b) { ds2_set_error("missing parameter '%s'", p.c_str()); return DS2_ERR_STATE; }
-  if (planes_out && g_ds2_precision == DS2_PREC_BF16X3) {
+  if (planes_out && ds2_split_mode()) {
     ds2_model::ActPlanes op;
     const int ld = round32i(C);
     op.hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * ld * 2));
@@ -655,7 +656,7 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
       aa.k_pad = qb ? qb + b.dim_out : nullptr;
       aa.v_pad = qb ? qb + 2 * b.dim_out : nullptr;
     }
-    if (g_ds2_precision == DS2_PREC_BF16X3) {   // attention output goes straight to the proj GEMM: emit planes
+    if (ds2_split_mode()) {   // attention output goes straight to the proj GEMM: emit planes
       ds2_model::ActPlanes ap;
       TRY(new_act_planes(m, a, hwq, b.dim_out, &ap, st));
       aa.o_hi = ap.hi; aa.o_lo = ap.lo; aa.ldop = ap.ld;
@@ -762,7 +763,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_attention", st);
   const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
-  const bool split = g_ds2_precision == DS2_PREC_BF16X3;
+  const bool split = ds2_split_mode();
+  const bool klo_planes = g_ds2_precision != DS2_PREC_BF16X3K || !use_w8();   // keys of the attention scores carry a lo plane
   const int nt_c = (Nk + 31) / 32, nt_s = TOK / 32;
   const size_t split_bytes = split ? ((size_t)B * Nk * 256 * 4 + (size_t)B * nt_c * 8192 + (size_t)rows * 256 * 4 +
                                       (size_t)4 * B * nt_s * 8192 + (1u << 20)) : 0;
@@ -829,13 +831,14 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
     TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
     if (split) {
-      TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_s, st));
+      TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st));
       ProfScope _p("kernel.self_attention", st);
       ds2_model::ActPlanes sa_p{};
       if (use_w8()) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
       if (use_w8()) {   // all 256 value columns in one pass
         TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));
-        TRY(launch_attention_w8(qkv, 768, khi_s, klo_s, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi, sa_p.lo, sa_p.ld));
+        TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
+                                sa_p.lo, sa_p.ld));
       } else {          // four 64-column passes
         for (int c = 0; c < 4; ++c) {
           void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 8192;
@@ -869,9 +872,9 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
       TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
                m->P(p + ".cross_attn_image.k_proj.bias"), K, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m, true, cis, Nk,
-               Nk - n_ptr_tok, TOK));
+               Nk - n_ptr_tok, TOK, !klo_planes));
       const ds2_model::ActPlanes kpl = m->act_planes[K];
-      khi = kpl.hi; klo = kpl.lo;
+      khi = kpl.hi; klo = klo_planes ? kpl.lo : nullptr;
       ProfScope _p("kernel.cross_attention", st);
       if (use_w8()) {
         ds2_model::ActPlanes cp;
@@ -915,7 +918,7 @@ namespace {
 #define DS2_KPE_PLANES 1
 #endif
 int keys_plus_pe(ds2_model* m, hipStream_t st, const float* keys, const float* dense_pe, float* kpe, int rows) {
-  if (DS2_KPE_PLANES && g_ds2_precision == DS2_PREC_BF16X3) {
+  if (DS2_KPE_PLANES && ds2_split_mode()) {
     ds2_model::ActPlanes kp;
     TRY(new_act_planes(m, kpe, rows, 256, &kp, st));
     return launch_add_bcast_split(keys, 256, dense_pe, 256, TOK, 1.0f, kp.hi, kp.lo, kp.ld, rows, 256, st);
@@ -979,11 +982,12 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   DS2_REQUIRE(m && m->finalized && B > 0 && pix_feat && fpn0 && fpn1 && low_res && obj_ptr && obj_logits,
               "ds2_sam_heads: bad argument");
   DeviceGuard _dg(m->device);
-  DS2_REQUIRE(P >= 0 && P <= 8 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
+  DS2_REQUIRE(P >= 0 && P <= 256 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.sam_heads", st);
   const int rows = B * TOK;
-  const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * 16 * 2048 * 4) * 4 +
+  const size_t Tmax = 6 + (size_t)(P > 0 ? P : 1) + 1;      // decoder tokens: 6 output tokens + prompt points + the padding point
+  const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * Tmax * (2048 + 256 * 10) * 2) * 4 +
                       (size_t)3 * rows * 256 * 4 /* key + pe operand planes, one set per use */ + (8u << 20);
   TRY(m->require(need, st));
   const std::string md = "sam_mask_decoder", tr = md + ".transformer";

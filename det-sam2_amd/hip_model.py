@@ -40,14 +40,17 @@ class HipOps:
     def _empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
+    PRECISIONS = ("fp32", "bf16x3", "bf16x3k")
+
     def set_precision(self, mode: str):
-        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-precision bf16 MFMA, default)."""
-        if mode not in ("fp32", "bf16x3"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {mode!r}")
-        _capi.check(self.lib.ds2_set_precision({"fp32": 0, "bf16x3": 1}[mode]), "ds2_set_precision")
+        """'fp32' (exact fp32 MFMA), 'bf16x3' (split-precision bf16 MFMA: three product terms everywhere) or 'bf16x3k'
+        (default: bf16x3, with the KEYS of the memory-attention scores carried as one bf16 plane)."""
+        if mode not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {self.PRECISIONS}, got {mode!r}")
+        _capi.check(self.lib.ds2_set_precision(self.PRECISIONS.index(mode)), "ds2_set_precision")
 
     def get_precision(self) -> str:
-        return ["fp32", "bf16x3"][self.lib.ds2_get_precision()]
+        return self.PRECISIONS[self.lib.ds2_get_precision()]
 
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on=True, gemm_shapes=False):

@@ -42,7 +42,7 @@ def test_resize_aa_matches_torch(hin, win, hout, wout):
         assert errl == 0.0          # exact 4x downscale of a 0/1 mask: dyadic weights, every product and sum exact
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3k"])
 def test_add_new_mask_matches_reference(golden_dir, prec):
     from det_sam2_amd.sam2_video_predictor import SAM2VideoPredictor
     from oracle.make_goldens import mask_prompts

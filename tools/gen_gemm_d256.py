@@ -4,6 +4,7 @@ ep_start = src256.index('  // ---- epilogue: each wave parks one 32 x 64 slab')
 ep_end = src256.index('}  // namespace')
 epilogue = src256[ep_start:ep_end]
 epilogue = epilogue.replace('MF', '4').replace('BM2', 'DBM')
+# (the source kernel already guards the lo-plane store)
 # r3-style tail: drain DMA before LDS reuse
 epilogue = epilogue.replace('  __syncthreads();\n  constexpr int EPLD = 68;', '  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the (redundant) tail DMA / touches before LDS is reused\n  __syncthreads();\n  constexpr int EPLD = 68;', 1)
 head = r'''// bf16x3 GEMM over pre-split operands: 256x256 block tile, 8 waves (wave tile 128x64), TWO-stage LDS-DMA pipeline with
