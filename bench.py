@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 PREFILL = 15  # tracked frames needed before the 7-frame bank + 16 pointers are in steady state
 # extra frames tracked AFTER the timed region with one HIP-event bracket per GEMM (roofline_gemm): one whole encoder batch
-GEMM_PROBE = int(os.environ.get("DS2_ENCODE_BATCH", "10"))
+GEMM_PROBE = int(os.environ.get("DS2_ENCODE_BATCH", "16"))
 # MI355X_MICROARCH.md dense MFMA peaks: fp32 (v_mfma_f32_32x32x2_f32) and bf16 (v_mfma_f32_*_bf16)
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3k": 2500.0}
 DTYPE = {"fp32": "f32",
@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--model", default="sam2.1_hiera_l")
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16x3k", choices=["fp32", "bf16x3", "bf16x3k"])
+    ap.add_argument("--precision", default=os.environ.get("DS2_BENCH_PREC", "bf16x3k"), choices=["fp32", "bf16x3", "bf16x3k"])
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: N independent streams, one per GPU (BASELINE config 5) instead of ONE stream sharded by pass (config 4)")
     a = ap.parse_args()

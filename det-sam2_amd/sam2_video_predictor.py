@@ -46,7 +46,9 @@ class SAM2VideoPredictor:
         self.stats = {"encoder_runs": 0, "encoder_launches": 0, "tracked_frames": 0}
         # frames encoded per image-encoder launch: the driver hands frames over 30 at a time, and one frame's
         # Hiera stage-3/4 GEMMs (4096 / 1024 tokens) cannot fill 256 CUs.  Same results as one-by-one.
-        self.encode_batch = int(os.environ.get("DS2_ENCODE_BATCH", "10"))
+        # Upper bound 16 (the C-ABI's limit); the actual batch splits the frames still to encode evenly (20 -> 10 + 10,
+        # 30 -> 15 + 15): at 16 frames every Hiera stage-3 GEMM of hiera_l is a whole number of 256-CU rounds.
+        self.encode_batch = int(os.environ.get("DS2_ENCODE_BATCH", "16"))
 
     # ------------------------------------------------------------------ frame ingest (A3)
     def _load_frames(self, video_path):
@@ -162,11 +164,10 @@ class SAM2VideoPredictor:
             order = st.get("_encode_order")
             if self.encode_batch > 1 and order is not None and frame_idx in order:
                 have = set(st["images_idx"])
-                for t in order[order.index(frame_idx) + 1:]:
-                    if len(todo) >= self.encode_batch:
-                        break
-                    if t not in cache and t in have:
-                        todo.append(t)
+                rest = [t for t in order[order.index(frame_idx) + 1:] if t not in cache and t in have]
+                n_rem = 1 + len(rest)
+                n_batches = -(-n_rem // self.encode_batch)
+                todo += rest[: -(-n_rem // n_batches) - 1]           # even split of what is left over the batches it needs
             if len(todo) == 1:
                 feats = [self.hip.image_encoder(st["images"][st["images_idx"].index(frame_idx)])]
             else:

@@ -28,8 +28,8 @@ def test_c_abi_rejects_bad_arguments(hm):
     with pytest.raises(Ds2Error, match="multiple of 4096"):            # Nk - num_obj_ptr_tokens must be whole frames
         hm.memory_attention(1, curr, mem, mem, 4)
     f0, f1, f2 = torch.zeros(65536, 32, device=d), torch.zeros(16384, 64, device=d), torch.zeros(1, 4096, 256, device=d)
-    with pytest.raises(Ds2Error, match="bad prompt"):                  # more points than the prompt encoder path holds
-        hm.sam_heads(1, f2, f0, f1, torch.zeros(1, 9, 2, device=d), torch.zeros(1, 9, dtype=torch.int32, device=d), False)
+    with pytest.raises(Ds2Error, match="bad prompt"):                  # more points than the entry point accepts (256)
+        hm.sam_heads(1, f2, f0, f1, torch.zeros(1, 300, 2, device=d), torch.zeros(1, 300, dtype=torch.int32, device=d), False)
     q = torch.zeros(1, 8, 40, device=d)
     with pytest.raises(Ds2Error, match="unsupported head dims"):
         hm.op_attention(q, q, q, 1, 1.0)
