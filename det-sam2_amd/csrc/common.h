@@ -59,9 +59,21 @@ __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (
 // ---- epilogue / activation codes shared by GEMM and LayerNorm
 enum { DS2_ACT_NONE = 0, DS2_ACT_RELU = 1, DS2_ACT_GELU = 2, DS2_ACT_SIGMOID = 3 };
 
+// GELU(x) = x * Phi(x), Phi(x) = erfc(-x / sqrt 2) / 2.  erfc(z), z >= 0, by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7 absolute): branch-free, one v_exp_f32 and one v_rcp_f32 - the libm erff() costs ~3x the VALU work and
+// the GEMM epilogues of the MLPs evaluate it once per output element.  The negative side uses the complementary form
+// directly (no 1 - erf cancellation), so the tail keeps its relative accuracy.
+__device__ __forceinline__ float ds2_gelu(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float half_erfc = 0.5f * poly * __expf(-z * z);           // erfc(z) / 2
+  return x * (x >= 0.f ? 1.f - half_erfc : half_erfc);
+}
+
 __device__ __forceinline__ float ds2_act(float x, int act) {
   if (act == DS2_ACT_RELU) return x > 0.f ? x : 0.f;
-  if (act == DS2_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+  if (act == DS2_ACT_GELU) return ds2_gelu(x);
   if (act == DS2_ACT_SIGMOID) return 1.f / (1.f + expf(-x));
   return x;
 }

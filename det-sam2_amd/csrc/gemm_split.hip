@@ -391,6 +391,9 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
   static const int tile_env = [] { const char* e = getenv("DS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (tile_env != 0) return launch_tile(g, tile_env, st);
+  // K = 64 projections over hundreds of thousands of rows (memory-attention keys): HBM-bound weight-stationary kernel
+  static const bool k64 = [] { const char* e = getenv("DS2_GEMM_K64"); return !(e && atoi(e) == 0); }();
+  if (k64 && gemm_split_k64_supported(g)) return launch_gemm_split_k64(g, st);
   // opt-in (DS2_GEMM_TUNE=1): on MI355X the tuner confirms the cost model on every shape of the four SAM 2.1 configs
   // (identical frames/s), so the default stays the deterministic heuristic
   static const bool tune = [] { const char* e = getenv("DS2_GEMM_TUNE"); return e && atoi(e) != 0; }();

@@ -1,0 +1,207 @@
+// bf16x3 GEMM over pre-split operands for K = 64 and N <= 256: WEIGHT-STATIONARY, HBM-bound by design.
+//
+// The memory attention's key projection is C[B*Nk, 256] = kin[B*Nk, 64] . Wk^T (+ RoPE, emitted as key planes): at 16
+// objects and a 7-frame bank M = 459 776 rows, K = 64.  A tile kernel pays a prologue, two K tiles and a 256 x 256 epilogue
+// per block and reaches 50-60 TFLOP/s; but the GEMM is a stream: 118 MB of operand planes in, 235-471 MB of key planes
+// out, 0.1 GFLOP per MB - its floor is the HBM time (~80-110 us), not the matrix pipe.  So:
+//   * the whole weight (N x 64, both planes: <= 64 KiB) is loaded into LDS ONCE per workgroup (XOR-swizzled rows);
+//   * a wave owns 32 rows x all N columns at a time: its A fragments come straight from global memory in MFMA fragment
+//     shape (8 x 16-byte loads per lane, prefetched one tile ahead) - an A element is used by this wave only, there is
+//     nothing to share through LDS;
+//   * the workgroups are persistent (grid ~ 2 x CUs x ...) and stride over the row tiles; the epilogue (the same LDS-staged,
+//     row-wise one as the tile kernels: bias, act, gamma, residual, RoPE, plane / fp32 output) streams the result out.
+// Same per-element accumulation order as the tile kernels (per 16-deep sub-step: lo*hi, hi*lo, hi*hi), so results are
+// bit-identical to them.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int KW = 64, WROWB = 128;   // K, bytes per weight row and plane in LDS
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+struct AFrags {
+  bf16x8 h[4], l[4];   // four 16-deep sub-steps
+};
+
+// NT = N / 32 column tiles (4 or 8)
+template <int NT>
+__global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int tiles_per_wave) {
+  constexpr int NCOL = NT * 32;
+  constexpr int WPL = NCOL * WROWB;                       // bytes of one weight plane
+  constexpr int EPLD = 68;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WPL + 8 * 32 * EPLD * 4];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+
+  // ---- weights -> LDS once: row n, plane p, 16-byte chunk c at  p*WPL + n*128 + ((c ^ ((n >> 1) & 7)) << 4)
+  for (int i = tid; i < NCOL * 8 * 2; i += 512) {
+    const int p = i / (NCOL * 8), r = (i / 8) % NCOL, c = i & 7;
+    const int nr = r < g.N ? r : g.N - 1;
+    const uint4 v = *reinterpret_cast<const uint4*>((p ? g.W_lo : g.W_hi) + (size_t)nr * g.ldw + c * 8);
+    *reinterpret_cast<uint4*>(lds + p * WPL + r * WROWB + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+  }
+  __syncthreads();
+
+  float* ep = reinterpret_cast<float*>(lds + 2 * WPL) + wave * (32 * EPLD);
+  const int c4 = lane & 15, r0 = lane >> 4;
+  const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+  const int ntiles = (g.M + 31) / 32;
+
+  auto load_a = [&](int tile, AFrags& F) {
+    int row = tile * 32 + l31;
+    row = row < g.M ? row : g.M - 1;
+    const unsigned short* ph = g.A_hi + (size_t)row * g.lda + half * 8;
+    const unsigned short* pl = g.A_lo + (size_t)row * g.lda + half * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      F.h[s] = *reinterpret_cast<const bf16x8*>(ph + s * 16);
+      F.l[s] = *reinterpret_cast<const bf16x8*>(pl + s * 16);
+    }
+  };
+
+  AFrags F, Fn;
+  {
+    const int t0 = gw < ntiles ? gw : ntiles - 1;
+    load_a(t0, F);
+  }
+  const int wsw = (l31 >> 1) & 7;
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int tile_raw = gw + it * nw;
+    const int tile = tile_raw < ntiles ? tile_raw : ntiles - 1;      // surplus iterations recompute the last tile, store nothing
+    const bool live = tile_raw < ntiles;
+    {
+      const int tn_raw = gw + (it + 1) * nw;
+      load_a(tn_raw < ntiles ? tn_raw : ntiles - 1, Fn);             // prefetch the next row tile's fragments
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int coff = (((s * 2 + half) ^ wsw) << 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned char* wp = lds + (t * 32 + l31) * WROWB + coff;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + WPL);
+        acc[t] = DS2_MFMA_IF(!DS2_EXP_GEMM2A, acc[t], F.l[s], bh);
+        acc[t] = DS2_MFMA_IF(!DS2_EXP_GEMM2W, acc[t], F.h[s], bl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bh, acc[t], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: 64-column slabs through the wave's LDS area, row-wise 16-byte traffic (as the tile kernels)
+    const int m0 = tile * 32;
+#pragma unroll
+    for (int sl = 0; sl < NT / 2; ++sl) {
+      const int n = sl * 64 + c4 * 4;
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), gam4 = make_float4(1.f, 1.f, 1.f, 1.f);
+      {
+        float* bp = reinterpret_cast<float*>(&bias4);
+        float* gp = reinterpret_cast<float*>(&gam4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (g.bias && n + j < g.N) bp[j] = g.bias[n + j];
+          if (g.gamma && n + j < g.N) gp[j] = g.gamma[n + j];
+        }
+      }
+      const bool vec_ok = (n + 3 < g.N);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ep[mfma32_row(e, half) * EPLD + tn * 32 + l31] = acc[sl * 2 + tn][e];
+      __syncthreads();
+#pragma unroll 4
+      for (int i8 = 0; i8 < 8; ++i8) {
+        const int rr = i8 * 4 + r0;
+        const int m = m0 + rr;
+        if (!live || m >= g.M) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(&ep[rr * EPLD + c4 * 4]);
+        float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
+                      ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
+        if (g.R) {
+          const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
+          const float* rp = g.R + (size_t)rm * g.ldr + n;
+          if (vec_ok && (g.ldr & 3) == 0) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rp);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (n + j < g.N) v[j] += rp[j];
+          }
+        }
+        if (g.C) {
+          float* cp = g.C + (size_t)m * g.ldc + n;
+          if (vec_ok && (g.ldc & 3) == 0) {
+            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (n + j < g.N) cp[j] = v[j];
+          }
+        }
+        if (g.C_hi && n < g.ldcp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n + j >= g.N) v[j] = 0.f;
+          if (g.rope_cis) {   // apply_rotary_enc (position_encoding.py:196-220) on the complex pairs (n, n+1), (n+2, n+3)
+            const int t = m % g.rope_L;
+            if (t < g.rope_n) {
+              const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
+              const float a0 = v[0] * c.x - v[1] * c.y, a1 = v[0] * c.y + v[1] * c.x;
+              const float a2 = v[2] * c.z - v[3] * c.w, a3 = v[2] * c.w + v[3] * c.z;
+              v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
+            }
+          }
+          uint2 h, l;
+          h.x = cvt_pk_bf16(v[0], v[1]);
+          h.y = cvt_pk_bf16(v[2], v[3]);
+          l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
+          l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
+          *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
+          if (g.C_lo) *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
+        }
+      }
+      __syncthreads();
+    }
+    F = Fn;
+  }
+}
+
+}  // namespace
+
+bool gemm_split_k64_supported(const GemmSplitArgs& g) {
+  const int ncols = g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N;
+  return g.Kp == KW && (ncols == 128 || ncols == 256) && g.N > ncols - 32 && g.M >= 4096;
+}
+
+int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st) {
+  DS2_REQUIRE(gemm_split_k64_supported(g), "gemm_split_k64: unsupported shape");
+  const int ncols = g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N;
+  const int ntiles = (g.M + 31) / 32;
+  int blocks = (ntiles + 7) / 8;
+  if (blocks > 256) blocks = 256;                      // one persistent workgroup per CU
+  const int tiles_per_wave = (ntiles + blocks * 8 - 1) / (blocks * 8);
+  if (ncols == 256)
+    hipLaunchKernelGGL((k_gemm_split_k64<8>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else
+    hipLaunchKernelGGL((k_gemm_split_k64<4>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}

@@ -58,9 +58,11 @@ def test_predictor_raises_like_the_reference():
         pred.add_new_points_or_box(st, 0, 1, box=np.array([1, 2, 30, 40], np.float32), clear_old_points=False)
     with pytest.raises(NotImplementedError):                          # frame sources outside the hot path (misc.py:292-303)
         pred.init_state("/some/video.mp4")
-    with pytest.raises(NotImplementedError):
-        pred.add_new_mask(st, 0, 1, np.zeros((1024, 1024), bool))
     # the state is still usable
     pred.add_new_points_or_box(st, 0, 1, box=np.array([100, 100, 400, 400], np.float32))
     outs = list(pred.propagate_in_video(st))
     assert [o[0] for o in outs] == [0, 1]
+    with pytest.raises(NotImplementedError):                          # correction prompts on tracked frames: not on the hot path
+        pred.add_new_mask(st, 0, 1, np.zeros((1024, 1024), bool))
+    with pytest.raises(NotImplementedError):
+        pred.add_new_points_or_box(st, 1, 1, box=np.array([100, 100, 400, 400], np.float32))

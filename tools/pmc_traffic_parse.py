@@ -25,7 +25,7 @@ def steady(rows):   # launches with the full 7-frame bank = the longest ones
 
 fk, nf = steady(f)
 wk, nw = steady(w)
-out = {"kernel": "k_attention_w8<64,2> (memory cross-attention, Nk=28736, 16 objects)",
+out = {"kernel": "k_attention_w8<64,2,*> (memory cross-attention, Nk=28736, 16 objects; default arithmetic mode of the run)",
        "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk, "launches_averaged": [nf, nw],
        "read_correction": 2.0,
        "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
