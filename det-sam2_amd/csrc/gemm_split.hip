@@ -334,6 +334,9 @@ int heuristic_tile(const GemmSplitArgs& g) {
   // its 32-bit DMA offsets need the operand planes to stay below 4 GiB
   static const bool d256 = [] { const char* e = getenv("DS2_GEMM_D256"); return !(e && atoi(e) == 0); }();
   if (tile == 4 && d256 && (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) tile = 5;
+  // four-stage 16-deep variant (three K slices in flight): DS2_GEMM_Q256=1/0
+  static const bool q256 = [] { const char* e = getenv("DS2_GEMM_Q256"); return e && atoi(e) != 0; }();
+  if (tile == 5 && q256) tile = 6;
   return tile;
 }
 
@@ -341,13 +344,14 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   GemmSplitArgs g = g_in;
   {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
     static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
-    const int bn = (tile == 4 || tile == 5) ? 256 : 128;
+    const int bn = (tile == 4 || tile == 5 || tile == 6) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
     g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
     static const int pf_env = [] { const char* e = getenv("DS2_GEMM_PF"); return e ? atoi(e) : 0; }();
     g.prefetch = pf_env;
   }
   if (tile == 5) return launch_gemm_split_d256(g, st);
+  if (tile == 6) return launch_gemm_split_q256(g, st);
   if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
   if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
