@@ -240,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       }
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
+        if (DS2_EXP_QK1 && !KLO) break;     // precision experiment only
         s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q1[g][ks], s0[g], 0, 0, 0);
         s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[g][ks], s1[g], 0, 0, 0);
       }

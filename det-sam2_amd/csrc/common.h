@@ -44,6 +44,9 @@ void ds2_set_error(const char* fmt, ...);
 #ifndef DS2_EXP_QK2
 #define DS2_EXP_QK2 0
 #endif
+#ifndef DS2_EXP_QK1   /* bf16x3k mode only: also drop k_hi . q_lo (plain bf16 x bf16 scores) */
+#define DS2_EXP_QK1 0
+#endif
 #define DS2_MFMA_IF(cond, acc, a, b) ((cond) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (acc), 0, 0, 0) : (acc))
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
