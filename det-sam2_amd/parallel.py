@@ -230,6 +230,7 @@ def _make_sharded_cls():
             self._round_frames = []          # frames of the current round, buffer by buffer
             self._next_pass = 0
             self._prev_buffer_feats = {}     # rank 0: features received at the end of round R for its pass of round R+1
+            self._host_frames = {}           # absolute index -> host frame (references) of the last rounds
             self.owned_passes = []
             self.comm_log = []               # (round, op, bytes) for the bench / tests
             assert self.detect_interval == -1 or self.detect_interval > 0
@@ -260,11 +261,27 @@ def _make_sharded_cls():
                 pass
 
         # -------------------------------------------------------------- helpers
-        def _ingest_buffer(self):
-            if self.inference_state is None and self.world > 1:      # only pass 0's owner needs frame 0's feature now
-                self.inference_state = self.predictor.init_state(video_path=self.frame_buffer, warm_up_first_frame=False)
+        def _ingest_round(self, first_abs, lo, hi):
+            """Ingest (H2D + resize/normalise) only the frames [lo, hi] of the round buffer - this rank's own buffer; the
+            other frames of the round are never needed as images here (their pyramids arrive by hand-off, the level-2
+            features of peer conditioning frames with the entries).  Frame numbering still advances by the whole round.
+            The host frames of the last two rounds stay reachable for the rare on-demand ingest (partial final window)."""
+            p, n_round = self.predictor, len(self.frame_buffer)
+            for i, fr in enumerate(self.frame_buffer):
+                self._host_frames[first_abs + i] = fr
+            for t in [t for t in self._host_frames if t < first_abs - n_round - 2 * self.frame_buffer_size]:
+                del self._host_frames[t]
+            own = self.frame_buffer[lo - first_abs: hi - first_abs + 1] if hi >= lo else []
+            idx = list(range(lo, hi + 1))
+            if self.inference_state is None:
+                seed = own if own else self.frame_buffer[:1]
+                st = p.init_state(video_path=seed, warm_up_first_frame=False)
+                st["images_idx"] = idx if own else [first_abs]
+                st["num_frames"] = n_round
+                self.inference_state = st
             else:
-                super()._ingest_buffer()
+                p.append_sparse_frames(self.inference_state, own, idx, advance=n_round)
+            self.inference_state["_frame_source"] = self._host_frames.get
 
         def _pass_abs_range(self, first_abs, j_local, n_frames_round):
             """Absolute frame indices of the NEW frames of the round's j-th pass."""
@@ -353,8 +370,12 @@ def _make_sharded_cls():
             past = self.inference_state["num_frames"] if self.inference_state else 0
             first_abs = past                                   # absolute index of the round's first frame
             mine = r if r < n_pass else None                   # local index of my pass in this round
-            # ---- every rank holds every frame (same indexing / eviction everywhere)
-            self._ingest_buffer()
+            # ---- frame numbering and eviction are the same on every rank; the images a rank holds are its own buffers
+            if N > 1 and self.handoff:
+                lo_, hi_ = self._pass_abs_range(first_abs, mine, n_round) if mine is not None else (0, -1)
+                self._ingest_round(first_abs, lo_, hi_)
+            else:
+                self._ingest_buffer()
             st = self.inference_state
             d = p.device
             # ---- 1. encode my buffer once, hand the pyramids to the owner of the next pass
@@ -380,8 +401,7 @@ def _make_sharded_cls():
                 else:
                     use = got
                 for t, f in use.items():
-                    if t in st["images_idx"]:
-                        st["cached_features"][t] = f
+                    st["cached_features"][t] = f
             # ---- 2. detections of my buffer -> everybody
             dets = {}
             if mine is not None:

@@ -118,6 +118,19 @@ class SAM2VideoPredictor:
         st["num_frames"] += len(new)
         return st
 
+    def append_sparse_frames(self, inference_state, frames, abs_indices, advance=0):
+        """Ingest ``frames`` under the given ABSOLUTE frame indices (not necessarily contiguous with what is retained) and
+        advance ``num_frames`` by ``advance``.  For drivers that hold only part of a stream on this GPU (the pass-sharded
+        driver ingests its own buffer; features of the other frames arrive from peer ranks)."""
+        st = inference_state
+        if len(frames):
+            new, vh, vw = self._load_frames(list(frames))
+            assert vh == st["video_height"] and vw == st["video_width"], "new frames must match the video size"
+            st["images_idx"].extend(int(t) for t in abs_indices)
+            st["images"] = torch.cat((st["images"], new), dim=0) if len(st["images"]) else new
+        st["num_frames"] += int(advance)
+        return st
+
     def init_preloading_state(self, inference_state, offload_video_to_cpu=True, offload_state_to_cpu=True):
         """init_preloading_state (sam2_video_predictor.py:123-156): in the reference this moves the preload bank to the
         storage device; here the bank (loaded by bank_io.load_bank: DS2BANK file or a reference pickle, both already
@@ -159,6 +172,10 @@ class SAM2VideoPredictor:
         on a miss, the next not-yet-encoded frames of the current propagation order ride along in one launch."""
         cache = st["cached_features"]
         f = cache.get(frame_idx)
+        if f is None and frame_idx not in st["images_idx"] and st.get("_frame_source") is not None:
+            fr = st["_frame_source"](frame_idx)          # a frame this GPU did not ingest (sharded driver): fetch it now
+            if fr is not None:
+                self.append_sparse_frames(st, [fr], [frame_idx])
         if f is None:
             todo = [frame_idx]
             order = st.get("_encode_order")
@@ -567,7 +584,7 @@ class SAM2VideoPredictor:
         if release_images:
             old = [t for t in st["images_idx"] if pre_frames - 1 < t <= oldest]
             rm = {st["images_idx"].index(t) for t in old}
-            keep = torch.tensor([i for i in range(st["images"].size(0)) if i not in rm], device=st["images"].device)
+            keep = torch.tensor([i for i in range(st["images"].size(0)) if i not in rm], dtype=torch.long, device=st["images"].device)
             st["images"] = torch.index_select(st["images"], 0, keep)
             st["images_idx"] = [t for t in st["images_idx"] if t not in old]
             assert len(st["images"]) == len(st["images_idx"])

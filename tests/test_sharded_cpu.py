@@ -60,7 +60,7 @@ def test_sharded_rounds_equal_sequential(world, appear, n):
     for v in vps:
         assert v.inference_state["obj_ids"] == seq.inference_state["obj_ids"]
         assert sorted(v.inference_state["output_dict"]["cond_frame_outputs"]) == sorted(seq.inference_state["output_dict"]["cond_frame_outputs"])
-        assert v.inference_state["images_idx"] == seq.inference_state["images_idx"]
+        assert set(v.inference_state["images_idx"]) <= set(seq.inference_state["images_idx"])   # a rank ingests only its own buffers
         assert v.special_classes_count == seq.special_classes_count
         assert np.array_equal(np.asarray(v.special_classes_detection), np.asarray(seq.special_classes_detection))
         assert [p[0] for p in v.pass_log] == [p[0] for p in seq.pass_log]
