@@ -34,7 +34,7 @@ void ds2_set_error(const char* fmt, ...);
 
 // Precision experiments (tools/ab.py build NAME -DDS2_EXP_...=1; never set in the shipped build, see DESIGN.md "precision
 // margin"): drop ONE of the three bf16x3 product terms - the activation's lo plane (GEMM2A), the weight's lo plane
-// (GEMM2W), or the key's lo plane in the memory-attention scores (QK2).
+// (GEMM2W), or the key's lo plane in the memory-attention scores of the full bf16x3 mode (QK2).
 #ifndef DS2_EXP_GEMM2A
 #define DS2_EXP_GEMM2A 0
 #endif
@@ -43,9 +43,6 @@ void ds2_set_error(const char* fmt, ...);
 #endif
 #ifndef DS2_EXP_QK2
 #define DS2_EXP_QK2 0
-#endif
-#ifndef DS2_EXP_QK1   /* bf16x3k mode only: also drop k_hi . q_lo (plain bf16 x bf16 scores) */
-#define DS2_EXP_QK1 0
 #endif
 #define DS2_MFMA_IF(cond, acc, a, b) ((cond) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (acc), 0, 0, 0) : (acc))
 
@@ -96,8 +93,8 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& g, hipStream_t st);          // exact fp32 MFMA
 
 // arithmetic mode of the matrix-core kernels (ds2_set_precision)
-// BF16X3K = BF16X3 everywhere except the scores of the memory attention (cross + self), whose KEYS are carried as one
-// bf16 plane (the queries keep both): 2 of the 3 product terms - see DESIGN.md "precision margin"
+// BF16X3K = BF16X3 everywhere except the SCORES of the memory attention (cross + self): plain bf16 x bf16 products (keys
+// and queries as one bf16 plane each, fp32 accumulation) - see DESIGN.md "precision margin"
 enum { DS2_PREC_FP32 = 0, DS2_PREC_BF16X3 = 1, DS2_PREC_BF16X3K = 2 };
 extern int g_ds2_precision;
 static inline bool ds2_split_mode() { return g_ds2_precision != DS2_PREC_FP32; }

@@ -377,7 +377,7 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
 // per second, so tuning is over within the first frames; the heuristic covers the samples still in flight.
 constexpr int TUNE_SAMPLES = 3;
 struct TuneState {
-  int cand[3] = {1, 3, 4};
+  int cand[3] = {1, 3, 5};
   int issued[3] = {0, 0, 0}, done[3] = {0, 0, 0};
   double best_ms[3] = {1e30, 1e30, 1e30};
   int chosen = 0;

@@ -125,7 +125,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ep[mfma32_row(e, half) * EPLD + tn * 32 + l31] = acc[sl * 2 + tn][e];
-      __syncthreads();
+      // the slab is private to this wave and a wave's LDS operations complete in order: no workgroup barrier, the waves
+      // run their tiles independently (only the compiler must not move the reads above the writes)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
       for (int i8 = 0; i8 < 8; ++i8) {
         const int rr = i8 * 4 + r0;
@@ -178,7 +181,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
           if (g.C_lo) *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
         }
       }
-      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
     F = Fn;
   }
