@@ -337,6 +337,13 @@ int heuristic_tile(const GemmSplitArgs& g) {
   // four-stage 16-deep variant (three K slices in flight): DS2_GEMM_Q256=1/0
   static const bool q256 = [] { const char* e = getenv("DS2_GEMM_Q256"); return e && atoi(e) != 0; }();
   if (tile == 5 && q256) tile = 6;
+  // phase-interleaved variant: DS2_GEMM_P256=1/0
+  static const bool p256 = [] { const char* e = getenv("DS2_GEMM_P256"); return e && atoi(e) != 0; }();
+  if (tile == 5 && p256) tile = 9;
+  // persistent variant with loader / storer waves for GEMMs without residual / RoPE epilogue (default; DS2_GEMM_PP256=0
+  // keeps the one-tile-per-workgroup kernel for A/B runs)
+  static const bool pp256 = [] { const char* e = getenv("DS2_GEMM_PP256"); return !(e && atoi(e) == 0); }();
+  if ((tile == 5 || tile == 9) && pp256 && gemm_split_pp256_supported(g)) tile = 10;
   return tile;
 }
 
@@ -344,7 +351,7 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   GemmSplitArgs g = g_in;
   {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
     static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
-    const int bn = (tile == 4 || tile == 5 || tile == 6) ? 256 : 128;
+    const int bn = (tile == 4 || tile == 5 || tile == 6 || tile == 9 || tile == 10) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
     g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
     static const int pf_env = [] { const char* e = getenv("DS2_GEMM_PF"); return e ? atoi(e) : 0; }();
@@ -352,6 +359,9 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   }
   if (tile == 5) return launch_gemm_split_d256(g, st);
   if (tile == 6) return launch_gemm_split_q256(g, st);
+  if (tile == 10 && !gemm_split_pp256_supported(g)) tile = 5;
+  if (tile == 9) return launch_gemm_split_p256(g, st);
+  if (tile == 10) return launch_gemm_split_pp256(g, st);
   if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
   if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);

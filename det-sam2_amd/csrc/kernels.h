@@ -107,6 +107,9 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 256x128 blocks, 8 waves, 3-stage LDS-DMA ring
 int launch_gemm_split256(const GemmSplitArgs& g, int mf, hipStream_t st);   // 256x256 (mf=4) / 256x128 (mf=2) block tiles
 int launch_gemm_split_d256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, two-stage LDS-DMA, one barrier per K tile
+int launch_gemm_split_p256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, phase-interleaved (half-tile DMA per phase, staggered wave groups)
+int launch_gemm_split_pp256(const GemmSplitArgs& g, hipStream_t st);        // persistent p256 with loader / storer waves (no residual)
+bool gemm_split_pp256_supported(const GemmSplitArgs& g);
 int launch_gemm_split_q256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, four 16-deep LDS-DMA stages, three in flight
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
