@@ -6,7 +6,7 @@
 // out, 0.1 GFLOP per MB - its floor is the HBM time (~80-110 us), not the matrix pipe.  So:
 //   * the whole weight (N x 64, both planes: <= 64 KiB) is loaded into LDS ONCE per workgroup (XOR-swizzled rows);
 //   * a wave owns 32 rows x all N columns at a time: its A fragments come straight from global memory in MFMA fragment
-//     shape (8 x 16-byte loads per lane, prefetched one tile ahead) - an A element is used by this wave only, there is
+//     shape (8 x 16-byte loads per lane, issued for the next tile ahead of this tile's last epilogue slab) - an A element is used by this wave only, there is
 //     nothing to share through LDS;
 //   * the workgroups are persistent (grid ~ 2 x CUs x ...) and stride over the row tiles; the epilogue (the same LDS-staged,
 //     row-wise one as the tile kernels: bias, act, gamma, residual, RoPE, plane / fp32 output) streams the result out.
@@ -30,6 +30,19 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
 }
 __device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// DS2_K64_TRACE (profiling builds only): waves of workgroup 0 stamp s_memtime along their first tiles (tools/k64_trace.py)
+#ifdef DS2_K64_TRACE
+__device__ unsigned long long g_k64_trace[8][256];
+#define K64_T()                                                                                    \
+  if (blockIdx.x == 0 && tix < 256 && (DS2_K64_TRACE == 1 || (g.rope_cis && g.M > 400000))) {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                    \
+    if (lane == 0) g_k64_trace[wave][tix] = t_;                                                    \
+    ++tix;                                                                                         \
+  }
+#else
+#define K64_T()
+#endif
 
 struct AFrags {
   bf16x8 h[4], l[4];   // four 16-deep sub-steps
@@ -73,20 +86,20 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
     }
   };
 
-  AFrags F, Fn;
+  AFrags F;
   {
     const int t0 = gw < ntiles ? gw : ntiles - 1;
     load_a(t0, F);
   }
   const int wsw = (l31 >> 1) & 7;
+#ifdef DS2_K64_TRACE
+  int tix = 0;
+#endif
   for (int it = 0; it < tiles_per_wave; ++it) {
+    K64_T()   // 0: tile start
     const int tile_raw = gw + it * nw;
     const int tile = tile_raw < ntiles ? tile_raw : ntiles - 1;      // surplus iterations recompute the last tile, store nothing
     const bool live = tile_raw < ntiles;
-    {
-      const int tn_raw = gw + (it + 1) * nw;
-      load_a(tn_raw < ntiles ? tn_raw : ntiles - 1, Fn);             // prefetch the next row tile's fragments
-    }
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -105,8 +118,23 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bh, acc[t], 0, 0, 0);
       }
     }
+    K64_T()   // 1: MFMAs issued
     // ---- epilogue: 64-column slabs through the wave's LDS area, row-wise 16-byte traffic (as the tile kernels)
     const int m0 = tile * 32;
+    // RoPE: the table rows of this lane's 8 output rows are the same for every slab; their (L2 / Infinity-Cache) loads are
+    // issued together ahead of the slab's LDS round trip - one dependent load per row cost ~1500 cycles per row
+    // (tools/k64_trace_bench.py: 75 % of the key projection)
+    int rope_t[8];
+    if (g.C_hi && g.rope_cis) {
+#pragma unroll
+      for (int i8 = 0; i8 < 8; ++i8) {
+        int m = m0 + i8 * 4 + r0;
+        m = m < g.M ? m : g.M - 1;
+        const int t = m % g.rope_L;
+        rope_t[i8] = t < g.rope_n ? (t % g.rope_grid) : -1;   // (-1: object-pointer tokens are not rotated)
+      }
+    }
+    {
 #pragma unroll
     for (int sl = 0; sl < NT / 2; ++sl) {
       const int n = sl * 64 + c4 * 4;
@@ -121,6 +149,21 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
         }
       }
       const bool vec_ok = (n + 3 < g.N);
+      if (sl == NT / 2 - 1) {   // the next row tile's fragments: fetched when most accumulators are dead (register budget),
+        const int tn_raw = gw + (it + 1) * nw;   // they land under the last slab's LDS round trip and stores
+        load_a(tn_raw < ntiles ? tn_raw : ntiles - 1, F);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the next slabs' table loads from being hoisted up here: register budget)
+      float4 cis[8];
+      if (g.C_hi && g.rope_cis && n < g.ldcp) {
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8)
+        {
+          int pos = rope_t[i8] < 0 ? 0 : rope_t[i8];
+          if (g.rope_w > 0) pos = (n >> 1) < 64 ? pos % g.rope_w : pos - pos % g.rope_w;   // compact rows, see GemmSplitArgs::rope_w
+          cis[i8] = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)pos * 128 + (n >> 1)) * 2);
+        }
+      }
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -129,7 +172,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
       // run their tiles independently (only the compiler must not move the reads above the writes)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
+      K64_T()   // 2 + 2 sl: slab parked
+#pragma unroll
       for (int i8 = 0; i8 < 8; ++i8) {
         const int rr = i8 * 4 + r0;
         const int m = m0 + rr;
@@ -164,9 +208,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
           for (int j = 0; j < 4; ++j)
             if (n + j >= g.N) v[j] = 0.f;
           if (g.rope_cis) {   // apply_rotary_enc (position_encoding.py:196-220) on the complex pairs (n, n+1), (n+2, n+3)
-            const int t = m % g.rope_L;
-            if (t < g.rope_n) {
-              const float4 c = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)(t % g.rope_grid) * 128 + (n >> 1)) * 2);
+            if (rope_t[i8] >= 0) {
+              const float4 c = cis[i8];
               const float a0 = v[0] * c.x - v[1] * c.y, a1 = v[0] * c.y + v[1] * c.x;
               const float a2 = v[2] * c.z - v[3] * c.w, a3 = v[2] * c.w + v[3] * c.z;
               v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
@@ -183,12 +226,19 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      K64_T()   // 3 + 2 sl: slab streamed out
     }
-    F = Fn;
+    }
   }
 }
 
 }  // namespace
+
+#ifdef DS2_K64_TRACE
+extern "C" int ds2_debug_k64_trace(unsigned long long* out) {   // [8][256] host buffer
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k64_trace), sizeof(unsigned long long) * 8 * 256) == hipSuccess ? 0 : 1;
+}
+#endif
 
 bool gemm_split_k64_supported(const GemmSplitArgs& g) {
   const int ncols = g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N;

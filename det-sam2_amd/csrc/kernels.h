@@ -96,6 +96,10 @@ struct GemmSplitArgs {
   // optional axial RoPE applied to the result before it is split into planes (cross-attention keys): row m is
   // token t = m % rope_L of its batch item; tokens t < rope_n are rotated with cis[(t % rope_grid)][col/2]
   const float* rope_cis; int rope_L, rope_n, rope_grid;
+  // axial table (compute_axial_cis): pairs [0, 64) depend on x = pos % rope_w only, pairs [64, 128) on y = pos / rope_w only.
+  // rope_w > 0 lets a kernel read row x resp. row y * rope_w instead of row pos (identical values): the rows touched shrink
+  // from rope_grid (4 MiB of table, competing with the streamed operands for L2) to 2 * rope_w (64 KiB).
+  int rope_w;
   // block -> tile order inside an XCD's share of the grid: 0/1 = row-major over n; > 1 = groups of group_m tile rows
   // walked column-major (the ~32 blocks an XCD runs at once then share A rows AND W rows through its L2).  Set by
   // launch_gemm_split.

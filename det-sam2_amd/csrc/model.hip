@@ -323,6 +323,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     TRY(new_act_planes(m, C, M, N, &op, st));
     g.C = nullptr; g.C_hi = op.hi; g.C_lo = out_hi_only ? nullptr : op.lo; g.ldcp = op.ld;
     g.rope_cis = rope_cis; g.rope_L = rope_L; g.rope_n = rope_n; g.rope_grid = rope_grid;
+    if (rope_cis && m->cfg.image_size / 16 * (m->cfg.image_size / 16) == rope_grid) g.rope_w = m->cfg.image_size / 16;
   }
   return launch_gemm_split(g, st);
 }

@@ -169,11 +169,16 @@ def test_memory_attention_at_bench_size():
     d = hm.device
     mem_d, pos_d = hm.bank_assemble(B, [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)],
                                     [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)])
-    out = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP)
+    out = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP).clone()
     torch.cuda.synchronize()
     e = rel_err(out, ref.transpose(0, 1))
     record("memory_attention_bench_size", B=B, Nk=28736, err=e)
-    assert e < TOL["bf16x3"], e
+    assert e < 1e-3, e        # measured 3.4e-4; (a racy epilogue variant of the K = 64 GEMM once showed up here as 2-4e-3)
+    # no atomics anywhere on this path: a second run must agree bit for bit (a difference is a race in a kernel)
+    for _ in range(2):
+        again = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP)
+        torch.cuda.synchronize()
+        assert torch.equal(again, out), float((again - out).abs().max())
 
 
 @pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True), ("click", True), ("clicks", False), ("clicks12", False)])

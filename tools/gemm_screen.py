@@ -14,7 +14,7 @@ SHAPES = [  # M, N, K, act, residual, gamma
     (256, 256, 32, 0, 0, 0), (256, 256, 64, 0, 0, 0), (512, 512, 96, 0, 0, 0), (300, 200, 288, 2, 1, 1),
     (4096, 768, 256, 0, 0, 0), (40960, 576, 576, 0, 1, 1), (70000, 1152, 288, 2, 0, 0), (65536, 2304, 576, 2, 0, 0),
     (65536, 576, 2304, 0, 1, 0), (65536, 2048, 256, 1, 0, 0), (16384, 4608, 1152, 2, 0, 0), (65536, 1728, 576, 0, 0, 0),
-    (1000, 1000, 1000 // 32 * 32 + 32, 0, 0, 0),
+    (1000, 1000, 1000 // 32 * 32 + 32, 0, 0, 0), (459776, 256, 64, 0, 0, 0), (65536, 256, 64, 2, 1, 1), (70001, 128, 64, 1, 0, 1),
 ]
 
 
@@ -59,7 +59,9 @@ if __name__ == "__main__":
     outs = []
     for t in tiles:
         out = f"/tmp/gemm_screen_{t}.pt"
-        env = dict(os.environ, DS2_GEMM_TILE=str(t))
+        env = dict(os.environ)
+        if t > 0:
+            env["DS2_GEMM_TILE"] = str(t)      # tile 0 = the default dispatch (incl. the K = 64 kernel)
         subprocess.run([sys.executable, __file__, "--worker", str(t), str(reps), out], env=env, check=True)
         outs.append(torch.load(out))
     ok = True
