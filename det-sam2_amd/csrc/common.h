@@ -78,6 +78,23 @@ __device__ __forceinline__ float ds2_act(float x, int act) {
   return x;
 }
 
+// four outputs at once with the (wave-uniform) activation switch taken ONCE: the GEMM epilogues evaluate it per row of four
+// columns, and a per-element switch cost them ~12 scalar branches per row (tools/k64_trace_bench.py: the epilogues are
+// instruction-issue bound)
+__device__ __forceinline__ void ds2_act4(float (&v)[4], int act) {
+  if (act == DS2_ACT_NONE) return;
+  if (act == DS2_ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+  } else if (act == DS2_ACT_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ds2_gelu(v[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = 1.f / (1.f + expf(-v[j]));
+  }
+}
+
 // ---- primitive launchers (implemented in the .hip files; all asynchronous on `st`)
 struct GemmArgs {
   int M, N, K;            // C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) * gamma[N] + R[M,N]

@@ -184,8 +184,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split256(GemmSplitArgs g, int m
       const int m = m0 + wm * (MF * 32) + tm * 32 + rr;
       if (m >= g.M) continue;
       const float4 a4 = *reinterpret_cast<const float4*>(&ep[rr * EPLD + c4 * 4]);
-      float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
-                    ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
+      float v[4] = {a4.x + bias4.x, a4.y + bias4.y, a4.z + bias4.z, a4.w + bias4.w};
+      ds2_act4(v, g.act);
+      v[0] *= gam4.x; v[1] *= gam4.y; v[2] *= gam4.z; v[3] *= gam4.w;
       if (g.R) {
         const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
         const float* rp = g.R + (size_t)rm * g.ldr + n;

@@ -48,8 +48,10 @@ struct AFrags {
   bf16x8 h[4], l[4];   // four 16-deep sub-steps
 };
 
-// NT = N / 32 column tiles (4 or 8)
-template <int NT>
+// NT = N / 32 column tiles (4 or 8).  PLANES = the launcher found the key / value projection's epilogue (no activation, gamma,
+// residual or fp32 output; plane output): those operands become compile-time constants and their (wave-uniform) branches
+// disappear from the row loop, which is instruction-issue bound.
+template <int NT, bool PLANES>
 __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int tiles_per_wave) {
   constexpr int NCOL = NT * 32;
   constexpr int WPL = NCOL * WROWB;                       // bytes of one weight plane
@@ -59,6 +61,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
+  const int e_act = PLANES ? (int)DS2_ACT_NONE : g.act;
+  const float* const e_gamma = PLANES ? nullptr : g.gamma;
+  const float* const e_R = PLANES ? nullptr : g.R;
+  float* const e_C = PLANES ? nullptr : g.C;
+  unsigned short* const e_Chi = g.C_hi;
 
   // ---- weights -> LDS once: row n, plane p, 16-byte chunk c at  p*WPL + n*128 + ((c ^ ((n >> 1) & 7)) << 4)
   for (int i = tid; i < NCOL * 8 * 2; i += 512) {
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
     // issued together ahead of the slab's LDS round trip - one dependent load per row cost ~1500 cycles per row
     // (tools/k64_trace_bench.py: 75 % of the key projection)
     int rope_t[8];
-    if (g.C_hi && g.rope_cis) {
+    if (e_Chi && g.rope_cis) {
 #pragma unroll
       for (int i8 = 0; i8 < 8; ++i8) {
         int m = m0 + i8 * 4 + r0;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (g.bias && n + j < g.N) bp[j] = g.bias[n + j];
-          if (g.gamma && n + j < g.N) gp[j] = g.gamma[n + j];
+          if (e_gamma && n + j < g.N) gp[j] = e_gamma[n + j];
         }
       }
       const bool vec_ok = (n + 3 < g.N);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
       }
       __builtin_amdgcn_sched_barrier(0);   // (keeps the next slabs' table loads from being hoisted up here: register budget)
       float4 cis[8];
-      if (g.C_hi && g.rope_cis && n < g.ldcp) {
+      if (e_Chi && g.rope_cis && n < g.ldcp) {
 #pragma unroll
         for (int i8 = 0; i8 < 8; ++i8)
         {
@@ -179,11 +186,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
         const int m = m0 + rr;
         if (!live || m >= g.M) continue;
         const float4 a4 = *reinterpret_cast<const float4*>(&ep[rr * EPLD + c4 * 4]);
-        float v[4] = {ds2_act(a4.x + bias4.x, g.act) * gam4.x, ds2_act(a4.y + bias4.y, g.act) * gam4.y,
-                      ds2_act(a4.z + bias4.z, g.act) * gam4.z, ds2_act(a4.w + bias4.w, g.act) * gam4.w};
-        if (g.R) {
+        float v[4] = {a4.x + bias4.x, a4.y + bias4.y, a4.z + bias4.z, a4.w + bias4.w};
+        ds2_act4(v, e_act);
+        v[0] *= gam4.x; v[1] *= gam4.y; v[2] *= gam4.z; v[3] *= gam4.w;
+        if (e_R) {
           const int rm = g.r_mod > 0 ? (m % g.r_mod) : m;
-          const float* rp = g.R + (size_t)rm * g.ldr + n;
+          const float* rp = e_R + (size_t)rm * g.ldr + n;
           if (vec_ok && (g.ldr & 3) == 0) {
             const float4 r4 = *reinterpret_cast<const float4*>(rp);
             v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
@@ -193,8 +201,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
               if (n + j < g.N) v[j] += rp[j];
           }
         }
-        if (g.C) {
-          float* cp = g.C + (size_t)m * g.ldc + n;
+        if (e_C) {
+          float* cp = e_C + (size_t)m * g.ldc + n;
           if (vec_ok && (g.ldc & 3) == 0) {
             *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
               if (n + j < g.N) cp[j] = v[j];
           }
         }
-        if (g.C_hi && n < g.ldcp) {
+        if (e_Chi && n < g.ldcp) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (n + j >= g.N) v[j] = 0.f;
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
           h.y = cvt_pk_bf16(v[2], v[3]);
           l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
           l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
-          *reinterpret_cast<uint2*>(g.C_hi + (size_t)m * g.ldcp + n) = h;
+          *reinterpret_cast<uint2*>(e_Chi + (size_t)m * g.ldcp + n) = h;
           if (g.C_lo) *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
         }
       }
@@ -252,10 +260,15 @@ int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st) {
   int blocks = (ntiles + 7) / 8;
   if (blocks > 256) blocks = 256;                      // one persistent workgroup per CU
   const int tiles_per_wave = (ntiles + blocks * 8 - 1) / (blocks * 8);
-  if (ncols == 256)
-    hipLaunchKernelGGL((k_gemm_split_k64<8>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  const bool planes = g.act == DS2_ACT_NONE && !g.gamma && !g.R && !g.C && g.C_hi;
+  if (ncols == 256 && planes)
+    hipLaunchKernelGGL((k_gemm_split_k64<8, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else if (ncols == 256)
+    hipLaunchKernelGGL((k_gemm_split_k64<8, false>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else if (planes)
+    hipLaunchKernelGGL((k_gemm_split_k64<4, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
   else
-    hipLaunchKernelGGL((k_gemm_split_k64<4>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+    hipLaunchKernelGGL((k_gemm_split_k64<4, false>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
