@@ -65,7 +65,7 @@ enum { DS2_ACT_NONE = 0, DS2_ACT_RELU = 1, DS2_ACT_GELU = 2, DS2_ACT_SIGMOID = 3
 // directly (no 1 - erf cancellation), so the tail keeps its relative accuracy.
 __device__ __forceinline__ float ds2_gelu(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float half_erfc = 0.5f * poly * __expf(-z * z);           // erfc(z) / 2
   return x * (x >= 0.f ? 1.f - half_erfc : half_erfc);
