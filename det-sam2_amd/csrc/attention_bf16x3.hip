@@ -218,8 +218,10 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(k0p + ks * 32);
         const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(k1p + ks * 32);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], acc, 0, 0, 0);
+        if (!DS2_EXP_HQK1) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0[ks], acc, 0, 0, 0);
       }
       float tmax = -INFINITY;

@@ -41,6 +41,9 @@ void ds2_set_error(const char* fmt, ...);
 #ifndef DS2_EXP_GEMM2W
 #define DS2_EXP_GEMM2W 0
 #endif
+#ifndef DS2_EXP_HQK1   /* Hiera attention scores as plain bf16 x bf16 products (precision experiment) */
+#define DS2_EXP_HQK1 0
+#endif
 #ifndef DS2_EXP_QK2
 #define DS2_EXP_QK2 0
 #endif
@@ -64,11 +67,19 @@ enum { DS2_ACT_NONE = 0, DS2_ACT_RELU = 1, DS2_ACT_GELU = 2, DS2_ACT_SIGMOID = 3
 // the GEMM epilogues of the MLPs evaluate it once per output element.  The negative side uses the complementary form
 // directly (no 1 - erf cancellation), so the tail keeps its relative accuracy.
 __device__ __forceinline__ float ds2_gelu(float x) {
+  // (contraction off + explicit fmaf: every kernel that inlines this must round identically - the tile choice of a GEMM
+  // depends on its row count, and a stream sharded over ranks encodes other batch sizes than a sequential one)
+#pragma clang fp contract(off)
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-instruction IEEE division
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float half_erfc = 0.5f * poly * __expf(-z * z);           // erfc(z) / 2
-  return x * (x >= 0.f ? 1.f - half_erfc : half_erfc);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));   // v_rcp_f32 (1 ulp); __frcp_rn is a 10-instruction IEEE division
+  float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  p = __builtin_fmaf(t, p, 1.421413741f);
+  p = __builtin_fmaf(t, p, -0.284496736f);
+  p = __builtin_fmaf(t, p, 0.254829592f);
+  const float poly = t * p;
+  const float half_erfc = (0.5f * poly) * __expf(-(z * z));           // erfc(z) / 2
+  const float r = x >= 0.f ? 1.f - half_erfc : half_erfc;
+  return x * r;
 }
 
 __device__ __forceinline__ float ds2_act(float x, int act) {
