@@ -10,13 +10,15 @@
 // ds_read_b128 and the 16-lane read groups are conflict-free; V is stored TRANSPOSED [DV][32 keys] with the
 // keys permuted into the accumulator's own row order (mfma32_row), so the V^T operand of O^T = V^T P^T is
 // also one ds_read_b128 and P needs no cross-lane movement.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BQ = 128, BKEYS = 32, VROWB = 80;   // V^T row: 32 keys * 2 B + 16 B pad
+constexpr int BKEYS = 32, VROWB = 80;   // V^T row: 32 keys * 2 B + 16 B pad
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   unsigned r;
@@ -61,14 +63,17 @@ __device__ __forceinline__ int vt_pos(int key) {
 
 // D / DV are the true head dims (multiples of 4); the MFMA shapes need DP = D rounded up to 16 and DVP = DV
 // rounded up to 32: the pad columns/rows of the LDS images are zeroed once and never written again.
-template <int D, int DV>
-__global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
+// NW = waves per workgroup (32 queries each): 8 where the query count allows it - a K / V tile is fetched, split and staged
+// once per workgroup, so twice the queries per workgroup halve that work per query.
+template <int D, int DV, int NW>
+__global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
+  constexpr int NTHR = 64 * NW, BQ = 32 * NW;
   static_assert(D % 4 == 0 && DV % 4 == 0, "head dims must be multiples of 4");
   constexpr int DP = (D + 15) / 16 * 16, DVP = (DV + 31) / 32 * 32;
   constexpr int KS = DP / 16, NT = DVP / 32;
   constexpr int KROWB = DP * 2 + 16;                   // bytes per K row per plane
   constexpr int KPLANE = BKEYS * KROWB, VPLANE = DVP * VROWB;
-  constexpr int NK4 = (8 * D + 255) / 256, NV4 = (8 * DV + 255) / 256;
+  constexpr int NK4 = (8 * D + NTHR - 1) / NTHR, NV4 = (8 * DV + NTHR - 1) / NTHR;
   constexpr int QSLD = DP + 1;                          // fp32 Q staging row stride
   constexpr int QBYTES = 32 * QSLD * 4;
   constexpr int KBUF = 2 * KPLANE > QBYTES ? 2 * KPLANE : QBYTES;   // one K buffer doubles as the Q staging area
@@ -87,10 +92,10 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   bf16x8 q0[KS], q1[KS];
   {
     float* Qs = reinterpret_cast<float*>(&Kraw[0][0]);   // [32][DP+1] floats
-    for (int idx = tid; idx < 32 * QSLD; idx += 256) Qs[idx] = 0.f;   // pad columns D..DP stay zero
+    for (int idx = tid; idx < 32 * QSLD; idx += NTHR) Qs[idx] = 0.f;   // pad columns D..DP stay zero
     __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-      for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
+    for (int w = 0; w < NW; ++w) {
+      for (int idx = tid; idx < 32 * (D / 4); idx += NTHR) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
         const int qi = q0i + w * 32 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   auto load_k = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < NK4; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NTHR * i;
       rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < 8 * D) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   auto load_v = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NTHR * i;
       rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < 8 * DV) {
         const int r = idx / (DV / 4), c4 = idx - r * (DV / 4);
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   auto store_k = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NK4; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NTHR * i;
       if (idx < 8 * D) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
         uint2 hi, lo;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   auto store_v = [&](int buf) {   // transposed + key-permuted
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
-      const int idx = tid + 256 * i;
+      const int idx = tid + NTHR * i;
       if (idx < 8 * DV) {
         const int r = idx / (DV / 4), c4 = idx - r * (DV / 4);
         const int pos = vt_pos(r) * 2;
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
   };
 
   // zero the LDS images once: pad columns (D..DP of K rows) and pad rows (DV..DVP of V^T) are never written
-  for (int idx = tid; idx < 2 * KBUF / 4; idx += 256) reinterpret_cast<unsigned*>(&Kraw[0][0])[idx] = 0u;
-  for (int idx = tid; idx < 4 * VPLANE / 4; idx += 256) reinterpret_cast<unsigned*>(&Vp[0][0][0])[idx] = 0u;
+  for (int idx = tid; idx < 2 * KBUF / 4; idx += NTHR) reinterpret_cast<unsigned*>(&Kraw[0][0])[idx] = 0u;
+  for (int idx = tid; idx < 4 * VPLANE / 4; idx += NTHR) reinterpret_cast<unsigned*>(&Vp[0][0][0])[idx] = 0u;
   __syncthreads();
   const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
   load_k(0);
@@ -311,8 +316,14 @@ __global__ __launch_bounds__(256) void k_attention_bf16x3(AttnArgs a) {
 
 template <int D, int DV>
 int launch_t(const AttnArgs& a, hipStream_t st) {
-  dim3 grid(cdiv(a.Lq, BQ), a.heads, a.batch);
-  hipLaunchKernelGGL((k_attention_bf16x3<D, DV>), grid, dim3(256), 0, st, a);
+  static const bool w8_off = [] { const char* e = getenv("DS2_ATTN_HW8"); return e && atoi(e) == 0; }();
+  if (D <= 96 && a.Lq >= 256 && !w8_off) {
+    dim3 grid(cdiv(a.Lq, 256), a.heads, a.batch);
+    hipLaunchKernelGGL((k_attention_bf16x3<D, DV, (D <= 96 ? 8 : 4)>), grid, dim3(D <= 96 ? 512 : 256), 0, st, a);
+  } else {
+    dim3 grid(cdiv(a.Lq, 128), a.heads, a.batch);
+    hipLaunchKernelGGL((k_attention_bf16x3<D, DV, 4>), grid, dim3(256), 0, st, a);
+  }
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
