@@ -41,6 +41,20 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1) {
   p1 = __builtin_bit_cast(bf16x8, l);
 }
 
+// DS2_ATT_TRACE (profiling builds only): wave 0 / 4 of workgroup (0,0,0) stamp s_memtime along their key tiles; =1 traces the
+// global-attention launches (Lk = 4096), =2 the 256-key window launches (tools/att_trace.py)
+#ifdef DS2_ATT_TRACE
+__device__ unsigned long long g_att_trace[2][512];
+#define ATT_T()                                                                                     \
+  if (trace_on && tix < 512) {                                                                      \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                     \
+    if (lane == 0) g_att_trace[wave >> 2][tix] = t_;                                                \
+    ++tix;                                                                                          \
+  }
+#else
+#define ATT_T()
+#endif
+
 struct RowMap {
   int win, H, W, nwx, L, wins;
   __device__ __forceinline__ long row(int b, int i) const {
@@ -129,35 +143,68 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   float4 rk[NK4], rv[NV4];
-  auto load_k = [&](int kt) {
+  // Key rows.  The tiles are fetched in order, so each staging slot keeps a cursor (key index + position inside the key
+  // window) that advances by one tile per fetch: no divisions in the loop (RowMap::row costs four per key; the trace of
+  // tools/att_trace.py showed the address arithmetic of the fetches at 30-50 % of a windowed tile).
+  struct KeyCur { int ki, ly, lx; };
+  long kw_base = 0;
+  int kw_y0 = 0, kw_x0 = 0;
+  if (km.win > 0) {
+    int bw = b;
+    if (km.wins > 0) { const int img = b / km.wins; bw = b - img * km.wins; kw_base = (long)img * km.H * km.W; }
+    const int wy = bw / km.nwx, wx = bw - wy * km.nwx;
+    kw_y0 = wy * km.win; kw_x0 = wx * km.win;
+  }
+  const int kw_dy = km.win > 0 ? BKEYS / km.win : 0, kw_dx = km.win > 0 ? BKEYS % km.win : 0;
+  auto cur_init = [&](int r) {
+    KeyCur c{r, 0, 0};
+    if (km.win > 0) { c.ly = r / km.win; c.lx = r - c.ly * km.win; }
+    return c;
+  };
+  auto cur_row = [&](const KeyCur& c) -> long {   // = km.row(b, c.ki)
+    if (km.win == 0) return (long)b * km.L + c.ki;
+    const int y = kw_y0 + c.ly, x = kw_x0 + c.lx;
+    return (y < km.H && x < km.W) ? kw_base + (long)y * km.W + x : -1;
+  };
+  auto cur_next = [&](KeyCur& c) {
+    c.ki += BKEYS;
+    c.ly += kw_dy; c.lx += kw_dx;
+    if (km.win > 0 && c.lx >= km.win) { c.lx -= km.win; ++c.ly; }
+  };
+  KeyCur kcur[NK4], vcur[NV4];
+#pragma unroll
+  for (int i = 0; i < NK4; ++i) kcur[i] = cur_init((tid + NTHR * i) / (D / 4));
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) vcur[i] = cur_init((tid + NTHR * i) / (DV / 4));
+  auto load_k = [&](int) {   // fetches the NEXT tile of the sequence 0, 1, 2, ...
 #pragma unroll
     for (int i = 0; i < NK4; ++i) {
       const int idx = tid + NTHR * i;
       rk[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < 8 * D) {
-        const int r = idx / (D / 4), c4 = idx - r * (D / 4);
-        const int ki = kt * BKEYS + r;
-        if (ki < a.Lk) {
-          const long row = km.row(b, ki);
+        const int c4 = idx % (D / 4);
+        if (kcur[i].ki < a.Lk) {
+          const long row = cur_row(kcur[i]);
           const float* p = row >= 0 ? a.k + row * a.ldk + h * D : (a.k_pad ? a.k_pad + h * D : nullptr);
           if (p) rk[i] = *reinterpret_cast<const float4*>(p + c4 * 4);
         }
+        cur_next(kcur[i]);
       }
     }
   };
-  auto load_v = [&](int kt) {
+  auto load_v = [&](int) {
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
       const int idx = tid + NTHR * i;
       rv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < 8 * DV) {
-        const int r = idx / (DV / 4), c4 = idx - r * (DV / 4);
-        const int ki = kt * BKEYS + r;
-        if (ki < a.Lk) {
-          const long row = km.row(b, ki);
+        const int c4 = idx % (DV / 4);
+        if (vcur[i].ki < a.Lk) {
+          const long row = cur_row(vcur[i]);
           const float* p = row >= 0 ? a.v + row * a.ldv + h * DV : (a.v_pad ? a.v_pad + h * DV : nullptr);
           if (p) rv[i] = *reinterpret_cast<const float4*>(p + c4 * 4);
         }
+        cur_next(vcur[i]);
       }
     }
   };
@@ -209,8 +256,15 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
   store_v(0);
   __syncthreads();
   int cur = 0;
+#ifdef DS2_ATT_TRACE
+  int tix = 0;
+  const bool trace_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && D == 72 &&
+                        a.Lk == (DS2_ATT_TRACE == 1 ? 4096 : 256);
+#endif
   for (int kt = 0; kt < nkt; ++kt) {
+    ATT_T()   // 0: tile start
     if (kt + 1 < nkt) load_k(kt + 1);
+    ATT_T()   // 1: K loads issued
     f32x16 acc;
     bf16x8 pb0[2], pb1[2];
     float alpha = 1.f;
@@ -229,6 +283,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0[ks], acc, 0, 0, 0);
       }
+      ATT_T()   // 2: QK MFMAs issued
       float tmax = -INFINITY;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -251,10 +306,12 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
       split8(p, pb0[0], pb1[0]);
       split8(p + 8, pb0[1], pb1[1]);
     }
+    ATT_T()   // 3: softmax + P split done
     if (kt + 1 < nkt) {
       store_k(cur ^ 1);
       load_v(kt + 1);
     }
+    ATT_T()   // 4: K staged, V loads issued
     if (wave_active) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -272,7 +329,9 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
         }
       }
     }
+    ATT_T()   // 5: PV MFMAs issued
     if (kt + 1 < nkt) store_v(cur ^ 1);
+    ATT_T()   // 6: V staged
     __syncthreads();
     cur ^= 1;
   }
@@ -329,6 +388,12 @@ int launch_t(const AttnArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef DS2_ATT_TRACE
+extern "C" int ds2_debug_att_trace(unsigned long long* out) {   // [2][512] host buffer
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_trace), sizeof(unsigned long long) * 2 * 512) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // Returns DS2_ERR_UNSUPPORTED (without setting an error) for head dims that have no bf16x3 kernel yet;
 // the caller then uses the exact-fp32 kernel.
