@@ -37,7 +37,7 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3k": 2500.0}
 DTYPE = {"fp32": "f32",
          "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
          "bf16x3k": "bf16x3k (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product; the memory-attention SCORES are "
-                    "plain bf16 x bf16 products; fp32 accumulate/softmax/storage)"}
+                    "plain bf16 x bf16 products and its softmax weights one bf16 plane in P.V; fp32 accumulate/softmax/storage)"}
 
 
 def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
@@ -377,8 +377,8 @@ def main():
                          "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
                          "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
                          "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time; "
-                                 "executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 (frac <= 1/3), bf16x3k 1.2 (one-term scores, "
-                                 "two-term P.V on the bf16-stored frame tokens)"},
+                                 "executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 (frac <= 1/3), bf16x3k 1.0 (one-term scores, "
+                                 "one-term P.V on the bf16-stored frame tokens)"},
             "ms_per_step_by_stage": stage_ms,
         }
         if gemm is not None:

@@ -121,8 +121,9 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& g, hipStream_t st);          // exact fp32 MFMA
 
 // arithmetic mode of the matrix-core kernels (ds2_set_precision)
-// BF16X3K = BF16X3 everywhere except the SCORES of the memory attention (cross + self): plain bf16 x bf16 products (keys
-// and queries as one bf16 plane each, fp32 accumulation) - see DESIGN.md "precision margin"
+// BF16X3K = BF16X3 everywhere except the memory attention (cross + self): its SCORES are plain bf16 x bf16 products (keys and
+// queries as one bf16 plane each, fp32 accumulation) and its softmax weights enter P.V as one bf16 plane - see DESIGN.md
+// "precision margin"
 enum { DS2_PREC_FP32 = 0, DS2_PREC_BF16X3 = 1, DS2_PREC_BF16X3K = 2 };
 extern int g_ds2_precision;
 static inline bool ds2_split_mode() { return g_ds2_precision != DS2_PREC_FP32; }

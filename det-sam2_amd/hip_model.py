@@ -44,7 +44,7 @@ class HipOps:
 
     def set_precision(self, mode: str):
         """'fp32' (exact fp32 MFMA), 'bf16x3' (split-precision bf16 MFMA: three product terms everywhere) or 'bf16x3k'
-        (default: bf16x3, with the memory-attention SCORES as plain bf16 x bf16 products, fp32 accumulate)."""
+        (default: bf16x3, with the memory-attention scores as plain bf16 x bf16 products and its softmax weights as one bf16 plane)."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {self.PRECISIONS}, got {mode!r}")
         _capi.check(self.lib.ds2_set_precision(self.PRECISIONS.index(mode)), "ds2_set_precision")

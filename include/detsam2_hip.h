@@ -181,10 +181,11 @@ int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, i
  *  0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
  *  1 = split-precision bf16x3: x = x0 + x1 in bf16, a0b0 + a0b1 + a1b0 with fp32 accumulation, ~2^-16 relative error
  *      per product;
- *  2 = bf16x3k (default): as 1, except that the SCORE products of the memory attention (cross and self attention,
- *      sam/transformer.py:312-363) are plain bf16 x bf16 with fp32 accumulation - q.k = q0 k0, 1 term - which removes two
- *      thirds of the score MFMAs and the key lo plane from HBM and LDS; softmax is fp32 and P.V split-precision as in 1.
- *      Passes the precision gate recorded in DESIGN.md (every reference golden <= 5e-4 in 1 - IoU).
+ *  2 = bf16x3k (default): as 1, except inside the memory attention (cross and self attention,
+ *      sam/transformer.py:312-363): the SCORE products are plain bf16 x bf16 with fp32 accumulation - q.k = q0 k0, 1 term -
+ *      and the softmax weights (computed and summed in fp32) enter the P.V product rounded to one bf16 plane.  This removes
+ *      two thirds of the score MFMAs, a third of the P.V MFMAs and the key lo plane from HBM and LDS.  Passes the precision
+ *      gate recorded in DESIGN.md (every reference golden <= 5e-4 in 1 - IoU).
  * Softmax, LayerNorm, residuals and all storage stay fp32 in every mode. */
 int ds2_set_precision(int32_t mode);
 int ds2_get_precision(void);
