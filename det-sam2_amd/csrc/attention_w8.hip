@@ -125,7 +125,8 @@ struct W8Args {
 // KLO = false ("bf16x3k" arithmetic mode): the SCORES are plain bf16 x bf16 products with fp32 accumulation - keys and
 // queries each carried as their hi plane only: 1 MFMA term instead of 3 in Q.K^T, no K lo plane in HBM / LDS - and the
 // softmax weights P (in [0, 1], computed, maximum-tracked and summed in fp32) enter P.V rounded to ONE bf16 plane: the V . P_lo
-// term is dropped, V keeps both planes where its lo plane is not identically zero.  Both accepted by the precision gate of
+// term is dropped; the values of the SELF-attention (DV = 256) are one plane too, the cross-attention's keep both where the
+// lo plane is not identically zero (the object-pointer tokens).  All accepted by the precision gate of
 // DESIGN.md (every reference golden <= 5e-4 in 1 - IoU: worst 1.3e-4).
 template <int DV, int QG, bool KLO>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                               \
     }                                                                         \
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j)                          \
-      if (DV != 64 || kt_ >= n_hi || tid < 256) rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; /* DV=64: threads >= 256 stage the lo plane */ \
+      if ((DV != 64 || kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) /* DV=64: threads >= 256 stage the lo plane; DV=256 in bf16x3k: no lo plane */ \
+        rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; \
   }
 #define W8_STORE(BUF, STKT)                                                   \
   {                                                                           \
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j) {                        \
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
-      if (DV != 64 || st_kt_ >= n_hi || tid < 256)                            \
+      if ((DV != 64 || st_kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) \
         *reinterpret_cast<uint4*>(&Vp[BUF][pl_][rw_ * VROWB + pt_ * 16]) = rv[j]; \
     }                                                                         \
   }
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
         const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-          o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
+          if (KLO) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);   // (self-attention in bf16x3k: V as one plane too)
           if (KLO) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
           o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0[g], o[g][t], 0, 0, 0);
         }

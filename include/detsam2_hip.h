@@ -183,7 +183,8 @@ int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, i
  *      per product;
  *  2 = bf16x3k (default): as 1, except inside the memory attention (cross and self attention,
  *      sam/transformer.py:312-363): the SCORE products are plain bf16 x bf16 with fp32 accumulation - q.k = q0 k0, 1 term -
- *      and the softmax weights (computed and summed in fp32) enter the P.V product rounded to one bf16 plane.  This removes
+ *      and the softmax weights (computed and summed in fp32) enter the P.V product rounded to one bf16 plane, as do
+ *      the values of the self-attention.  This removes
  *      two thirds of the score MFMAs, a third of the P.V MFMAs and the key lo plane from HBM and LDS.  Passes the precision
  *      gate recorded in DESIGN.md (every reference golden <= 5e-4 in 1 - IoU).
  * Softmax, LayerNorm, residuals and all storage stay fp32 in every mode. */
