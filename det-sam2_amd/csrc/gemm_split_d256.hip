@@ -172,11 +172,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     // flight); tile kt+1 in flight into s1 (issued one step ago)
     // (the first MFMA term goes ahead of the sub-step-1 reads: hipcc guards the first use of F0 with lgkmcnt(0), which
     // would otherwise also wait for the twelve reads just issued)
-    if (!DS2_EXP_GEMM2A) D2_MFMA_TERM(F0, al, bh)
+    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) D2_MFMA_TERM(F0, al, bh)
     __builtin_amdgcn_sched_barrier(0);
     D2_READ(F1, s0, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (!DS2_EXP_GEMM2W) D2_MFMA_TERM(F0, ah, bl)
+    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) D2_MFMA_TERM(F0, ah, bl)
     D2_MFMA_TERM(F0, ah, bh)
     __builtin_amdgcn_sched_barrier(0);
     // F1 landed => this wave no longer reads stage s0; its own pieces of tile kt+1 landed.  After the barrier: stage s0
@@ -188,11 +188,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     D2_FILL(kt + 2, s0)
     D2_TOUCH(kt + 2)
     __builtin_amdgcn_sched_barrier(0);
-    if (!DS2_EXP_GEMM2A) D2_MFMA_TERM(F1, al, bh)
+    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) D2_MFMA_TERM(F1, al, bh)
     __builtin_amdgcn_sched_barrier(0);
     D2_READ(F0, s1, 0)
     __builtin_amdgcn_sched_barrier(0);
-    if (!DS2_EXP_GEMM2W) D2_MFMA_TERM(F1, ah, bl)
+    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) D2_MFMA_TERM(F1, ah, bl)
     D2_MFMA_TERM(F1, ah, bh)
     const int t_ = s0; s0 = s1; s1 = t_;
     if (DS2_ABL_NOREAD && kt >= 1) kt_first = false;

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
         const unsigned char* wp = lds + (t * 32 + l31) * WROWB + coff;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + WPL);
-        acc[t] = DS2_MFMA_IF(!DS2_EXP_GEMM2A, acc[t], F.l[s], bh);
-        acc[t] = DS2_MFMA_IF(!DS2_EXP_GEMM2W, acc[t], F.h[s], bl);
+        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2A || (g.drop_terms & 1)), acc[t], F.l[s], bh);
+        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2W || (g.drop_terms & 2)), acc[t], F.h[s], bl);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bh, acc[t], 0, 0, 0);
       }
     }

@@ -171,10 +171,12 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_pp256(GemmSplitArgs g, in
   }
 #define PP_MFMA(qm, qn, F)                                                                                      \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                               \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
-      acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[t][s], F.h[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
-      acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[t][s], F.l[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
+    if (!(g.drop_terms & 1))                                                                                    \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
+        acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[t][s], F.h[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
+    if (!(g.drop_terms & 2))                                                                                    \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
+        acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[t][s], F.l[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
       acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[t][s], F.h[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
   }

@@ -123,17 +123,17 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
     R3_READ(F1, s0, 1)
     R3_FILL(kt + 2, s2)
     __builtin_amdgcn_sched_barrier(0);
-    if (!DS2_EXP_GEMM2A) R3_MFMA_TERM(F0, al, bh)
-    if (!DS2_EXP_GEMM2W) R3_MFMA_TERM(F0, ah, bl)
+    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F0, al, bh)
+    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F0, ah, bl)
     R3_MFMA_TERM(F0, ah, bh)
-    if (!DS2_EXP_GEMM2A) R3_MFMA_TERM(F1, al, bh)
+    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F1, al, bh)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 landed; tile kt+2's 6 pieces stay in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     R3_READ(F0, s1, 0)
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's first reads AHEAD of the trailing MFMAs
-    if (!DS2_EXP_GEMM2W) R3_MFMA_TERM(F1, ah, bl)
+    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F1, ah, bl)
     R3_MFMA_TERM(F1, ah, bh)
     const int t_ = s0; s0 = s1; s1 = s2; s2 = t_;
   }

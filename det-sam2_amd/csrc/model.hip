@@ -258,6 +258,16 @@ static int new_act_planes(ds2_model* m, const void* key, int rows, int cols, ds2
 // C = act(A W^T + bias) * gamma + R.   bf16x3 mode: A is taken from registered planes when its producer emitted
 // them (else split by a pre-pass); with planes_out the result is emitted as planes registered under key C and
 // the fp32 buffer C is NOT written (its only consumers must be GEMMs).
+// precision experiment scope (DS2_EXP_MA_DROP=1|2|3): GEMMs issued while this is non-zero drop product terms (GemmSplitArgs)
+static thread_local int g_gemm_drop_terms = 0;
+struct GemmDropScope {
+  int prev;
+  explicit GemmDropScope(const char* env) : prev(g_gemm_drop_terms) {
+    const char* e = getenv(env);
+    if (e) g_gemm_drop_terms = atoi(e);
+  }
+  ~GemmDropScope() { g_gemm_drop_terms = prev; }
+};
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
                 const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false,
@@ -318,6 +328,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   g.A_hi = ahi; g.A_lo = alo; g.lda = a_ld;
   g.W_hi = wp.hi; g.W_lo = wp.lo; g.ldw = wp.ld;
   g.bias = bias; g.C = C; g.ldc = ldc; g.act = act; g.gamma = gamma; g.R = R; g.ldr = ldr; g.r_mod = r_mod;
+  g.drop_terms = g_gemm_drop_terms;
   if (planes_out && m) {
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, C, M, N, &op, st));
@@ -758,6 +769,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   DS2_REQUIRE(m && m->finalized && B > 0 && curr && memory && memory_pos && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
               "ds2_memory_attention: bad argument");
   DeviceGuard _dg(m->device);
+  GemmDropScope _gds("DS2_EXP_MA_DROP");
   // the layer-0 self-attention is shared by the B objects only when they all see the same tokens AND positions
   const bool shared0 = curr_shared && (curr_pos == nullptr || pos_shared);
   DS2_REQUIRE((Nk - n_ptr_tok) % TOK == 0, "ds2_memory_attention: Nk - num_obj_ptr_tokens must be a multiple of 4096");

@@ -124,11 +124,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_q256(GemmSplitArgs g, int
   {                                                                                            \
     Q2_FILL((t) + 4)                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if (!DS2_EXP_GEMM2A) Q2_MFMA_TERM(FA, al, bh)                                              \
+    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) Q2_MFMA_TERM(FA, al, bh)                                              \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     Q2_READ(FB, (t) + 1)                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                         \
-    if (!DS2_EXP_GEMM2W) Q2_MFMA_TERM(FA, ah, bl)                                              \
+    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) Q2_MFMA_TERM(FA, ah, bl)                                              \
     Q2_MFMA_TERM(FA, ah, bh)                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     /* slice t+2 landed (this wave's pieces; the 8 pieces of t+3, t+4 may fly on), FB landed */\
