@@ -92,20 +92,6 @@ __global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v,
   }
 }
 
-// DS2_W8_TRACE (profiling builds only): waves 0 / 4 of workgroup 0 of the cross-attention launches (DV = 64, QG = 2) stamp
-// s_memtime along their key tiles (tools/w8_trace.py)
-#ifdef DS2_W8_TRACE
-__device__ unsigned long long g_w8_trace[2][512];
-#define W8_T()                                                                                      \
-  if (trace_on && tix < 512) {                                                                      \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                     \
-    if (lane == 0) g_w8_trace[wave >> 2][tix] = t_;                                                 \
-    ++tix;                                                                                          \
-  }
-#else
-#define W8_T()
-#endif
-
 struct W8Args {
   const float* q; int ldq;
   const uint4* k_hi; const uint4* k_lo;
@@ -133,8 +119,19 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int BQ = 128 * QG;
   constexpr int VROWB = DV >= 256 ? VROWB_NARROW : VROWB_WIDE;
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
+  // STAG (experiment, -DDS2_W8_STAG=1, cross-attention in bf16x3k only): waves 4-7 run half a tile behind waves 0-3 - per
+  // barrier interval the leading group does [scores of tile t, softmax, P.V], the lagging group [softmax + P.V of tile t-1,
+  // scores of tile t], three V buffers - so that on every SIMD one wave is in a matrix segment while its partner is in the
+  // softmax (VALU) segment.  Bit-identical, but 4 % SLOWER in one call (1.37 vs 1.32 ms per launch,
+  // profiles/r02an_ab_stag.txt): the phases of the two waves of a SIMD evidently do not coincide the way the per-wave
+  // s_memtime stamps suggested; off by default.
+#ifndef DS2_W8_STAG
+#define DS2_W8_STAG 0
+#endif
+  constexpr bool STAG = DS2_W8_STAG && !KLO && DV == 64;
+  constexpr int NVB = STAG ? 3 : 2, VPL = (DV == 256 && !KLO) ? 1 : 2;
   __shared__ __attribute__((aligned(16))) unsigned char Kp[2][KLO ? 2 : 1][KPLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Vp[2][2][VPLANE];
+  __shared__ __attribute__((aligned(16))) unsigned char Vp[NVB][VPL][VPLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
@@ -214,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       if ((DV != 64 || kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) /* DV=64: threads >= 256 stage the lo plane; DV=256 in bf16x3k: no lo plane */ \
         rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; \
   }
-#define W8_STORE(BUF, STKT)                                                   \
+#define W8_STORE(BUF, VBUF, STKT)                                             \
   {                                                                           \
     const int st_kt_ = (STKT);                                                \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso0]) = rk0;                       \
@@ -227,28 +224,17 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
       if ((DV != 64 || st_kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) \
-        *reinterpret_cast<uint4*>(&Vp[BUF][pl_][rw_ * VROWB + pt_ * 16]) = rv[j]; \
+        *reinterpret_cast<uint4*>(&Vp[VBUF][pl_ < VPL ? pl_ : 0][rw_ * VROWB + pt_ * 16]) = rv[j]; \
     }                                                                         \
   }
 
-  W8_LOAD(0)
-  W8_STORE(0, 0)
-  __syncthreads();
-  int cur = 0;
-#ifdef DS2_W8_TRACE
-  int tix = 0;
-  const bool trace_on = blockIdx.x == 0 && (wave & 3) == 0 && DV == 64 && QG == 2 && a.Lk > 20000;
-#endif
-  for (int kt = 0; kt < nkt; ++kt) {
-    W8_T()   // 0: tile start
-    W8_LOAD(kt + 1 < nkt ? kt + 1 : kt)
-    W8_T()   // 1: loads issued
-    // ---- S^T = K Q^T for the two 16-key blocks of the tile (each K fragment serves QG query groups)
-    f32x4 s0[QG], s1[QG];
+  f32x4 s0[QG], s1[QG];   // scores of the current tile (they cross the barrier in the lagging group)
+  // ---- S^T = K Q^T for the two 16-key blocks of tile kt_ in K buffer kb (each K fragment serves QG query groups)
+  auto scores = [&](int kb, int kt_) {
 #pragma unroll
     for (int g = 0; g < QG; ++g) { s0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const unsigned char* kp0 = &Kp[cur][0][l15 * KROWB + grp * 16];
-    const unsigned char* kp1 = &Kp[cur][KLO ? 1 : 0][l15 * KROWB + grp * 16];
+    const unsigned char* kp0 = &Kp[kb][0][l15 * KROWB + grp * 16];
+    const unsigned char* kp1 = &Kp[kb][KLO ? 1 : 0][l15 * KROWB + grp * 16];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + ks * 64);
@@ -261,29 +247,31 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
           s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[g][ks], s0[g], 0, 0, 0);
           s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, q0[g][ks], s1[g], 0, 0, 0);
         }
-      }
 #pragma unroll
-      for (int g = 0; g < QG; ++g) {
-        if (!KLO) break;     // bf16x3k: the queries of the scores are one bf16 plane too (q_hi . k_hi only)
-        s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q1[g][ks], s0[g], 0, 0, 0);
-        s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[g][ks], s1[g], 0, 0, 0);
+        for (int g = 0; g < QG; ++g) {
+          s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q1[g][ks], s0[g], 0, 0, 0);
+          s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[g][ks], s1[g], 0, 0, 0);
+        }
       }
+      // (bf16x3k: the queries of the scores are one bf16 plane too - q_hi . k_hi only)
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
         s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q0[g][ks], s0[g], 0, 0, 0);
         s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q0[g][ks], s1[g], 0, 0, 0);
       }
     }
-    W8_T()   // 2: QK MFMAs issued
-    if (kt == nkt - 1) {   // keys >= Lk only exist in the last tile; lane holds keys 4*grp + r (+16)
+    if (kt_ == nkt - 1) {   // keys >= Lk only exist in the last tile; lane holds keys 4*grp + r (+16)
 #pragma unroll
       for (int g = 0; g < QG; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (kt * BKEYS + 4 * grp + r >= a.Lk) s0[g][r] = -INFINITY;
-          if (kt * BKEYS + 16 + 4 * grp + r >= a.Lk) s1[g][r] = -INFINITY;
+          if (kt_ * BKEYS + 4 * grp + r >= a.Lk) s0[g][r] = -INFINITY;
+          if (kt_ * BKEYS + 16 + 4 * grp + r >= a.Lk) s1[g][r] = -INFINITY;
         }
     }
+  };
+  // ---- online softmax of the scores in s0 / s1, then O^T += V^T P^T with tile kt_ in V buffer vb
+  auto softmax_pv = [&](int vb, int kt_) {
     bf16x8 pb0[QG], pb1[QG];
     float alpha[QG];
 #pragma unroll
@@ -300,11 +288,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       m_run[g] = m_new;
       split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0[g], pb1[g]);
     }
-    W8_T()   // 3: softmax done
-    // ---- O^T += V^T P^T : one 32-key MFMA k-step per 16-row dv block (each V^T fragment serves QG groups).
-    // The running-max rescale is skipped when no lane of the wave raised its maximum (alpha == 1 exactly; after the
-    // first ~100 key tiles that is the common case), and the three product terms are issued term-major so that
-    // consecutive MFMAs never target the same accumulator.
+    // One 32-key MFMA k-step per 16-row dv block (each V^T fragment serves QG groups).  The running-max rescale is
+    // skipped when no lane of the wave raised its maximum (alpha == 1 exactly; after the first ~100 key tiles that is the
+    // common case), and the product terms are issued term-major so that consecutive MFMAs never target the same accumulator.
 #pragma unroll
     for (int g = 0; g < QG; ++g)
       if (__any(alpha[g] != 1.f)) {
@@ -314,10 +300,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     if constexpr (NT <= 4) {
       bf16x8 v0[NT], v1[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
-      if (kt >= n_hi) {   // V lo plane present: third product term
+      for (int t = 0; t < NT; ++t) v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
+      if (kt_ >= n_hi) {   // V lo plane present: third product term
 #pragma unroll
-        for (int t = 0; t < NT; ++t) v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+        for (int t = 0; t < NT; ++t) v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][VPL - 1][(t * 16 + l15) * VROWB + grp * 16]);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -336,22 +322,40 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[cur][0][(t * 16 + l15) * VROWB + grp * 16]);
-        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[cur][1][(t * 16 + l15) * VROWB + grp * 16]);
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-          if (KLO) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);   // (self-attention in bf16x3k: V as one plane too)
-          if (KLO) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
+          if constexpr (KLO) {   // (self-attention in bf16x3k: V as one plane too)
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[vb][VPL - 1][(t * 16 + l15) * VROWB + grp * 16]);
+            o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
+            o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
+          }
           o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0[g], o[g][t], 0, 0, 0);
         }
       }
     }
-    W8_T()   // 4: PV MFMAs issued
-    W8_STORE(cur ^ 1, (kt + 1 < nkt ? kt + 1 : kt))
-    W8_T()   // 5: next tile staged
+  };
+
+  W8_LOAD(0)
+  W8_STORE(0, 0, 0)
+  __syncthreads();
+  const bool lag = STAG && wave >= 4;
+  int vb_prev = NVB - 1, vb_cur = 0, vb_next = 1;   // V buffers of tiles kt-1, kt, kt+1 (kt mod NVB, without the division)
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int nxt = kt + 1 < nkt ? kt + 1 : kt;
+    W8_LOAD(nxt)
+    if (!lag) {
+      scores(kt & 1, kt);
+      softmax_pv(vb_cur, kt);
+    } else {
+      if (kt > 0) softmax_pv(vb_prev, kt - 1);
+      scores(kt & 1, kt);
+    }
+    W8_STORE((kt + 1) & 1, vb_next, nxt)
     __syncthreads();
-    cur ^= 1;
+    vb_prev = vb_cur; vb_cur = vb_next; vb_next = vb_next + 1 == NVB ? 0 : vb_next + 1;
   }
+  if (lag) softmax_pv(vb_prev, nkt - 1);   // (its V buffer was last written two intervals ago: nothing to wait for)
 
 #pragma unroll
   for (int g = 0; g < QG; ++g) {
@@ -382,11 +386,6 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 
 }  // namespace
 
-#ifdef DS2_W8_TRACE
-extern "C" int ds2_debug_w8_trace(unsigned long long* out) {   // [2][512] host buffer
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w8_trace), sizeof(unsigned long long) * 2 * 512) == hipSuccess ? 0 : 1;
-}
-#endif
 
 int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys, int* flag) {
   DS2_REQUIRE(dv == 64 || dv == 128 || dv == 256, "vt_split16: dv must be 64, 128 or 256");
