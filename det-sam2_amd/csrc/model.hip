@@ -678,9 +678,15 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
     ALLOC(t2, (size_t)hwq * b.dim_out);
     TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f, DS2_ACT_NONE, true));
     ALLOC(h, (size_t)hwq * 4 * b.dim_out);
-    TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU,
-               nullptr, 0, 0, nullptr, true));   // hidden activations only feed mlp.layers.1: planes only
-    TRY(linear(m, st, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, h, 4 * b.dim_out, xn, b.dim_out, DS2_ACT_NONE, xn, b.dim_out));
+    {
+      GemmDropScope _d1("DS2_EXP_FC1_DROP");
+      TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU,
+                 nullptr, 0, 0, nullptr, true));   // hidden activations only feed mlp.layers.1: planes only
+    }
+    {
+      GemmDropScope _d2("DS2_EXP_FC2_DROP");
+      TRY(linear(m, st, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, h, 4 * b.dim_out, xn, b.dim_out, DS2_ACT_NONE, xn, b.dim_out));
+    }
     m->release(mark);
     x = xn;
     side = side_q;
