@@ -103,6 +103,9 @@ struct W8Args {
   // key tiles [0, n_hi_tiles) have an all-zero V lo plane unless *vlo_flag != 0 (k_vt_split16): their P.V product
   // needs two MFMA terms instead of three and no lo-plane staging.  n_hi_tiles == 0 disables the fast path.
   int n_hi_tiles; const int* vlo_flag;
+  // optional: apply_rotary_enc (position_encoding.py:196-220) to the queries while they are loaded (query t of a batch item
+  // is rotated with cis[t % rope_grid]) - replaces a separate in-place k_rope pass over q
+  const float* rope_cis; int rope_grid;
 };
 
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
@@ -152,7 +155,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     for (int r4 = 0; r4 < BQ / 32; ++r4) {
       for (int idx = tid; idx < 32 * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
-        const float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
+        float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
+        if (a.rope_cis) {   // complex pairs (4 c4, 4 c4 + 1), (4 c4 + 2, 4 c4 + 3): same expression as k_rope
+          const int t = (q0i + r4 * 32 + r) % a.rope_grid;
+          const float4 c = *reinterpret_cast<const float4*>(a.rope_cis + ((size_t)t * 128 + c4 * 2) * 2);
+          v = make_float4(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x, v.z * c.z - v.w * c.w, v.z * c.w + v.w * c.z);
+        }
         float* dst = Qs + r * (D + 1) + c4 * 4;
         dst[0] = v.x * sc; dst[1] = v.y * sc; dst[2] = v.z * sc; dst[3] = v.w * sc;
       }
@@ -406,7 +414,7 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
-                        int n_exact_keys, const int* vlo_flag) {
+                        int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid) {
   const bool klo = g_ds2_precision != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
@@ -414,7 +422,8 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
-           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag};
+           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid};
+  DS2_REQUIRE(!q_rope_cis || q_rope_grid > 0, "attention_w8: rope grid");
   DS2_REQUIRE(o || o_hi, "attention_w8: no output");
   DS2_REQUIRE(klo ? (k_lo != nullptr) : true, "attention_w8: the K lo plane is required in bf16x3 mode");
   if (dv == 64 && !qg1) {

@@ -848,7 +848,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     const float* xin = once ? x1 : x;
     TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
-    TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));
+    if (!(split && use_w8())) TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));   // (the 8-wave kernel rotates q while loading it)
     if (split) {
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st));
       ProfScope _p("kernel.self_attention", st);
@@ -857,7 +857,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       if (use_w8()) {   // all 256 value columns in one pass
         TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));
         TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
-                                sa_p.lo, sa_p.ld));
+                                sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK));
       } else {          // four 64-column passes
         for (int c = 0; c < 4; ++c) {
           void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 8192;
@@ -886,7 +886,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     m->act_planes.erase(a);   // self-attention planes are consumed; `a` is re-used below
     TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
-    TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
+    if (!(split && use_w8())) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     if (split) {
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
       TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
@@ -899,7 +899,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
         ds2_model::ActPlanes cp;
         TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
         TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
-                                Nk - n_ptr_tok, vlo_flag));
+                                Nk - n_ptr_tok, vlo_flag, cis, TOK));
       } else {
         TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
       }
