@@ -105,7 +105,7 @@ struct W8Args {
   int n_hi_tiles; const int* vlo_flag;
   // optional: apply_rotary_enc (position_encoding.py:196-220) to the queries while they are loaded (query t of a batch item
   // is rotated with cis[t % rope_grid]) - replaces a separate in-place k_rope pass over q
-  const float* rope_cis; int rope_grid;
+  const float* rope_cis; int rope_grid, rope_w;   // rope_w > 0: compact table rows (GemmSplitArgs::rope_w)
 };
 
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
@@ -157,7 +157,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
         float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
         if (a.rope_cis) {   // complex pairs (4 c4, 4 c4 + 1), (4 c4 + 2, 4 c4 + 3): same expression as k_rope
-          const int t = (q0i + r4 * 32 + r) % a.rope_grid;
+          int t = (q0i + r4 * 32 + r) % a.rope_grid;
+          if (a.rope_w > 0) t = c4 * 2 < 64 ? t % a.rope_w : t - t % a.rope_w;   // pairs < 64 depend on x only, the others on y
           const float4 c = *reinterpret_cast<const float4*>(a.rope_cis + ((size_t)t * 128 + c4 * 2) * 2);
           v = make_float4(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x, v.z * c.z - v.w * c.w, v.z * c.w + v.w * c.z);
         }
@@ -422,7 +423,9 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
-           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid};
+           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0};
+  for (int w = 1; w * w <= q_rope_grid; ++w)
+    if (w * w == q_rope_grid) a.rope_w = w;   // square axial grid (compute_axial_cis with end_x = end_y)
   DS2_REQUIRE(!q_rope_cis || q_rope_grid > 0, "attention_w8: rope grid");
   DS2_REQUIRE(o || o_hi, "attention_w8: no output");
   DS2_REQUIRE(klo ? (k_lo != nullptr) : true, "attention_w8: the K lo plane is required in bf16x3 mode");
