@@ -345,6 +345,12 @@ int heuristic_tile(const GemmSplitArgs& g) {
   // keeps the one-tile-per-workgroup kernel for A/B runs)
   static const bool pp256 = [] { const char* e = getenv("DS2_GEMM_PP256"); return !(e && atoi(e) == 0); }();
   if ((tile == 5 || tile == 9) && pp256 && gemm_split_pp256_supported(g)) tile = 10;
+  // ... and it also beats the 256x128 ring wherever that one was chosen for its smaller column padding: the GEMMs of Hiera
+  // stages 1-2 (K = 144 / 288: five to nine K tiles, i.e. mostly epilogue) run 10-25 % faster persistent
+  // (profiles/r02at_tile_time_s12.txt)
+  if (tile == 3 && pp256 && gemm_split_pp256_supported(g) && b256 >= 256 && ncols > 128 &&
+      (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32))
+    tile = 10;
   return tile;
 }
 
