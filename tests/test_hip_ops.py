@@ -32,6 +32,7 @@ def ops(request):
     (300, 256, 576, 1, True, 100, True),
     (4096, 768, 256, 0, False, 0, False),
     (70000, 1152, 288, 2, False, 0, False),      # 256x256 LDS-DMA kernel (k_gemm_split_d256), ragged M and N tiles
+    (66000, 432, 144, 2, False, 0, True),        # persistent 256x256 kernel (k_gemm_split_pp256): ragged N tile (432 of 512), 5 K tiles
     (40960, 576, 576, 0, True, 0, True),
     (9000, 256, 64, 0, True, 4500, False),       # K = 64 weight-stationary kernel (k_gemm_split_k64), ragged last row tile
     (4101, 128, 64, 1, False, 0, True),
