@@ -46,6 +46,19 @@ __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, f
   p0 = __builtin_bit_cast(bf16x8, h);
   p1 = __builtin_bit_cast(bf16x8, l);
 }
+// max over lanes {l, l ^ 16} resp. {l, l ^ 32} with gfx950's row / half swaps: v_permlane16_swap exchanges the odd 16-lane
+// rows of its first operand with the even rows of its second, so with both operands = x one result holds the partner's
+// value in the even rows and the other in the odd rows - their maximum is the pair maximum in every lane.
+__device__ __forceinline__ float xmax16(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xmax32(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 // key (0..31) -> position in a V^T row for the 16x16x32 P.V product: lane group g = (key>>2)&3 holds keys
 // {4g+r} of key-block 0 and {16+4g+r} of key-block 1 in its accumulators; its 8 k-slots are pos 8g..8g+7.
 __device__ __forceinline__ int vt_pos16(int key) { return 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4); }
@@ -287,8 +300,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     for (int g = 0; g < QG; ++g) {
       float tmax = fmaxf(fmaxf(fmaxf(s0[g][0], s0[g][1]), fmaxf(s0[g][2], s0[g][3])),
                          fmaxf(fmaxf(s1[g][0], s1[g][1]), fmaxf(s1[g][2], s1[g][3])));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      tmax = xmax16(tmax);   // the four lane groups of a query column: VALU lane swaps, not two LDS round trips (ds_bpermute)
+      tmax = xmax32(tmax);
       const float m_new = fmaxf(m_run[g], tmax);
       alpha[g] = __builtin_amdgcn_exp2f(m_run[g] - m_new);
       const float p0 = __builtin_amdgcn_exp2f(s0[g][0] - m_new), p1 = __builtin_amdgcn_exp2f(s0[g][1] - m_new), p2 = __builtin_amdgcn_exp2f(s0[g][2] - m_new), p3 = __builtin_amdgcn_exp2f(s0[g][3] - m_new);
