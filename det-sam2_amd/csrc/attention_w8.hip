@@ -12,6 +12,8 @@
 // ds_read_b128.  Operands arrive pre-split (k_rope_split, k_vt_split16).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -135,17 +137,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int BQ = 128 * QG;
   constexpr int VROWB = DV >= 256 ? VROWB_NARROW : VROWB_WIDE;
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
-  // STAG (experiment, -DDS2_W8_STAG=1, cross-attention in bf16x3k only): waves 4-7 run half a tile behind waves 0-3 - per
-  // barrier interval the leading group does [scores of tile t, softmax, P.V], the lagging group [softmax + P.V of tile t-1,
-  // scores of tile t], three V buffers - so that on every SIMD one wave is in a matrix segment while its partner is in the
-  // softmax (VALU) segment.  Bit-identical, but 4 % SLOWER in one call (1.37 vs 1.32 ms per launch,
-  // profiles/r02an_ab_stag.txt): the phases of the two waves of a SIMD evidently do not coincide the way the per-wave
-  // s_memtime stamps suggested; off by default.
-#ifndef DS2_W8_STAG
-#define DS2_W8_STAG 0
-#endif
-  constexpr bool STAG = DS2_W8_STAG && !KLO && DV == 64;
-  constexpr int NVB = STAG ? 3 : 2, VPL = (DV == 256 && !KLO) ? 1 : 2;
+  // Software pipeline: the scores of tile t+1 are issued BEFORE the softmax of tile t, in one basic block - their MFMAs are
+  // independent of that VALU work, so the matrix pipe runs under the exponentials instead of idling (K is staged one tile
+  // ahead of V for this; two score register sets).  (Tried before and left out: running waves 4-7 half a tile behind waves
+  // 0-3 with three V buffers - bit-identical but 4 % slower, profiles/r02an_ab_stag.txt.)
+  constexpr int NVB = 2, VPL = (DV == 256 && !KLO) ? 1 : 2;
   __shared__ __attribute__((aligned(16))) unsigned char Kp[2][KLO ? 2 : 1][KPLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[NVB][VPL][VPLANE];
 
@@ -217,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   const int kso0 = krow * KROWB + kpart * 16, kso1 = (krow + 16) * KROWB + kpart * 16;
 
   uint4 rk0, rk1, rk2, rk3, rv[NVLD];
-#define W8_LOAD(KT)                                                           \
+#define W8_LOAD_K(KT)                                                         \
   {                                                                           \
     const int kt_ = (KT);                                                     \
     int k0_ = kt_ * BKEYS + krow, k1_ = k0_ + 16;                             \
@@ -229,19 +225,26 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                               \
       rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                               \
     }                                                                         \
+  }
+#define W8_LOAD_V(KT)                                                         \
+  {                                                                           \
+    const int kt_ = (KT);                                                     \
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j)                          \
       if ((DV != 64 || kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) /* DV=64: threads >= 256 stage the lo plane; DV=256 in bf16x3k: no lo plane */ \
         rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; \
   }
-#define W8_STORE(BUF, VBUF, STKT)                                             \
+#define W8_STORE_K(BUF)                                                       \
   {                                                                           \
-    const int st_kt_ = (STKT);                                                \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso0]) = rk0;                       \
     *reinterpret_cast<uint4*>(&Kp[BUF][0][kso1]) = rk1;                       \
     if (KLO) {                                                                \
       *reinterpret_cast<uint4*>(&Kp[BUF][KLO ? 1 : 0][kso0]) = rk2;           \
       *reinterpret_cast<uint4*>(&Kp[BUF][KLO ? 1 : 0][kso1]) = rk3;           \
     }                                                                         \
+  }
+#define W8_STORE_V(VBUF, STKT)                                                \
+  {                                                                           \
+    const int st_kt_ = (STKT);                                                \
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j) {                        \
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
@@ -250,9 +253,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }                                                                         \
   }
 
-  f32x4 s0[QG], s1[QG];   // scores of the current tile (they cross the barrier in the lagging group)
+  f32x4 sa0[QG], sa1[QG], sb0[QG], sb1[QG];   // two score sets: tile t (being exponentiated) and tile t+1 (being accumulated)
   // ---- S^T = K Q^T for the two 16-key blocks of tile kt_ in K buffer kb (each K fragment serves QG query groups)
-  auto scores = [&](int kb, int kt_) {
+  auto scores = [&](auto mask_tag, int kb, int kt_, f32x4 (&s0)[QG], f32x4 (&s1)[QG]) {
+    constexpr bool MASK = decltype(mask_tag)::value;   // only a key count that is not a multiple of 32 needs the tail mask
 #pragma unroll
     for (int g = 0; g < QG; ++g) { s0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const unsigned char* kp0 = &Kp[kb][0][l15 * KROWB + grp * 16];
@@ -282,18 +286,18 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
         s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q0[g][ks], s1[g], 0, 0, 0);
       }
     }
-    if (kt_ == nkt - 1) {   // keys >= Lk only exist in the last tile; lane holds keys 4*grp + r (+16)
-#pragma unroll
+    if constexpr (MASK) {   // keys >= Lk (last tile); lane holds keys 4*grp + r (+16).  Branch-free: the block must stay one
+#pragma unroll           // basic block with the softmax of the previous tile
       for (int g = 0; g < QG; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (kt_ * BKEYS + 4 * grp + r >= a.Lk) s0[g][r] = -INFINITY;
-          if (kt_ * BKEYS + 16 + 4 * grp + r >= a.Lk) s1[g][r] = -INFINITY;
+          s0[g][r] = kt_ * BKEYS + 4 * grp + r >= a.Lk ? -INFINITY : s0[g][r];
+          s1[g][r] = kt_ * BKEYS + 16 + 4 * grp + r >= a.Lk ? -INFINITY : s1[g][r];
         }
     }
   };
   // ---- online softmax of the scores in s0 / s1, then O^T += V^T P^T with tile kt_ in V buffer vb
-  auto softmax_pv = [&](int vb, int kt_) {
+  auto softmax_pv = [&](int vb, int kt_, f32x4 (&s0)[QG], f32x4 (&s1)[QG]) {
     bf16x8 pb0[QG], pb1[QG];
     float alpha[QG];
 #pragma unroll
@@ -358,26 +362,43 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }
   };
 
-  W8_LOAD(0)
-  W8_STORE(0, 0, 0)
+  W8_LOAD_K(0)
+  W8_LOAD_V(0)
+  W8_STORE_K(0)
+  W8_STORE_V(0, 0)
+  W8_LOAD_K(nkt > 1 ? 1 : 0)
+  W8_STORE_K(1)
   __syncthreads();
-  const bool lag = STAG && wave >= 4;
-  int vb_prev = NVB - 1, vb_cur = 0, vb_next = 1;   // V buffers of tiles kt-1, kt, kt+1 (kt mod NVB, without the division)
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int nxt = kt + 1 < nkt ? kt + 1 : kt;
-    W8_LOAD(nxt)
-    if (!lag) {
-      scores(kt & 1, kt);
-      softmax_pv(vb_cur, kt);
-    } else {
-      if (kt > 0) softmax_pv(vb_prev, kt - 1);
-      scores(kt & 1, kt);
-    }
-    W8_STORE((kt + 1) & 1, vb_next, nxt)
-    __syncthreads();
-    vb_prev = vb_cur; vb_cur = vb_next; vb_next = vb_next + 1 == NVB ? 0 : vb_next + 1;
+  // one iteration: [global loads of K(kt+2), V(kt+1)] [scores of tile kt+1 -> nxt] [softmax + P.V of tile kt <- cur] [stage] [barrier]
+  // (the scores of a tile past the end are computed on the clamped K buffer and ignored: no branch inside the block)
+#define W8_STEP(MT, KT, C0, C1, N0, N1)                                       \
+  {                                                                           \
+    const int kt_s = (KT);                                                    \
+    W8_LOAD_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1)                            \
+    W8_LOAD_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1)                            \
+    scores(MT, (kt_s + 1) & 1, kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, N0, N1);  \
+    softmax_pv(kt_s & 1, kt_s, C0, C1);                                       \
+    W8_STORE_K(kt_s & 1)                                                      \
+    W8_STORE_V((kt_s + 1) & 1, (kt_s + 1 < nkt ? kt_s + 1 : nkt - 1))         \
+    __syncthreads();                                                          \
   }
-  if (lag) softmax_pv(vb_prev, nkt - 1);   // (its V buffer was last written two intervals ago: nothing to wait for)
+  if (a.Lk % BKEYS == 0) {
+    const std::false_type nm{};
+    scores(nm, 0, 0, sa0, sa1);
+    __syncthreads();   // every wave has read K(0) before iteration 0 overwrites it with K(2)
+    for (int kt = 0; kt < nkt; kt += 2) {
+      W8_STEP(nm, kt, sa0, sa1, sb0, sb1)
+      if (kt + 1 < nkt) W8_STEP(nm, kt + 1, sb0, sb1, sa0, sa1)
+    }
+  } else {
+    const std::true_type wm{};
+    scores(wm, 0, 0, sa0, sa1);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+      W8_STEP(wm, kt, sa0, sa1, sb0, sb1)
+      if (kt + 1 < nkt) W8_STEP(wm, kt + 1, sb0, sb1, sa0, sa1)
+    }
+  }
 
 #pragma unroll
   for (int g = 0; g < QG; ++g) {
