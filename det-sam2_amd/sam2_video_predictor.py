@@ -49,6 +49,15 @@ class SAM2VideoPredictor:
         # Upper bound 16 (the C-ABI's limit); the actual batch splits the frames still to encode evenly (20 -> 10 + 10,
         # 30 -> 15 + 15): at 16 frames every Hiera stage-3 GEMM of hiera_l is a whole number of 256-CU rounds.
         self.encode_batch = int(os.environ.get("DS2_ENCODE_BATCH", "16"))
+        # The next encoder batch is launched AHEAD of need on a second HIP stream, through a second ds2_model (same weights,
+        # its own workspace arena), so that its large GEMMs fill the CUs the small kernels of the tracking chain (SAM
+        # heads, memory encoder) leave idle: +4.5 % frames/s at hiera_l / 16 objects.  Same kernels, same results.
+        # Overlapped kernels share CUs, so every per-kernel duration (and the bench's roofline fraction) reads ~5 %
+        # worse than in isolation; DS2_ASYNC_ENCODE=0 switches it off.
+        self.async_encode = hip is None and os.environ.get("DS2_ASYNC_ENCODE", "1") not in ("", "0")
+        self.async_lookahead = int(os.environ.get("DS2_ASYNC_LOOKAHEAD", "12"))
+        self._sd_for_enc = state_dict if self.async_encode else None
+        self._hip_enc, self._enc_stream = None, None
 
     # ------------------------------------------------------------------ frame ingest (A3)
     def _load_frames(self, video_path):
@@ -87,6 +96,7 @@ class SAM2VideoPredictor:
         st["point_inputs_per_obj"] = {}
         st["mask_inputs_per_obj"] = {}
         st["cached_features"] = {}
+        st["_pending_features"] = {}
         st["constants"] = {}
         st["obj_id_to_idx"] = OrderedDict()
         st["obj_idx_to_id"] = OrderedDict()
@@ -159,6 +169,7 @@ class SAM2VideoPredictor:
         # level-2 features of the bank's conditioning frames (DS2BANK carries them instead of frames): pinned in the
         # feature cache for the online new-object re-consolidation (A17), which only runs the memory encoder on them
         st["cached_features"] = {}
+        st["_pending_features"] = {}
         st["_pinned_features"] = set()
         for t, f2 in (st.get("preload_fpn2") or {}).items():
             f2 = f2.to(self.device).contiguous()
@@ -172,6 +183,15 @@ class SAM2VideoPredictor:
         on a miss, the next not-yet-encoded frames of the current propagation order ride along in one launch."""
         cache = st["cached_features"]
         f = cache.get(frame_idx)
+        pend = st.get("_pending_features")
+        if f is None and pend and frame_idx in pend:       # encoded ahead on the side stream: wait for its event, adopt it
+            f, ev = pend.pop(frame_idx)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            for x in f:
+                x.record_stream(cur)
+            cache[frame_idx] = f
+            self._trim_feature_cache(st, keep={frame_idx})
         if f is None and frame_idx not in st["images_idx"] and st.get("_frame_source") is not None:
             fr = st["_frame_source"](frame_idx)          # a frame this GPU did not ingest (sharded driver): fetch it now
             if fr is not None:
@@ -196,7 +216,42 @@ class SAM2VideoPredictor:
             self.stats["encoder_runs"] += len(todo)
             self.stats["encoder_launches"] += 1
             f = cache[frame_idx]
+        if self.async_encode:
+            self._prefetch_features(st, frame_idx)
         return f
+
+    def _prefetch_features(self, st, frame_idx):
+        """Launch the next encoder batch on the side stream when the first frame without features is at most
+        `async_lookahead` frames away in the propagation order."""
+        order = st.get("_encode_order")
+        if not order or frame_idx not in order or self.encode_batch <= 1:
+            return
+        cache, pend = st["cached_features"], st.setdefault("_pending_features", {})
+        ahead = order[order.index(frame_idx) + 1:]
+        have = set(st["images_idx"])
+        missing = [t for t in ahead if t not in cache and t not in pend and t in have]
+        if not missing or ahead.index(missing[0]) > self.async_lookahead:
+            return
+        n_batches = -(-len(missing) // self.encode_batch)
+        todo = missing[: -(-len(missing) // n_batches)]
+        if self._hip_enc is None:
+            self._hip_enc = HipSam2(self.cfg, self._sd_for_enc, self.device, 16)
+            self._enc_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        es = self._enc_stream
+        es.wait_stream(main)                       # the frames were ingested on the caller's stream
+        with torch.cuda.stream(es):
+            if len(todo) == 1:
+                feats = [self._hip_enc.image_encoder(st["images"][st["images_idx"].index(todo[0])])]
+            else:
+                pos = torch.tensor([st["images_idx"].index(t) for t in todo], device=st["images"].device)
+                feats = self._hip_enc.image_encoder_batch(st["images"].index_select(0, pos))
+            ev = torch.cuda.Event()
+            ev.record(es)
+        for t, ft in zip(todo, feats):
+            pend[t] = (ft, ev)
+        self.stats["encoder_runs"] += len(todo)
+        self.stats["encoder_launches"] += 1
 
     def encode_frames(self, st, frame_indices):
         """Encode the given retained frames now (batches of encode_batch) and return their pyramids in order; frames that
@@ -579,6 +634,7 @@ class SAM2VideoPredictor:
                 o["cond_frame_outputs"].pop(t, None)
         for t in [t for t in st["cached_features"] if pre_frames - 1 < t <= oldest]:
             st["cached_features"].pop(t, None)
+            (st.get("_pending_features") or {}).pop(t, None)
             if st.get("_pinned_features"):
                 st["_pinned_features"].discard(t)
         if release_images:
