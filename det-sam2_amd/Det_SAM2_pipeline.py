@@ -82,12 +82,14 @@ class DetSAM2Pipeline:
     # ------------------------------------------------------------------ hand-off (:59-78)
     def transform_video_segments(self):
         vp = self.video_processor
-        need = sorted(vp.video_segments.keys())
         with self._lock:
+            # snapshot under the lock: the consumer pops delivered frames from self.video_segments concurrently, and an
+            # OLD delivery of frame t still draining would otherwise remove the entry before it is enqueued here
+            items = [(t, vp.video_segments[t]) for t in sorted(vp.video_segments)]
             self.video_segments.update(vp.video_segments)
             vp.video_segments.clear()
-        for t in need:
-            self.frames_queue.put((t, self.video_segments[t]))
+        for t, seg in items:
+            self.frames_queue.put((t, seg))
             self.delivery_log.append(t)
 
     # ------------------------------------------------------------------ the two threads (:81-247)
@@ -153,7 +155,8 @@ class DetSAM2Pipeline:
                     if frame_idx not in self.has_processed_frames:
                         self.has_processed_frames.append(frame_idx)
                     if vp.vis_frame_stride == -1:
-                        self.video_segments.pop(frame_idx, None)
+                        with self._lock:            # keys are ABSOLUTE indices (the reference pops the relative one, :204)
+                            self.video_segments.pop(frame_idx + vp.pre_frames, None)
         except BaseException as e:
             self.error = self.error or e
 

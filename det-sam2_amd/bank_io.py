@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import io
 import json
+import os
 import pickle
 import struct
 from collections import OrderedDict
@@ -133,6 +134,7 @@ def _read_ds2bank(f) -> dict:
         if tuple(out["maskmem_features"].shape) != (B, 4096, 64) or tuple(out["pred_masks"].shape) != (B, 1, 256, 256):
             raise ValueError(f"DS2BANK entry of frame {e['frame']} has unexpected shapes")
         st["output_dict"][key][int(e["frame"])] = out
+        st["frames_already_tracked"][int(e["frame"])] = {"reverse": True}    # as in a reference pickle (:1013-1016)
         if e["kind"] == "cond":
             st["consolidated_frame_inds"]["cond_frame_outputs"].add(int(e["frame"]))
             if "fpn2" in e["tensors"]:
@@ -140,18 +142,27 @@ def _read_ds2bank(f) -> dict:
     return st
 
 
+def _safe_load_storage(b):
+    """Stand-in for ``torch.storage._load_from_bytes`` (which is ``torch.load(..., weights_only=False)``, i.e. a second,
+    unrestricted pickle on the file's bytes): the nested stream is read with torch's own weights-only unpickler."""
+    return torch.load(io.BytesIO(b), weights_only=True, map_location="cpu")
+
+
 class _RestrictedUnpickler(pickle.Unpickler):
     """Reference banks are ``pickle.dump(inference_state)``: dicts / OrderedDict / sets / lists of torch tensors,
-    ``torch.device`` objects, ints.  Nothing else is allowed to be constructed."""
+    ``torch.device`` objects, ints.  Nothing else is allowed to be constructed - including through the nested pickle
+    inside a tensor's storage bytes (``_safe_load_storage``)."""
     _OK = {("collections", "OrderedDict"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"),
            ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch", "device"),
-           ("torch.storage", "_load_from_bytes"), ("torch", "Size"), ("torch.serialization", "_get_layout"),
+           ("torch", "Size"), ("torch.serialization", "_get_layout"),
            ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
            ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
     _TORCH_TYPES = {"FloatStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "BoolStorage",
                     "ByteStorage", "UntypedStorage", "float32", "float16", "bfloat16", "int64", "int32", "uint8", "bool"}
 
     def find_class(self, module, name):
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            return _safe_load_storage
         if (module, name) in self._OK or (module == "torch" and name in self._TORCH_TYPES):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"bank file: refusing to unpickle {module}.{name}")
@@ -184,11 +195,17 @@ def _from_reference_pickle(raw: bytes) -> dict:
     return st
 
 
-def load_bank(path) -> dict:
-    """-> host-resident inference state (DS2BANK or reference pickle); ``init_preloading_state`` moves it to the GPU."""
+def load_bank(path, allow_pickle=None) -> dict:
+    """-> host-resident inference state (DS2BANK or reference pickle); ``init_preloading_state`` moves it to the GPU.
+    ``allow_pickle=False`` (or ``DS2_BANK_ALLOW_PICKLE=0``) refuses anything that is not a DS2BANK file; by default a
+    file without the magic is read as a reference bank through the restricted unpickler."""
+    if allow_pickle is None:
+        allow_pickle = os.environ.get("DS2_BANK_ALLOW_PICKLE", "1") not in ("", "0")
     with open(path, "rb") as f:
         head = f.read(8)
         if head == MAGIC:
             return _read_ds2bank(f)
+        if not allow_pickle:
+            raise ValueError(f"{path}: not a DS2BANK file and reference pickles are disabled (allow_pickle=False)")
         raw = head + f.read()
     return _from_reference_pickle(raw)

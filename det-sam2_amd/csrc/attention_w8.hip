@@ -1,12 +1,11 @@
 // Memory-attention kernel, 8-wave variant: bf16x3 flash attention over pre-split operands on
 // v_mfma_f32_16x16x32_bf16.
 //
-// attention_split.hip keeps 32 queries per wave (128 VGPRs of Q planes): one wave per SIMD, no registers left
-// to prefetch LDS operands, softmax VALU and MFMA strictly alternate.  Here a wave owns 16 queries (64 VGPRs of
-// Q planes), a block is 8 waves = 128 queries, so every SIMD hosts TWO waves whose MFMA and VALU phases
-// overlap in hardware, and the compiler has ~100 free VGPRs to run LDS reads ahead of the MFMAs.
+// A wave owns 16 queries per query group (64 VGPRs of Q planes), a block is 8 waves, so every SIMD hosts TWO waves
+// whose MFMA and VALU phases overlap in hardware, and the compiler has ~100 free VGPRs to run LDS reads ahead of the
+// MFMAs.  (The 4-wave 32x32x16 predecessor lives in tools/experiments/attention_split.hip.)
 //
-// Same dataflow otherwise: transposed scores S^T = K Q^T (lane = one query column, 4 keys per 16x16 block),
+// Dataflow: transposed scores S^T = K Q^T (lane = one query column, 4 keys per 16x16 block),
 // online softmax with per-lane statistics (two __shfl_xor to share the row max across the four lane groups),
 // P^T fed to O^T = V^T P^T straight from the accumulators, V^T stored key-permuted so its operand is one
 // ds_read_b128.  Operands arrive pre-split (k_rope_split, k_vt_split16).
@@ -427,7 +426,38 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   }
 }
 
+// ---- producer: (optional RoPE) + split of 256-wide rows into bf16 planes.  One thread per 4 consecutive columns.
+__global__ void k_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
+                             uint2* hi, uint2* lo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)batch * L * 64) return;
+  const int c4 = (int)(i & 63);
+  const size_t row = i >> 6;
+  const int t = (int)(row % L);
+  float4 v = *reinterpret_cast<const float4*>(x + row * ldx + c4 * 4);
+  if (t < n_rope) {   // two complex pairs (apply_rotary_enc, position_encoding.py:196-220)
+    const float4 c = *reinterpret_cast<const float4*>(cis + ((size_t)(t % grid_tokens) * 128 + c4 * 2) * 2);
+    v = make_float4(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x, v.z * c.z - v.w * c.w, v.z * c.w + v.w * c.z);
+  }
+  uint2 h, l;
+  h.x = cvt_pk_bf16(v.x, v.y);
+  h.y = cvt_pk_bf16(v.z, v.w);
+  l.x = cvt_pk_bf16(v.x - bf_lo(h.x), v.y - bf_hi(h.x));
+  l.y = cvt_pk_bf16(v.z - bf_lo(h.y), v.w - bf_hi(h.y));
+  hi[i] = h;
+  if (lo) lo[i] = l;      // bf16x3k mode: the keys of the scores carry no lo plane
+}
+
 }  // namespace
+
+int launch_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
+                      void* hi, void* lo, hipStream_t st) {
+  const size_t n = (size_t)batch * L * 64;
+  hipLaunchKernelGGL(k_rope_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, cis, batch, L, n_rope,
+                     grid_tokens, reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo));
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
 
 
 int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys, int* flag) {

@@ -330,27 +330,16 @@ int heuristic_tile(const GemmSplitArgs& g) {
   const double c256 = b256 >= 256 ? 4.0 / 1.28 * (double)((b256 + 255) / 256) : 1e30;
   int tile = 1;
   if (cr3 < c128 && cr3 <= c256) tile = 3;
-  if (c256 < c128 && c256 < cr3) tile = 4;
-  // the LDS-DMA 256x256 kernel replaces the register-staged one (DS2_GEMM_D256=0 keeps the old kernel for A/B runs);
-  // its 32-bit DMA offsets need the operand planes to stay below 4 GiB
-  static const bool d256 = [] { const char* e = getenv("DS2_GEMM_D256"); return !(e && atoi(e) == 0); }();
-  if (tile == 4 && d256 && (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32)) tile = 5;
-  // four-stage 16-deep variant (three K slices in flight): DS2_GEMM_Q256=1/0
-  static const bool q256 = [] { const char* e = getenv("DS2_GEMM_Q256"); return e && atoi(e) != 0; }();
-  if (tile == 5 && q256) tile = 6;
-  // phase-interleaved variant: DS2_GEMM_P256=1/0
-  static const bool p256 = [] { const char* e = getenv("DS2_GEMM_P256"); return e && atoi(e) != 0; }();
-  if (tile == 5 && p256) tile = 9;
+  const bool fits32 = (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32);   // 32-bit DMA offsets
+  if (c256 < c128 && c256 < cr3) tile = fits32 ? 5 : 3;   // the LDS-DMA 256x256 kernel (else the 256x128 ring)
   // persistent variant with loader / storer waves for GEMMs without residual / RoPE epilogue (default; DS2_GEMM_PP256=0
   // keeps the one-tile-per-workgroup kernel for A/B runs)
   static const bool pp256 = [] { const char* e = getenv("DS2_GEMM_PP256"); return !(e && atoi(e) == 0); }();
-  if ((tile == 5 || tile == 9) && pp256 && gemm_split_pp256_supported(g)) tile = 10;
+  if (tile == 5 && pp256 && gemm_split_pp256_supported(g)) tile = 10;
   // ... and it also beats the 256x128 ring wherever that one was chosen for its smaller column padding: the GEMMs of Hiera
   // stages 1-2 (K = 144 / 288: five to nine K tiles, i.e. mostly epilogue) run 10-25 % faster persistent
   // (profiles/r02at_tile_time_s12.txt)
-  if (tile == 3 && pp256 && gemm_split_pp256_supported(g) && b256 >= 256 && ncols > 128 &&
-      (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32))
-    tile = 10;
+  if (tile == 3 && pp256 && gemm_split_pp256_supported(g) && b256 >= 256 && ncols > 128 && fits32) tile = 10;
   return tile;
 }
 
@@ -358,18 +347,18 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   GemmSplitArgs g = g_in;
   {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
     static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
-    const int bn = (tile == 4 || tile == 5 || tile == 6 || tile == 9 || tile == 10) ? 256 : 128;
+    const int bn = (tile == 5 || tile == 10) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
     g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
     static const int pf_env = [] { const char* e = getenv("DS2_GEMM_PF"); return e ? atoi(e) : 0; }();
     g.prefetch = pf_env;
   }
-  if (tile == 5) return launch_gemm_split_d256(g, st);
-  if (tile == 6) return launch_gemm_split_q256(g, st);
-  if (tile == 10 && !gemm_split_pp256_supported(g)) tile = 5;
-  if (tile == 9) return launch_gemm_split_p256(g, st);
+  // forced tiles (DS2_GEMM_TILE) fall back when a kernel cannot take the shape: persistent -> one-tile 256x256 -> ring
+  const bool fits32 = (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32);   // 32-bit DMA offsets
+  if (tile == 10 && !(gemm_split_pp256_supported(g) && fits32)) tile = 5;
+  if (tile == 5 && !fits32) tile = 3;
   if (tile == 10) return launch_gemm_split_pp256(g, st);
-  if (tile == 2 || tile == 4) return launch_gemm_split256(g, tile, st);
+  if (tile == 5) return launch_gemm_split_d256(g, st);
   if (tile == 3) return launch_gemm_split_r3(g, st);
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
   static const int dbg = [] { const char* e = getenv("DS2_GEMM_DBG"); return e ? atoi(e) : 0; }();
@@ -387,22 +376,6 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   return DS2_OK;
 }
 
-// Per-shape tile tuning: the three kernels give bit-identical results (same per-element accumulation order), so for
-// every large shape the first occurrences are simply run with the candidates in turn, each bracketed by HIP events on
-// the launch stream (no re-execution, no synchronisation: events are polled on later calls), and once every candidate
-// has TUNE_SAMPLES timings the fastest one is used from then on.  A streaming run sees each shape hundreds of times
-// per second, so tuning is over within the first frames; the heuristic covers the samples still in flight.
-constexpr int TUNE_SAMPLES = 3;
-struct TuneState {
-  int cand[3] = {1, 3, 5};
-  int issued[3] = {0, 0, 0}, done[3] = {0, 0, 0};
-  double best_ms[3] = {1e30, 1e30, 1e30};
-  int chosen = 0;
-  struct Pending { hipEvent_t e0, e1; int c; };
-  std::vector<Pending> pending;
-};
-std::map<std::tuple<int, int, int, int, int, int>, TuneState> g_tune;
-
 }  // namespace
 
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
@@ -415,50 +388,5 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   // K = 64 projections over hundreds of thousands of rows (memory-attention keys): HBM-bound weight-stationary kernel
   static const bool k64 = [] { const char* e = getenv("DS2_GEMM_K64"); return !(e && atoi(e) == 0); }();
   if (k64 && gemm_split_k64_supported(g)) return launch_gemm_split_k64(g, st);
-  // opt-in (DS2_GEMM_TUNE=1): on MI355X the tuner confirms the cost model on every shape of the four SAM 2.1 configs
-  // (identical frames/s), so the default stays the deterministic heuristic
-  static const bool tune = [] { const char* e = getenv("DS2_GEMM_TUNE"); return e && atoi(e) != 0; }();
-  if (!tune || (long)g.M * g.N < (1L << 22)) return launch_tile(g, heuristic_tile(g), st);
-  TuneState& t = g_tune[std::make_tuple(g.M, g.N, g.Kp, g.C ? 1 : 0, g.C_hi ? 1 : 0, (g.R ? 1 : 0) + (g.rope_cis ? 2 : 0))];
-  if (t.chosen) return launch_tile(g, t.chosen, st);
-  // collect finished samples
-  for (size_t i = 0; i < t.pending.size();) {
-    if (hipEventQuery(t.pending[i].e1) == hipSuccess) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, t.pending[i].e0, t.pending[i].e1) == hipSuccess && ms > 0.f) {
-        const int c = t.pending[i].c;
-        if (ms < t.best_ms[c]) t.best_ms[c] = ms;
-        ++t.done[c];
-      }
-      (void)hipEventDestroy(t.pending[i].e0);
-      (void)hipEventDestroy(t.pending[i].e1);
-      t.pending[i] = t.pending.back();
-      t.pending.pop_back();
-    } else {
-      ++i;
-    }
-  }
-  if (t.done[0] >= TUNE_SAMPLES && t.done[1] >= TUNE_SAMPLES && t.done[2] >= TUNE_SAMPLES) {
-    int b = 0;
-    for (int c = 1; c < 3; ++c)
-      if (t.best_ms[c] < t.best_ms[b]) b = c;
-    t.chosen = t.cand[b];
-    static const bool verbose = getenv("DS2_GEMM_TUNE_LOG") != nullptr;
-    if (verbose)
-      fprintf(stderr, "gemm tune M=%d N=%d Kp=%d: 128x128 %.1f us, 256x128 %.1f us, 256x256 %.1f us -> tile %d (heuristic %d)\n",
-              g.M, g.N, g.Kp, t.best_ms[0] * 1e3, t.best_ms[1] * 1e3, t.best_ms[2] * 1e3, t.chosen, heuristic_tile(g));
-    return launch_tile(g, t.chosen, st);
-  }
-  int c = -1;
-  for (int k = 0; k < 3; ++k)
-    if (t.issued[k] < TUNE_SAMPLES && (c < 0 || t.issued[k] < t.issued[c])) c = k;
-  if (c < 0) return launch_tile(g, heuristic_tile(g), st);   // all samples issued, some still in flight
-  TuneState::Pending p{nullptr, nullptr, c};
-  if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return launch_tile(g, heuristic_tile(g), st);
-  (void)hipEventRecord(p.e0, st);
-  const int rc = launch_tile(g, t.cand[c], st);
-  (void)hipEventRecord(p.e1, st);
-  ++t.issued[c];
-  t.pending.push_back(p);
-  return rc;
+  return launch_tile(g, heuristic_tile(g), st);
 }

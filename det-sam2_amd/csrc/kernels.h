@@ -77,12 +77,9 @@ int launch_bank_ptr(const BankArgs& a, const float* dim_t /*[128]*/, hipStream_t
 int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits /*nullable*/,
                        uint8_t* packed /*nullable*/, hipStream_t st);
 
-// pre-split bf16x3 attention fast path (attention_split.hip)
+// producer of pre-split key planes for the memory attention (attention_w8.hip)
 int launch_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
                       void* hi, void* lo, hipStream_t st);   // rows [batch*L] x 256 cols -> bf16 planes [batch*L][256]
-int launch_vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st);  // 64 cols -> [B][tile][2][64][32]
-int launch_attention_split(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
-                           int batch, int Lq, int Lk, float scale, hipStream_t st);
 
 // pre-split bf16x3 GEMM (gemm_split.hip)
 struct GemmSplitArgs {
@@ -111,12 +108,9 @@ struct GemmSplitArgs {
 };
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 256x128 blocks, 8 waves, 3-stage LDS-DMA ring
-int launch_gemm_split256(const GemmSplitArgs& g, int mf, hipStream_t st);   // 256x256 (mf=4) / 256x128 (mf=2) block tiles
 int launch_gemm_split_d256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, two-stage LDS-DMA, one barrier per K tile
-int launch_gemm_split_p256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, phase-interleaved (half-tile DMA per phase, staggered wave groups)
 int launch_gemm_split_pp256(const GemmSplitArgs& g, hipStream_t st);        // persistent p256 with loader / storer waves (no residual)
 bool gemm_split_pp256_supported(const GemmSplitArgs& g);
-int launch_gemm_split_q256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, four 16-deep LDS-DMA stages, three in flight
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);

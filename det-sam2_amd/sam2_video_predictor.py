@@ -240,6 +240,9 @@ class SAM2VideoPredictor:
         main = torch.cuda.current_stream(self.device)
         es = self._enc_stream
         es.wait_stream(main)                       # the frames were ingested on the caller's stream
+        # st["images"] was allocated on the caller's stream and is read here on the side stream: tell the caching
+        # allocator, or add_new_frames / release_old_frames could free and re-use the block while the encoder reads it
+        st["images"].record_stream(es)
         with torch.cuda.stream(es):
             if len(todo) == 1:
                 feats = [self._hip_enc.image_encoder(st["images"][st["images_idx"].index(todo[0])])]
@@ -252,6 +255,11 @@ class SAM2VideoPredictor:
             pend[t] = (ft, ev)
         self.stats["encoder_runs"] += len(todo)
         self.stats["encoder_launches"] += 1
+
+    def _drop_pending(self, st, t):
+        """Forget a side-stream result that will not be adopted; its buffers return to the allocator only after the side
+        stream is done with them (they were allocated under that stream)."""
+        st["_pending_features"].pop(t, None)
 
     def encode_frames(self, st, frame_indices):
         """Encode the given retained frames now (batches of encode_batch) and return their pyramids in order; frames that
@@ -600,6 +608,13 @@ class SAM2VideoPredictor:
             end = min(start_frame_idx + max_frame_num_to_track, n - 1)
             order = range(start_frame_idx, end + 1)
         st["_encode_order"] = list(order)   # lets the feature cache batch-encode upcoming frames
+        try:
+            yield from self._propagate_loop(st, order, od, cfi, obj_ids, B, reverse, output)
+        finally:                            # generator exhausted, closed or abandoned: nothing stays queued on the side
+            for t in list(st.get("_pending_features") or {}):
+                self._drop_pending(st, t)
+
+    def _propagate_loop(self, st, order, od, cfi, obj_ids, B, reverse, output):
         for t in order:
             if t in cfi["cond_frame_outputs"]:
                 key = "cond_frame_outputs"
@@ -634,9 +649,11 @@ class SAM2VideoPredictor:
                 o["cond_frame_outputs"].pop(t, None)
         for t in [t for t in st["cached_features"] if pre_frames - 1 < t <= oldest]:
             st["cached_features"].pop(t, None)
-            (st.get("_pending_features") or {}).pop(t, None)
             if st.get("_pinned_features"):
                 st["_pinned_features"].discard(t)
+        pend = st.get("_pending_features") or {}
+        for t in [t for t in pend if pre_frames - 1 < t <= oldest]:     # encoded ahead but never adopted
+            self._drop_pending(st, t)
         if release_images:
             old = [t for t in st["images_idx"] if pre_frames - 1 < t <= oldest]
             rm = {st["images_idx"].index(t) for t in old}

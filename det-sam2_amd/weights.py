@@ -11,6 +11,7 @@ and ``bench.py`` all use this generator (numpy Philox keyed by crc32(name)).
 """
 from __future__ import annotations
 
+import re
 import zlib
 from collections import OrderedDict
 
@@ -214,14 +215,25 @@ def synthetic_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
     return np.ascontiguousarray(out.astype(np.float32))
 
 
-def synthetic_state_dict(cfg, seed: int = 0):
-    """OrderedDict[name -> torch.FloatTensor] (CPU) with exactly the keys of ``param_shapes``."""
+LOGIT_SCALE_KEYS = re.compile(r"sam_mask_decoder\.output_hypernetworks_mlps\.\d+\.layers\.2\.(weight|bias)$")
+
+
+def synthetic_state_dict(cfg, seed: int = 0, logit_scale: float = 1.0):
+    """OrderedDict[name -> torch.FloatTensor] (CPU) with exactly the keys of ``param_shapes``.
+
+    ``logit_scale`` multiplies the last layer of the four hypernetwork MLPs (``mask_decoder.py:227-235``), i.e. every
+    mask logit: the default weights give |logit| up to 14-17 (saturated sigmoids into the memory encoder); 1/30 gives the
+    low-margin regime |logit| < 1 of the held-out goldens (VERDICT r2 weak #1)."""
     import torch
 
     cfg = resolve_config(cfg)
-    return OrderedDict(
-        (k, torch.from_numpy(synthetic_tensor(k, s, seed))) for k, s in param_shapes(cfg).items()
-    )
+    out = OrderedDict()
+    for k, s in param_shapes(cfg).items():
+        a = synthetic_tensor(k, s, seed)
+        if logit_scale != 1.0 and LOGIT_SCALE_KEYS.search(k):
+            a = np.ascontiguousarray(a * np.float32(logit_scale))
+        out[k] = torch.from_numpy(a)
+    return out
 
 
 def check_state_dict(cfg, sd) -> None:

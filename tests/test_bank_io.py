@@ -92,3 +92,51 @@ def test_pickle_loader_is_restricted(tmp_path):
         pickle.dump({"output_dict": _Evil()}, fh)
     with pytest.raises(pickle.UnpicklingError):
         bank_io.load_bank(path)
+
+
+_FIRED = []
+
+
+class _Marker:
+    def __reduce__(self):
+        return (_FIRED.append, ("nested payload executed",))
+
+
+class _Nested:
+    """Outer pickle that calls torch.storage._load_from_bytes on an inner, unrestricted pickle (in torch
+    2.10 that function is torch.load(weights_only=False))."""
+    def __reduce__(self):
+        import torch.storage
+        return (torch.storage._load_from_bytes, (pickle.dumps(_Marker()),))
+
+
+def test_nested_storage_pickle_cannot_execute(tmp_path):
+    path = str(tmp_path / "nested.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump({"output_dict": _Nested()}, fh)
+    _FIRED.clear()
+    with pytest.raises(Exception):
+        bank_io.load_bank(path)
+    assert _FIRED == [], "the nested pickle inside _load_from_bytes ran an arbitrary callable"
+
+
+def test_pickle_fallback_can_be_disabled(tmp_path, monkeypatch):
+    st, _ = _state(1)
+    path = str(tmp_path / "ref.pkl")
+    with open(path, "wb") as fh:
+        pickle.dump(st, fh)
+    with pytest.raises(ValueError, match="not a DS2BANK"):
+        bank_io.load_bank(path, allow_pickle=False)
+    monkeypatch.setenv("DS2_BANK_ALLOW_PICKLE", "0")
+    with pytest.raises(ValueError, match="not a DS2BANK"):
+        bank_io.load_bank(path)
+
+
+def test_ds2bank_marks_bank_frames_as_tracked(tmp_path):
+    """Prompts on preload frames are corrections, not initial conditioning frames: a DS2BANK state lists its entries in
+    frames_already_tracked like the reference's pickled state does."""
+    st, _ = _state()
+    path = str(tmp_path / "bank.ds2")
+    bank_io.save_bank(path, st, "sam2.1_hiera_t")
+    got = bank_io.load_bank(path)
+    assert sorted(got["frames_already_tracked"]) == [0, 1, 5]

@@ -1,0 +1,113 @@
+"""GPU parity on HELD-OUT reference goldens: the default arithmetic mode bf16x3k was selected against
+the seed-0 / uniform-noise / |logit| 14-17 fixtures of tests/test_hip_e2e.py.  The fixtures here were produced by the
+REFERENCE afterwards (oracle/make_goldens.py HELDOUT) and differ in weights (seed 1), frames (structured: moving discs
+on a gradient) and - variant "lm" - in the margin (hypernetwork output layer / 30 => |logit| < 1, non-saturated sigmoids
+into the memory encoder).  Same bar: 1 - IoU <= 1e-3 per (frame, object); logits within 4e-3 of the fixture's |logit|max."""
+import os
+
+import numpy as np
+import pytest
+
+from _util import record
+from det_sam2_amd.config import resolve_config
+from det_sam2_amd.synth import SyntheticDetector, synthetic_frame
+from det_sam2_amd.weights import synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+TINY = "sam2.1_hiera_t"
+REL_LOGIT_TOL = 4e-3          # the seed-0 tests allow 5e-2 on |logit| <= 17 (3e-3 relative)
+
+
+def _iou(a, b):
+    inter, union = np.logical_and(a, b).sum(), np.logical_or(a, b).sum()
+    return 1.0 if union == 0 else inter / union
+
+
+def _vp(name, variant, prec, detector, max_batch, **kw):
+    from det_sam2_amd.det_sam2_RT import VideoProcessor
+    from det_sam2_amd.sam2_video_predictor import SAM2VideoPredictor
+    from oracle.make_goldens import HELDOUT
+    ws, ls, st = HELDOUT[variant]
+    cfg = resolve_config(name)
+    pred = SAM2VideoPredictor(cfg, synthetic_state_dict(cfg, ws, ls), "cuda:0", max_batch=max_batch)
+    pred.hip.set_precision(prec)
+    return VideoProcessor(model_cfg=name, detector=detector, predictor=pred, **kw), st
+
+
+def _compare_full(vp, g, nobj):
+    od = vp.inference_state["output_dict"]
+    worst, worst_logit = 0.0, 0.0
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].cpu().numpy()
+        worst_logit = max(worst_logit, float(np.abs(low - g["low"][i]).max()))
+        ref = np.unpackbits(g["bits"][i]).reshape(nobj, 1, 1024, 1024).astype(bool)
+        for o in range(nobj):
+            worst = max(worst, 1.0 - _iou(vp.video_segments[int(t)][o], ref[o]))
+    return worst, worst_logit, float(np.abs(g["low"]).max())
+
+
+@pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
+@pytest.mark.parametrize("variant", ["s1", "lm"])
+def test_heldout_config1(golden_dir, variant, prec):
+    g = np.load(os.path.join(golden_dir, f"ho_cfg1_{variant}.npz"))
+    vp, st = _vp(TINY, variant, prec, SyntheticDetector(1), 4, skip_classes=set(), frame_buffer_size=8, detect_interval=8,
+                 max_frame_num_to_track=8, max_inference_state_frames=-1)
+    for t in range(8):
+        vp.process_frame(t, synthetic_frame(t, structured=st))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    worst, dlogit, amax = _compare_full(vp, g, 1)
+    record("heldout_cfg1", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
+    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
+@pytest.mark.parametrize("variant", ["s1", "lm"])
+def test_heldout_hiera_large(golden_dir, variant, prec):
+    from oracle.make_goldens import LARGE_KW
+    g = np.load(os.path.join(golden_dir, f"ho_large_{variant}.npz"))
+    vp, st = _vp("sam2.1_hiera_l", variant, prec, SyntheticDetector(2), 2, **LARGE_KW)
+    for t in range(3):
+        vp.process_frame(t, synthetic_frame(t, structured=st))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    worst, dlogit, amax = _compare_full(vp, g, 2)
+    record("heldout_large", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
+    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)
+
+
+@pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
+@pytest.mark.parametrize("variant", ["s1", "lm"])
+def test_heldout_16_objects(golden_dir, variant, prec):
+    from oracle.make_goldens import B16_KW
+    g = np.load(os.path.join(golden_dir, f"ho_b16_{variant}.npz"))
+    vp, st = _vp(TINY, variant, prec, SyntheticDetector(16), 16, **B16_KW)
+    lows = []
+    orig = vp.predictor.propagate_in_video
+
+    def capture(state, **k):
+        for t, ids, bits in orig(state, **k):
+            od = state["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            lows.append((t, len(ids), od[key][t]["pred_masks"].clone()))
+            yield t, ids, bits
+
+    vp.predictor.propagate_in_video = capture
+    for t in range(3):
+        vp.process_frame(t, synthetic_frame(t, structured=st))
+    assert [l[0] for l in lows] == list(g["frames"]) and [l[1] for l in lows] == list(g["nobj"])
+    amax = float(g["logit_absmax"])
+    worst, dlogit = 0.0, 0.0
+    for i, (t, nobj, low) in enumerate(lows):
+        low = low.cpu().numpy()
+        ref_bits = np.unpackbits(g[f"lowbits{i}"])[: low.size].reshape(low.shape).astype(bool)
+        for o in range(nobj):
+            worst = max(worst, 1.0 - _iou(low[o] > 0, ref_bits[o]))
+        sub = low[:, :, ::4, ::4]
+        ref = g[f"low{i}"].astype(np.float32)                       # fp16 storage of the fixture: 2^-11 relative
+        dlogit = max(dlogit, float((np.abs(sub - ref) - np.abs(ref) * 2.0 ** -11).max()))
+        seg = np.stack([vp.video_segments[t][oid] for oid in vp.inference_state["obj_ids"][:nobj]])[:, :, ::4, ::4]
+        rb = np.unpackbits(g[f"bits{i}"])[: seg.size].reshape(seg.shape).astype(bool)
+        for o in range(nobj):
+            worst = max(worst, 1.0 - _iou(seg[o], rb[o]))
+    record("heldout_b16", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
+    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)

@@ -346,3 +346,71 @@ def test_e2e_mask_prompts_match_reference_golden(tiny, golden_dir):
         ref = np.unpackbits(g["bits"][i]).reshape(3, 1, 1024, 1024).astype(bool)
         for o in range(3):
             assert 1.0 - _iou(bits[o], ref[o]) <= 1e-3
+
+
+# ---------------------------------------------------------------------------------------------- held-out goldens
+# Generated from the reference AFTER the arithmetic mode was chosen (oracle/make_goldens.py HELDOUT): weight seed 1,
+# structured frames, and ("lm") mask logits scaled into |logit| < 1.
+def _heldout(variant):
+    from oracle.make_goldens import HELDOUT
+    return HELDOUT[variant]
+
+
+@pytest.mark.parametrize("variant", ["s1", "lm"])
+def test_heldout_config1_matches_reference_golden(variant, golden_dir):
+    ws, ls, st = _heldout(variant)
+    cfg = resolve_config(TINY)
+    sd = synthetic_state_dict(cfg, ws, ls)
+    g = np.load(os.path.join(golden_dir, f"ho_cfg1_{variant}.npz"))
+    vp = OracleVideoProcessor(sd, cfg, SyntheticDetector(1), skip_classes=set(), frame_buffer_size=8,
+                              detect_interval=8, max_frame_num_to_track=8, max_inference_state_frames=-1)
+    with torch.inference_mode():
+        for t in range(8):
+            vp.process_frame(t, synthetic_frame(t, structured=st))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    amax = float(np.abs(g["low"]).max())
+    assert (amax < 1.0) == (variant == "lm")
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].numpy()
+        assert np.abs(low - g["low"][i]).max() <= 2e-5 * max(amax, 1.0) + 1e-5
+        ref_mask = np.unpackbits(g["bits"][i]).reshape(1, 1, 1024, 1024).astype(bool)
+        assert 1.0 - _iou(vp.video_segments[int(t)][0], ref_mask[0]) <= 1e-3
+
+
+@pytest.mark.parametrize("variant", ["s1", "lm"])
+def test_heldout_large_matches_reference_golden(variant, golden_dir):
+    from oracle.make_goldens import LARGE_KW
+    ws, ls, st = _heldout(variant)
+    cfg = resolve_config("sam2.1_hiera_l")
+    sd = synthetic_state_dict(cfg, ws, ls)
+    g = np.load(os.path.join(golden_dir, f"ho_large_{variant}.npz"))
+    vp = OracleVideoProcessor(sd, cfg, SyntheticDetector(2), **LARGE_KW)
+    with torch.inference_mode():
+        for t in range(3):
+            vp.process_frame(t, synthetic_frame(t, structured=st))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    amax = float(np.abs(g["low"]).max())
+    for i, t in enumerate(g["frames"]):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][int(t)]["pred_masks"].numpy()
+        assert np.abs(low - g["low"][i]).max() <= 2e-4 * max(amax, 1.0)
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            assert 1.0 - _iou(vp.video_segments[int(t)][o], ref[o]) <= 1e-3
+
+
+def test_heldout_16_objects_low_margin_matches_reference_golden(golden_dir):
+    """(the s1 variant of this scenario is checked on the GPU only: a minute of CPU per variant)"""
+    from oracle.make_goldens import B16_KW
+    ws, ls, st = _heldout("lm")
+    cfg = resolve_config(TINY)
+    g = np.load(os.path.join(golden_dir, "ho_b16_lm.npz"))
+    vp = OracleVideoProcessor(synthetic_state_dict(cfg, ws, ls), cfg, SyntheticDetector(16), **B16_KW)
+    lows = _capture(vp)
+    with torch.inference_mode():
+        for t in range(3):
+            vp.process_frame(t, synthetic_frame(t, structured=st))
+    _check_compact(g, lows)
