@@ -56,6 +56,8 @@ SIGNATURES = {
     "ds2_mask_output": (C.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp, c_vp]),
     "ds2_set_precision": (C.c_int, [i32]),
     "ds2_get_precision": (C.c_int, []),
+    "ds2_model_set_precision": (C.c_int, [c_vp, i32]),
+    "ds2_model_get_precision": (C.c_int, [c_vp]),
     "ds2_profile_enable": (C.c_int, [i32]),
     "ds2_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ds2_profile_tags": (C.c_int, [C.c_char_p, C.c_int64]),

@@ -480,7 +480,7 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
                         int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid) {
-  const bool klo = g_ds2_precision != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
+  const bool klo = ds2_precision() != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
   static const bool qg1 = [] { const char* e = getenv("DS2_ATTN_QG"); return e && atoi(e) == 1; }();

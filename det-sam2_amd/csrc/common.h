@@ -125,8 +125,18 @@ int launch_gemm(const GemmArgs& g, hipStream_t st);          // exact fp32 MFMA
 // queries as one bf16 plane each, fp32 accumulation) and its softmax weights enter P.V as one bf16 plane - see DESIGN.md
 // "precision margin"
 enum { DS2_PREC_FP32 = 0, DS2_PREC_BF16X3 = 1, DS2_PREC_BF16X3K = 2 };
-extern int g_ds2_precision;
-static inline bool ds2_split_mode() { return g_ds2_precision != DS2_PREC_FP32; }
+// The mode belongs to a ds2_model (ds2_model_set_precision); every model entry point installs it for the calling thread
+// while it runs (ds2_precision_scope), so two models in one process - other GPUs, other streams, other modes - never
+// see each other's setting.  Outside a model call (the primitive ops) the process default applies (ds2_set_precision).
+extern int g_ds2_default_precision;
+extern thread_local int t_ds2_precision;          // < 0: no model call in progress on this thread
+static inline int ds2_precision() { return t_ds2_precision >= 0 ? t_ds2_precision : g_ds2_default_precision; }
+static inline bool ds2_split_mode() { return ds2_precision() != DS2_PREC_FP32; }
+struct ds2_precision_scope {
+  int prev;
+  explicit ds2_precision_scope(int mode) : prev(t_ds2_precision) { t_ds2_precision = mode; }
+  ~ds2_precision_scope() { t_ds2_precision = prev; }
+};
 
 int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
                      float eps, int act, hipStream_t st);
@@ -147,7 +157,7 @@ struct AttnArgs {
   // instead of fp32 `o`
   unsigned short *o_hi, *o_lo; int ldop;
 };
-int launch_attention(const AttnArgs& a, hipStream_t st);         // dispatches on g_ds2_precision
+int launch_attention(const AttnArgs& a, hipStream_t st);         // dispatches on ds2_precision()
 bool attention_fewq_supported(const AttnArgs& a);                // Lq <= 16 against >= 1024 keys, head dim 16/32
 int launch_attention_fewq(const AttnArgs& a, hipStream_t st);    // split-key exact fp32 path (attention_fewq.hip)
 bool attention_smallwin_supported(const AttnArgs& a);            // 16- / 64-key Hiera windows, bf16x3 (attention_smallwin.hip)

@@ -24,14 +24,15 @@ void ds2_set_error(const char* fmt, ...) {
 extern "C" const char* ds2_last_error(void) { return g_err; }
 extern "C" int ds2_abi_version(void) { return DS2_ABI_VERSION; }
 
-int g_ds2_precision = DS2_PREC_BF16X3K;
+int g_ds2_default_precision = DS2_PREC_BF16X3K;
+thread_local int t_ds2_precision = -1;
 extern "C" int ds2_set_precision(int32_t mode) {
   DS2_REQUIRE(mode == DS2_PREC_FP32 || mode == DS2_PREC_BF16X3 || mode == DS2_PREC_BF16X3K,
               "ds2_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3k)");
-  g_ds2_precision = mode;
+  g_ds2_default_precision = mode;
   return DS2_OK;
 }
-extern "C" int ds2_get_precision(void) { return g_ds2_precision; }
+extern "C" int ds2_get_precision(void) { return g_ds2_default_precision; }
 
 // ------------------------------------------------------------------------------------------------ profiling
 // HIP-event brackets on the caller's stream around named launch sites; read back by bench.py for the
@@ -139,9 +140,19 @@ struct DeviceGuard {
   }
 };
 
+struct ds2_model;
+static int model_precision(const ds2_model* m);
+// Every model entry point: the model's device current + the model's arithmetic mode installed for this thread.
+struct ModelScope {
+  DeviceGuard dg;
+  ds2_precision_scope ps;
+  explicit ModelScope(const ds2_model* m);
+};
+
 struct ds2_model {
   ds2_config cfg;
   int device = 0;              // the device that was current at ds2_model_create
+  int precision = DS2_PREC_BF16X3K;   // arithmetic mode of this model's stages (ds2_model_set_precision)
   GemmCtx gctx;
   std::vector<BlockCfg> blocks;
   std::vector<int> stage_ends;
@@ -204,6 +215,9 @@ struct ds2_model {
   }
 };
 
+static int model_precision(const ds2_model* m) { return m->precision; }
+ModelScope::ModelScope(const ds2_model* m) : dg(m->device), ps(m->precision) {}
+
 #define ALLOC(var, n)                                                        \
   float* var = m->alloc(n);                                                  \
   if (!var) {                                                                \
@@ -221,20 +235,6 @@ struct ds2_model {
 // ---- bf16x3 operand planes: weights are split once and cached (model-owned pointers only); activations are
 // split per call into a process-wide scratch buffer (until their producers emit planes directly).
 namespace {
-// memory-attention kernel selection (A/B switch for experiments): DS2_ATTN_KERNEL=split selects the 4-wave
-// 32x32x16 kernel, anything else the 8-wave 16x16x32 kernel.
-bool use_w8() {
-  static const bool v = [] { const char* e = getenv("DS2_ATTN_KERNEL"); return !(e && strcmp(e, "split") == 0); }();
-  return v;
-}
-int vt_split(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st, int n_exact_keys = 0, int* flag = nullptr) {
-  return use_w8() ? launch_vt_split16(v, ldv, batch, L, vt, 64, st, n_exact_keys, flag) : launch_vt_split(v, ldv, batch, L, vt, st);
-}
-int attn_split(const float* q, int ldq, const void* khi, const void* klo, const void* vt, float* o, int ldo, int batch,
-               int Lq, int Lk, float scale, hipStream_t st) {
-  return use_w8() ? launch_attention_w8(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, 64, st)
-                  : launch_attention_split(q, ldq, khi, klo, vt, o, ldo, batch, Lq, Lk, scale, st);
-}
 inline int round32(int k) { return (k + 31) / 32 * 32; }
 }  // namespace
 
@@ -372,6 +372,7 @@ extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
               "ds2_model_create: only image_size=1024, d_model=256, mem_dim=64 are supported");
   ds2_model* m = new ds2_model();
   m->cfg = *cfg;
+  m->precision = g_ds2_default_precision;
   DS2_CHECK_HIP(hipGetDevice(&m->device));
   // per-block geometry: Hiera.__init__ loop (hieradet.py:236-267)
   int depth = 0;
@@ -395,7 +396,7 @@ extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
 
 extern "C" void ds2_model_destroy(ds2_model* m) {
   if (!m) return;
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   m->gctx.release();
   for (auto& kv : m->params)
     if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -403,9 +404,18 @@ extern "C" void ds2_model_destroy(ds2_model* m) {
   delete m;
 }
 
+extern "C" int ds2_model_set_precision(ds2_model* m, int32_t mode) {
+  DS2_REQUIRE(m, "ds2_model_set_precision: null model");
+  DS2_REQUIRE(mode == DS2_PREC_FP32 || mode == DS2_PREC_BF16X3 || mode == DS2_PREC_BF16X3K,
+              "ds2_model_set_precision: mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16x3k)");
+  m->precision = mode;
+  return DS2_OK;
+}
+extern "C" int ds2_model_get_precision(const ds2_model* m) { return m ? m->precision : -1; }
+
 extern "C" int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_t nbytes) {
   DS2_REQUIRE(m && name && data && nbytes > 0, "ds2_model_set_param: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   DS2_REQUIRE(!m->finalized, "ds2_model_set_param: model already finalized");
   Blob b;
   b.bytes = (size_t)nbytes;
@@ -429,7 +439,7 @@ static int expect(ds2_model* m, const std::string& name, size_t n_floats) {
 
 extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
   DS2_REQUIRE(m, "ds2_model_finalize: null model");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   hipStream_t st = (hipStream_t)stream;
   const int C0 = m->cfg.embed_dim, D = 256;
   // ---- strict presence / size check of everything the stages read
@@ -543,7 +553,7 @@ static void resize_tables(int dst, int src, bool clamp_weights, int* ofs, int* w
 extern "C" int ds2_ingest_frames(ds2_model* m, const uint8_t* rgb_u8, int32_t n, int32_t height, int32_t width,
                                  uint16_t* frames_f16, void* stream) {
   DS2_REQUIRE(m && m->finalized && rgb_u8 && frames_f16 && n > 0 && height > 0 && width > 0, "ds2_ingest_frames: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   const int S = m->cfg.image_size;
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* lut = reinterpret_cast<const uint16_t*>(m->P("#ingest_lut"));
@@ -578,7 +588,7 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
                               void* stream) {
   const uint16_t* frames_f16 = reinterpret_cast<const uint16_t*>(frames);
   DS2_REQUIRE(m && m->finalized && frames_f16 && fpn0 && fpn1 && fpn2 && n >= 1 && n <= 16, "ds2_image_encoder_batch: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.image_encoder", st);
   const int C0 = m->cfg.embed_dim;
@@ -722,7 +732,7 @@ extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const v
                                  int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
                                  float* memory_pos, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && memory && memory_pos, "ds2_bank_assemble: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   DS2_REQUIRE(n_mem >= 0 && n_ptr >= 0 && (n_mem == 0 || (feats && tpos_row)) && (n_ptr == 0 || (ptrs && ptr_pos)),
               "ds2_bank_assemble: bad entry tables (n_mem=%d, n_ptr=%d)", n_mem, n_ptr);
   hipStream_t st = (hipStream_t)stream;
@@ -774,7 +784,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
                                  float* out, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && curr && memory && memory_pos && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
               "ds2_memory_attention: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   GemmDropScope _gds("DS2_EXP_MA_DROP");
   // the layer-0 self-attention is shared by the B objects only when they all see the same tokens AND positions
   const bool shared0 = curr_shared && (curr_pos == nullptr || pos_shared);
@@ -783,7 +793,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   ProfScope _ps("stage.memory_attention", st);
   const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
   const bool split = ds2_split_mode();
-  const bool klo_planes = g_ds2_precision != DS2_PREC_BF16X3K || !use_w8();   // keys of the attention scores carry a lo plane
+  const bool klo_planes = ds2_precision() != DS2_PREC_BF16X3K;   // keys of the attention scores carry a lo plane
   const int nt_c = (Nk + 31) / 32, nt_s = TOK / 32;
   const size_t split_bytes = split ? ((size_t)B * Nk * 256 * 4 + (size_t)B * nt_c * 8192 + (size_t)rows * 256 * 4 +
                                       (size_t)4 * B * nt_s * 8192 + (1u << 20)) : 0;
@@ -815,7 +825,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (!vlo_flag) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     static const bool no_vlo_skip = getenv("DS2_ATTN_NO_VLO_SKIP") != nullptr;
     if (no_vlo_skip) vlo_flag = nullptr;
-    TRY(vt_split(memory, 64, B, Nk, vt_c, st, Nk - n_ptr_tok, vlo_flag));
+    TRY(launch_vt_split16(memory, 64, B, Nk, vt_c, 64, st, Nk - n_ptr_tok, vlo_flag));
   }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object in the tracking loop
   // (curr is the frame's feature, curr_pos the model constant); the general form takes per-object tokens / positions
@@ -848,23 +858,15 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     const float* xin = once ? x1 : x;
     TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
-    if (!(split && use_w8())) TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));   // (the 8-wave kernel rotates q while loading it)
+    if (!split) TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));   // (the bf16x3 kernel rotates q while loading it)
     if (split) {
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st));
       ProfScope _p("kernel.self_attention", st);
       ds2_model::ActPlanes sa_p{};
-      if (use_w8()) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
-      if (use_w8()) {   // all 256 value columns in one pass
-        TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));
-        TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
-                                sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK));
-      } else {          // four 64-column passes
-        for (int c = 0; c < 4; ++c) {
-          void* vt = (char*)vt_s + (size_t)c * Bs * nt_s * 8192;
-          TRY(launch_vt_split(qkv + 512 + c * 64, 768, Bs, TOK, vt, st));
-          TRY(launch_attention_split(qkv, 768, khi_s, klo_s, vt, a + c * 64, 256, Bs, TOK, TOK, sc, st));
-        }
-      }
+      TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
+      TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));   // all 256 value columns in one pass
+      TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
+                              sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK));
     } else {
       TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
       AttnArgs sa{};
@@ -886,7 +888,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     m->act_planes.erase(a);   // self-attention planes are consumed; `a` is re-used below
     TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
-    if (!(split && use_w8())) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
+    if (!split) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     if (split) {
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
       TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
@@ -895,14 +897,10 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       const ds2_model::ActPlanes kpl = m->act_planes[K];
       khi = kpl.hi; klo = klo_planes ? kpl.lo : nullptr;
       ProfScope _p("kernel.cross_attention", st);
-      if (use_w8()) {
-        ds2_model::ActPlanes cp;
-        TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
-        TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
-                                Nk - n_ptr_tok, vlo_flag, cis, TOK));
-      } else {
-        TRY(attn_split(q, 256, khi, klo, vt_c, a64, 64, B, TOK, Nk, sc, st));
-      }
+      ds2_model::ActPlanes cp;
+      TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
+      TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
+                              Nk - n_ptr_tok, vlo_flag, cis, TOK));
     } else {
       TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
@@ -1000,7 +998,7 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
                                   float* low_res, float* obj_ptr, float* obj_logits, float* ious, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && pix_feat && fpn0 && fpn1 && low_res && obj_ptr && obj_logits,
               "ds2_sam_heads: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   DS2_REQUIRE(P >= 0 && P <= 256 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.sam_heads", st);
@@ -1137,7 +1135,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
                                const float* masks_hi, int hi_sigmoid, const float* obj_logits, int32_t binarize,
                                uint16_t* maskmem_bf16, float* out_f32, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && fpn2, "ds2_memory_encoder: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_encoder", st);
   const int rows = B * TOK;
@@ -1209,7 +1207,7 @@ extern "C" int ds2_resize_aa(const float* in, int32_t B, int32_t Hin, int32_t Wi
 extern "C" int ds2_mask_prompt_prepare(ds2_model* m, int32_t B, const float* mask, float* mask_ds, float* obj_logits,
                                        int32_t* work, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && mask && mask_ds && obj_logits && work, "ds2_mask_prompt_prepare: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   const float* w = m->P("mask_downsample.weight");
   const float* b = m->P("mask_downsample.bias");
   CHECK_PARAMS();
@@ -1218,7 +1216,7 @@ extern "C" int ds2_mask_prompt_prepare(ds2_model* m, int32_t B, const float* mas
 
 extern "C" int ds2_obj_ptr_gate(ds2_model* m, int32_t B, float* obj_ptr, const float* obj_logits, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && obj_ptr && obj_logits, "ds2_obj_ptr_gate: bad argument");
-  DeviceGuard _dg(m->device);
+  ModelScope _dg(m);
   const float* no = m->P("no_obj_ptr");
   CHECK_PARAMS();
   return launch_ptr_gate(obj_ptr, obj_logits, no, B, 256, (hipStream_t)stream);

@@ -44,13 +44,20 @@ class HipOps:
 
     def set_precision(self, mode: str):
         """'fp32' (exact fp32 MFMA), 'bf16x3' (split-precision bf16 MFMA: three product terms everywhere) or 'bf16x3k'
-        (default: bf16x3, with the memory-attention scores as plain bf16 x bf16 products and its softmax weights as one bf16 plane)."""
+        (default: bf16x3, with the memory-attention scores as plain bf16 x bf16 products and its softmax weights as one bf16 plane).
+        On a model (HipSam2) this sets THAT model's mode; on a bare HipOps the process default used by the primitive ops
+        and by models created afterwards."""
         if mode not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {self.PRECISIONS}, got {mode!r}")
-        _capi.check(self.lib.ds2_set_precision(self.PRECISIONS.index(mode)), "ds2_set_precision")
+        h = getattr(self, "h", None)
+        if h:
+            _capi.check(self.lib.ds2_model_set_precision(h, self.PRECISIONS.index(mode)), "ds2_model_set_precision")
+        else:
+            _capi.check(self.lib.ds2_set_precision(self.PRECISIONS.index(mode)), "ds2_set_precision")
 
     def get_precision(self) -> str:
-        return self.PRECISIONS[self.lib.ds2_get_precision()]
+        h = getattr(self, "h", None)
+        return self.PRECISIONS[self.lib.ds2_model_get_precision(h) if h else self.lib.ds2_get_precision()]
 
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on=True, gemm_shapes=False):

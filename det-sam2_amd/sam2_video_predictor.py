@@ -196,6 +196,9 @@ class SAM2VideoPredictor:
             fr = st["_frame_source"](frame_idx)          # a frame this GPU did not ingest (sharded driver): fetch it now
             if fr is not None:
                 self.append_sparse_frames(st, [fr], [frame_idx])
+        if f is None and frame_idx not in st["images_idx"]:
+            raise RuntimeError(f"frame {frame_idx} has neither a retained image nor cached features (released, or a preload-"
+                               "bank frame stored without its level-2 feature): it cannot be encoded")
         if f is None:
             todo = [frame_idx]
             order = st.get("_encode_order")
@@ -235,8 +238,11 @@ class SAM2VideoPredictor:
         n_batches = -(-len(missing) // self.encode_batch)
         todo = missing[: -(-len(missing) // n_batches)]
         if self._hip_enc is None:
+            # a second ds2_model: same weights (+0.9 GB fp32 and +0.9 GB of bf16 planes at hiera_l), its own workspace arena
             self._hip_enc = HipSam2(self.cfg, self._sd_for_enc, self.device, 16)
             self._enc_stream = torch.cuda.Stream(device=self.device)
+        if self._hip_enc.get_precision() != self.hip.get_precision():     # the mode is per model: keep the twin in step
+            self._hip_enc.set_precision(self.hip.get_precision())
         main = torch.cuda.current_stream(self.device)
         es = self._enc_stream
         es.wait_stream(main)                       # the frames were ingested on the caller's stream
@@ -372,29 +378,41 @@ class SAM2VideoPredictor:
                    "point_labels": torch.cat([old["point_labels"], pin["point_labels"]], dim=1)}
         st["point_inputs_per_obj"][obj_idx][frame_idx] = pin
         st["mask_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        # a frame that was never tracked is an initial conditioning frame: the prompt alone produces the mask, no memory
+        # (as in SAM).  Otherwise the prompt CORRECTS the tracked mask (sam2_video_predictor.py:428-433): the pass is
+        # conditioned on this object's memory, in the direction the frame was tracked in, and its output replaces the
+        # frame's non-conditioning entry (add_all_frames_to_correct_as_cond is false in every sam2.1 config).
         is_init_cond_frame = frame_idx not in st["frames_already_tracked"]
-        if not is_init_cond_frame:
-            raise NotImplementedError("correction prompts on already-tracked frames are outside the Det-SAM2 hot path "
-                                      "(Det-SAM2 only prompts frames of the newest buffer, det_sam2_RT.py:217-222)")
+        reverse = False if is_init_cond_frame else st["frames_already_tracked"][frame_idx]["reverse"]
+        storage_key = "cond_frame_outputs" if is_init_cond_frame else "non_cond_frame_outputs"
         obj_tmp, obj_out = st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]
-        prev = obj_tmp["cond_frame_outputs"].get(frame_idx) or obj_out["cond_frame_outputs"].get(frame_idx) \
+        prev = obj_tmp[storage_key].get(frame_idx) or obj_out["cond_frame_outputs"].get(frame_idx) \
             or obj_out["non_cond_frame_outputs"].get(frame_idx)
-        # a second prompt for the same object on the same frame (e.g. YOLO emits two boxes of one class): the previous
-        # prediction, clamped to [-32, 32], is fed back as a mask prompt (sam2_video_predictor.py:470-483)
+        # a second prompt for the same object on the same frame (e.g. YOLO emits two boxes of one class) or a correction:
+        # the previous prediction, clamped to [-32, 32], is fed back as a mask prompt (sam2_video_predictor.py:470-483)
         prev_logits = None
         if prev is not None and prev["pred_masks"] is not None:
             prev_logits = torch.clamp(prev["pred_masks"].to(self.device, torch.float32), -32.0, 32.0).reshape(1, 256, 256)
-        # single-object SAM pass without memory (is_init_cond_frame): pix = feat + no_mem_embed (sam2_base.py:651-657)
-        f0, f1, f2 = self._get_image_feature(st, frame_idx)
+        f0, f1, f2 = self._prompt_features(st, frame_idx)
         npts = pin["point_labels"].shape[1]
         multimask = self.cfg.multimask_min_pt_num <= npts <= self.cfg.multimask_max_pt_num   # _use_multimask :922-932
-        low, ptr, obj, _ = self.hip.sam_heads(1, f2, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
-                                              pix_bcast=True, add_no_mem_embed=True, mask_inputs=prev_logits)
+        if is_init_cond_frame:
+            # single-object SAM pass without memory: pix = feat + no_mem_embed (sam2_base.py:651-657)
+            low, ptr, obj, _ = self.hip.sam_heads(1, f2, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
+                                                  pix_bcast=True, add_no_mem_embed=True, mask_inputs=prev_logits)
+        else:
+            # _run_single_frame_inference(output_dict=<this object's slice>, batch_size=1, is_init_cond_frame=False):
+            # memory-conditioned features from the object's own bank entries, then the SAM heads with the prompt
+            mem_entries, ptr_entries = self._bank_for_frame(st, frame_idx, 1, reverse, od=obj_out)
+            memory, memory_pos = self.hip.bank_assemble(1, mem_entries, ptr_entries)
+            pix = self.hip.memory_attention(1, f2, memory, memory_pos, 4 * len(ptr_entries))
+            low, ptr, obj, _ = self.hip.sam_heads(1, pix, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
+                                                  mask_inputs=prev_logits)
         low = self._fill_holes(low)
-        obj_tmp["cond_frame_outputs"][frame_idx] = {
+        obj_tmp[storage_key][frame_idx] = {
             "maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1),
             "obj_ptr": ptr, "object_score_logits": obj.unsqueeze(1)}
-        cons = self._consolidate(st, frame_idx, True, False)
+        cons = self._consolidate(st, frame_idx, is_init_cond_frame, False)
         return frame_idx, st["obj_ids"], self._video_res(st, cons["pred_masks"])
 
     def add_new_points(self, *a, **k):
@@ -408,26 +426,36 @@ class SAM2VideoPredictor:
         non-empty.  A mask of another size is resized to the model resolution (bilinear, antialias) and re-binarised at
         0.5 (:552-561)."""
         st = inference_state
-        obj_idx = self._obj_id_to_idx(st, obj_id)
         if not isinstance(mask, torch.Tensor):
             mask = torch.tensor(np.asarray(mask), dtype=torch.bool)
         assert mask.dim() == 2
+        obj_idx = self._obj_id_to_idx(st, obj_id)
         S = self.image_size
         m = mask.to(self.device).to(torch.float32)[None].contiguous()
         if tuple(m.shape[-2:]) != (S, S):
             m = self.hip.resize_aa(m, S, S, threshold=0.5)
-        st["mask_inputs_per_obj"][obj_idx][frame_idx] = m[None]
-        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
-        if frame_idx in st["frames_already_tracked"]:
-            raise NotImplementedError("correction masks on already-tracked frames are outside the Det-SAM2 hot path")
-        f0, f1, f2 = self._get_image_feature(st, frame_idx)
+        # on an already-tracked frame the mask corrects the tracked output: same computation (the mask IS the output, no
+        # memory is read: track_step :873-879), stored as the frame's non-conditioning entry (:583-586)
+        is_init_cond_frame = frame_idx not in st["frames_already_tracked"]
+        storage_key = "cond_frame_outputs" if is_init_cond_frame else "non_cond_frame_outputs"
+        f0, f1, f2 = self._prompt_features(st, frame_idx)
         low, ptr, obj = self.hip.use_mask_as_output(1, f2, f0, f1, m)
         low = self._fill_holes(low)
-        st["temp_output_dict_per_obj"][obj_idx]["cond_frame_outputs"][frame_idx] = {
+        st["mask_inputs_per_obj"][obj_idx][frame_idx] = m[None]
+        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        st["temp_output_dict_per_obj"][obj_idx][storage_key][frame_idx] = {
             "maskmem_features": None, "maskmem_pos_enc": None, "pred_masks": low.unsqueeze(1), "obj_ptr": ptr,
             "object_score_logits": obj.unsqueeze(1)}
-        cons = self._consolidate(st, frame_idx, True, False)
+        cons = self._consolidate(st, frame_idx, is_init_cond_frame, False)
         return frame_idx, st["obj_ids"], self._video_res(st, cons["pred_masks"])
+
+    def _prompt_features(self, st, frame_idx):
+        """Pyramid of a frame that receives a prompt.  A DS2BANK preload frame carries only its level-2 feature (enough
+        for the A17 re-consolidation), not the image: it cannot be prompted."""
+        f0, f1, f2 = self._get_image_feature(st, frame_idx)
+        if f0 is None or f1 is None:
+            raise RuntimeError(f"frame {frame_idx} is a preload-bank frame without its image: prompts on it are not possible")
+        return f0, f1, f2
 
     def _video_res(self, st, low, packed=False):
         """_get_orig_video_res_output (sam2_video_predictor.py:618-642)."""
@@ -523,10 +551,13 @@ class SAM2VideoPredictor:
                 sel[t] = cond[t]
         return sel, {t: v for t, v in cond.items() if t not in sel}
 
-    def _bank_for_frame(self, st, frame_idx, B, reverse):
+    def _bank_for_frame(self, st, frame_idx, B, reverse, od=None):
         """Index logic of _prepare_memory_conditioned_features (sam2_base.py:500-648): which stored entries
-        enter the bank, their temporal slots and the pointer list.  Returns (mem_entries, ptr_entries)."""
-        od = st["output_dict"]
+        enter the bank, their temporal slots and the pointer list.  Returns (mem_entries, ptr_entries).
+        ``od``: the output dict to read - the batch dict (tracking) or one object's slice (correction prompts, B = 1)."""
+        od = st["output_dict"] if od is None else od
+        if len(od["cond_frame_outputs"]) == 0:
+            raise RuntimeError(f"frame {frame_idx}: no conditioning frame to attend to (sam2_base.py:516)")
         sign = -1 if reverse else 1
         sel, unsel = self._select_cond(frame_idx, od["cond_frame_outputs"], st["preloading_memory_cond_frame_idx"])
         slots = [(0, t, out) for t, out in sel.items()]

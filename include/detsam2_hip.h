@@ -177,7 +177,9 @@ int ds2_obj_ptr_gate(ds2_model* m, int32_t B, float* obj_ptr, const float* obj_l
 int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, int32_t Wv, float* logits,
                     uint8_t* packed, void* stream);
 
-/* ---- arithmetic mode of the matrix-core kernels (process-wide):
+/* ---- arithmetic mode of the matrix-core kernels.  The mode is a property of a MODEL (ds2_model_set_precision; two models
+ * in one process may differ); ds2_set_precision sets the process default that new models start with and that the
+ * model-less primitive ops (ds2_op_*) use:
  *  0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
  *  1 = split-precision bf16x3: x = x0 + x1 in bf16, a0b0 + a0b1 + a1b0 with fp32 accumulation, ~2^-16 relative error
  *      per product;
@@ -190,6 +192,8 @@ int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, i
  * Softmax, LayerNorm, residuals and all storage stay fp32 in every mode. */
 int ds2_set_precision(int32_t mode);
 int ds2_get_precision(void);
+int ds2_model_set_precision(ds2_model* m, int32_t mode);
+int ds2_model_get_precision(const ds2_model* m);   /* -1 for a NULL model */
 
 /* ---- measurement: HIP-event brackets (on the caller's stream) around named launch sites.  Tags:
  * "kernel.cross_attention", "kernel.self_attention", "stage.image_encoder", "stage.memory_attention",

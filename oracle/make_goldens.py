@@ -344,6 +344,71 @@ def e2e_mask(name="sam2.1_hiera_t"):
     print("e2e_mask", dt, "s", out["frames"], out["low"].shape, out["obj_score0"].ravel())
 
 
+def correction_prompts(size=1024):
+    """Seeded correction prompts of e2e_correct (points in video pixels)."""
+    from det_sam2_amd.synth import synthetic_box
+    b0, b1 = synthetic_box(0, 0, size=size), synthetic_box(1, 0, size=size)
+    c0 = np.array([[(b0[0] + b0[2]) / 2, (b0[1] + b0[3]) / 2]], np.float32)
+    c1 = np.array([[(b1[0] + b1[2]) / 2, (b1[1] + b1[3]) / 2], [b1[0] + 12.0, b1[1] + 15.0]], np.float32)
+    yy, xx = np.mgrid[0:size, 0:size]
+    disc = ((xx - 0.375 * size) ** 2 + (yy - 0.125 * size) ** 2) < (0.06 * size) ** 2
+    return [("points", 3, 0, c0, np.array([0], np.int32)),            # a negative click on object 0, frame 3 (1 point)
+            ("points", 4, 1, c1, np.array([1, 0], np.int32)),         # a positive + a negative click on object 1, frame 4
+            ("mask", 2, 1, disc, None)]                               # a mask for object 1 on frame 2
+
+
+def e2e_correct(name="sam2.1_hiera_t"):
+    """A6 completeness: correction prompts on ALREADY-TRACKED frames (sam2_video_predictor.py:428-483,583-586; preflight
+    :836-857) through the reference predictor: boxes for 2 objects on frame 0, forward propagation over 6 frames, then a
+    negative click (frame 3, object 0), two clicks (frame 4, object 1) and a mask (frame 2, object 1), then propagation
+    again - frames 2, 3, 4 come back corrected (consolidated non-conditioning outputs), frames 1 and 5 are re-tracked."""
+    from det_sam2_amd.synth import synthetic_box
+    cfg = resolve_config(name)
+    sd = synthetic_state_dict(cfg, 0)
+    ref = RS.instantiate_from_yaml(f"configs/sam2.1/{name}.yaml", sd)
+    # The Det-SAM2 copy of SAM2VideoPredictor.__init__ (sam2_video_predictor.py:24-40) lost upstream's
+    # `add_all_frames_to_correct_as_cond` argument while :463 / :581 still read it, so AS SHIPPED a prompt on a tracked
+    # frame dies with AttributeError.  The harness sets the attribute to upstream's default (False) - no reference file is
+    # edited - so that the path the attribute guards can be pinned.
+    assert not hasattr(ref, "add_all_frames_to_correct_as_cond")
+    ref.add_all_frames_to_correct_as_cond = False
+    frames = [synthetic_frame(t) for t in range(6)]
+    t0 = time.time()
+    out = {}
+    with torch.inference_mode():
+        st = ref.init_state(frames, offload_video_to_cpu=True, offload_state_to_cpu=False)
+        for o in range(2):
+            ref.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0))
+        first = [(t, (lg > 0).numpy()) for t, ids, lg in ref.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6)]
+        out["first_frames"] = np.array([t for t, _ in first])
+        out["first_bits"] = np.stack([np.packbits(b) for _, b in first])
+        for i, (kind, t, oid, a, b) in enumerate(correction_prompts()):
+            if kind == "points":
+                _, ids, vr = ref.add_new_points_or_box(st, t, oid, points=a, labels=b)
+            else:
+                _, ids, vr = ref.add_new_mask(st, t, oid, a)
+            out[f"prompt_bits{i}"] = np.packbits((vr > 0).numpy())
+            tmp = st["temp_output_dict_per_obj"][oid]
+            assert t in tmp["non_cond_frame_outputs"] and t not in tmp["cond_frame_outputs"]
+            out[f"prompt_low{i}"] = tmp["non_cond_frame_outputs"][t]["pred_masks"].clone().numpy()
+        yields = []
+        for t, ids, logits in ref.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6):
+            od = st["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            yields.append((t, od[key][t]["pred_masks"].clone().numpy(), (logits > 0).numpy()))
+    dt = time.time() - t0
+    od = st["output_dict"]
+    out.update(seconds=np.float64(dt), frames=np.array([y[0] for y in yields]), low=np.stack([y[1] for y in yields]),
+               bits=np.stack([np.packbits(y[2]) for y in yields]),
+               final_cond=np.array(sorted(od["cond_frame_outputs"])), final_noncond=np.array(sorted(od["non_cond_frame_outputs"])),
+               consolidated_noncond=np.array(sorted(st["consolidated_frame_inds"]["non_cond_frame_outputs"])))
+    np.savez_compressed(os.path.join(GOLD, "e2e_correct.npz"), **out)
+    print("e2e_correct", dt, "s", out["frames"], out["low"].shape, out["final_cond"], out["final_noncond"],
+          out["consolidated_noncond"], "changed px by corrections:",
+          [int((np.unpackbits(out[f"prompt_bits{i}"]) != np.unpackbits(out["first_bits"][t].reshape(-1))).sum())
+           for i, (_, t, _, _, _) in enumerate(correction_prompts())])
+
+
 # ---------------------------------------------------------------------------------------------- held-out family
 # VERDICT r2 weak #1: the arithmetic mode bf16x3k was selected against the fixtures above (weight seed 0, uniform-noise
 # frames, |logit| up to 14-17).  The fixtures below were generated AFTER that choice and differ in all three respects:

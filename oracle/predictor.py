@@ -314,21 +314,24 @@ class OraclePredictor:
         pin = {"point_coords": points, "point_labels": labels}
         st["point_inputs_per_obj"][obj_idx][frame_idx] = pin
         st["mask_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        # never tracked => initial conditioning frame (no memory); else a correction conditioned on this object's memory,
+        # stored as a non-conditioning output (:428-433; add_all_frames_to_correct_as_cond is false)
         is_init = frame_idx not in st["frames_already_tracked"]
-        assert is_init, "oracle covers prompts on not-yet-tracked frames only (Det-SAM2 usage)"
+        reverse = False if is_init else st["frames_already_tracked"][frame_idx]["reverse"]
+        key = "cond_frame_outputs" if is_init else "non_cond_frame_outputs"
         obj_out, obj_tmp = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
-        prev = obj_tmp["cond_frame_outputs"].get(frame_idx) or obj_out["cond_frame_outputs"].get(frame_idx) \
+        prev = obj_tmp[key].get(frame_idx) or obj_out["cond_frame_outputs"].get(frame_idx) \
             or obj_out["non_cond_frame_outputs"].get(frame_idx)
         prev_logits = None
         if prev is not None and prev["pred_masks"] is not None:
             prev_logits = torch.clamp(prev["pred_masks"], -32.0, 32.0)
-        cur, _ = self.single_frame(st, obj_out, frame_idx, 1, True, pin, None, False, False, prev_logits)
-        obj_tmp["cond_frame_outputs"][frame_idx] = cur
-        cons = self.consolidate(st, frame_idx, True, False, True)
+        cur, _ = self.single_frame(st, obj_out, frame_idx, 1, is_init, pin, None, reverse, False, prev_logits)
+        obj_tmp[key][frame_idx] = cur
+        cons = self.consolidate(st, frame_idx, is_init, False, True)
         return frame_idx, st["obj_ids"], self.video_res(st, cons["pred_masks_video_res"])
 
     def add_new_mask(self, st, frame_idx, obj_id, mask):
-        """add_new_mask (sam2_video_predictor.py:527-616) on a not-yet-tracked frame: the mask (resized with antialiasing
+        """add_new_mask (sam2_video_predictor.py:527-616) (on a tracked frame the output is stored as a non-conditioning entry): the mask (resized with antialiasing
         to the model resolution and re-binarised at 0.5 when its size differs, :552-561) IS the output
         (_use_mask_as_output, sam2_base.py:399-448); the SAM heads only supply the object pointer."""
         obj_idx = self.obj_id_to_idx(st, obj_id)
@@ -341,11 +344,12 @@ class OraclePredictor:
         st["mask_inputs_per_obj"][obj_idx][frame_idx] = m
         st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
         is_init = frame_idx not in st["frames_already_tracked"]
-        assert is_init, "oracle covers prompts on not-yet-tracked frames only (Det-SAM2 usage)"
+        reverse = False if is_init else st["frames_already_tracked"][frame_idx]["reverse"]
+        key = "cond_frame_outputs" if is_init else "non_cond_frame_outputs"
         obj_out, obj_tmp = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
-        cur, _ = self.single_frame(st, obj_out, frame_idx, 1, True, None, m, False, False)
-        obj_tmp["cond_frame_outputs"][frame_idx] = cur
-        cons = self.consolidate(st, frame_idx, True, False, True)
+        cur, _ = self.single_frame(st, obj_out, frame_idx, 1, is_init, None, m, reverse, False)
+        obj_tmp[key][frame_idx] = cur
+        cons = self.consolidate(st, frame_idx, is_init, False, True)
         return frame_idx, st["obj_ids"], self.video_res(st, cons["pred_masks_video_res"])
 
     def video_res(self, st, masks):

@@ -414,3 +414,41 @@ def test_heldout_16_objects_low_margin_matches_reference_golden(golden_dir):
         for t in range(3):
             vp.process_frame(t, synthetic_frame(t, structured=st))
     _check_compact(g, lows)
+
+
+def test_e2e_correction_prompts_match_reference_golden(tiny, golden_dir):
+    """A6: prompts on already-tracked frames (sam2_video_predictor.py:428-483,583-586) - golden e2e_correct."""
+    from det_sam2_amd.synth import synthetic_box
+    from oracle.make_goldens import correction_prompts
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_correct.npz"))
+    op = OraclePredictor(sd, cfg)
+    with torch.inference_mode():
+        st = op.init_state([synthetic_frame(t) for t in range(6)])
+        for o in range(2):
+            op.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0))
+        first = [(t, (lg > 0).numpy()) for t, ids, lg in op.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6)]
+        assert [t for t, _ in first] == list(g["first_frames"])
+        for i, (kind, t, oid, a, b) in enumerate(correction_prompts()):
+            if kind == "points":
+                _, ids, vr = op.add_new_points_or_box(st, t, oid, points=a, labels=b)
+            else:
+                _, ids, vr = op.add_new_mask(st, t, oid, a)
+            tmp = st["temp_output_dict_per_obj"][oid]
+            assert t in tmp["non_cond_frame_outputs"] and t not in tmp["cond_frame_outputs"]
+            assert np.abs(tmp["non_cond_frame_outputs"][t]["pred_masks"].numpy() - g[f"prompt_low{i}"]).max() <= 2e-4
+            ref = np.unpackbits(g[f"prompt_bits{i}"]).reshape(2, 1, 1024, 1024).astype(bool)
+            for o in range(2):
+                assert 1.0 - _iou((vr > 0).numpy()[o], ref[o]) <= 1e-3, (i, o)
+        ys = list(op.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6))
+    assert [y[0] for y in ys] == list(g["frames"])
+    od = st["output_dict"]
+    assert sorted(od["cond_frame_outputs"]) == list(g["final_cond"])
+    assert sorted(od["non_cond_frame_outputs"]) == list(g["final_noncond"])
+    assert sorted(st["consolidated_frame_inds"]["non_cond_frame_outputs"]) == list(g["consolidated_noncond"])
+    for i, (t, ids, logits) in enumerate(ys):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        assert np.abs(od[key][t]["pred_masks"].numpy() - g["low"][i]).max() <= 5e-4
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            assert 1.0 - _iou((logits > 0).numpy()[o], ref[o]) <= 1e-3, (t, o)

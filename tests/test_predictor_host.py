@@ -1,0 +1,76 @@
+"""Host logic of the predictor state machine over the CPU stand-in for the stages (tests/_fake_hip.py): the paths whose
+control flow matters more than their arithmetic.  The arithmetic of the same paths is pinned on the GPU against reference
+goldens (tests/test_hip_correct.py) and in the oracle (tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from _fake_hip import fake_predictor
+from det_sam2_amd.synth import synthetic_box
+
+
+def _frames(n):
+    rng = np.random.default_rng(3)
+    return [rng.integers(0, 256, (64, 64, 3), dtype=np.uint8) for _ in range(n)]
+
+
+def _tracked(p):
+    return p.stats["tracked_frames"]
+
+
+def test_correction_prompts_on_tracked_frames():
+    """sam2_video_predictor.py:428-483 (points), :583-586 (mask), preflight :836-857: a prompt on a tracked frame runs a
+    memory-conditioned single-object pass in the frame's tracking direction, is stored as a NON-conditioning temp output,
+    consolidated by the next preflight (memory re-encoded), reused by the next propagation; the frames around it are
+    re-tracked."""
+    p = fake_predictor()
+    st = p.init_state(_frames(6))
+    for o in range(2):
+        p.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0, size=64))
+    first = {t: m.clone() for t, _, m in p.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6)}
+    assert sorted(first) == list(range(6)) and _tracked(p) == 5
+    assert st["frames_already_tracked"][3] == {"reverse": False}
+    ma0 = p.hip.calls["memory_attention"]
+    old3 = st["output_dict"]["non_cond_frame_outputs"][3]["pred_masks"].clone()
+    # (1) a negative click on object 0, frame 3
+    t, ids, vr = p.add_new_points_or_box(st, 3, 0, points=np.array([[20.0, 20.0]], np.float32), labels=np.array([0], np.int32))
+    assert (t, list(ids)) == (3, [0, 1]) and vr.shape == (2, 1, 64, 64)
+    assert p.hip.calls["memory_attention"] == ma0 + 1                       # memory-conditioned, unlike an init-cond prompt
+    tmp = st["temp_output_dict_per_obj"][0]
+    assert 3 in tmp["non_cond_frame_outputs"] and 3 not in tmp["cond_frame_outputs"]
+    assert tmp["non_cond_frame_outputs"][3]["maskmem_features"] is None     # memory encoder deferred to the preflight
+    assert not torch.equal(tmp["non_cond_frame_outputs"][3]["pred_masks"][0], old3[0])
+    # the returned masks: object 0 corrected, object 1 as tracked
+    low1 = p.hip.mask_output(old3[1:2, 0], 64, 64)[0]
+    assert torch.equal(vr[1], low1[0])
+    # (2) a second click on the same frame feeds the first correction back as mask prompt (prev_sam_mask_logits)
+    p.add_new_points_or_box(st, 3, 0, points=np.array([[24.0, 20.0]], np.float32), labels=np.array([1], np.int32))
+    assert p.hip.calls["memory_attention"] == ma0 + 2
+    # (3) a mask on object 1, frame 2 (tracked): stored as non-cond too, no memory read
+    m = np.zeros((64, 64), bool)
+    m[10:30, 12:40] = True
+    p.hip.resize_aa = lambda x, h, w, threshold=0.5: (torch.nn.functional.interpolate(x[None], size=(h, w))[0] >= threshold).float()
+    p.add_new_mask(st, 2, 1, m)
+    assert 2 in st["temp_output_dict_per_obj"][1]["non_cond_frame_outputs"]
+    assert p.hip.calls["memory_attention"] == ma0 + 2
+    # second propagation: frames 2, 3 come back consolidated, 1, 4, 5 are re-tracked
+    n0 = _tracked(p)
+    second = {t: m.clone() for t, _, m in p.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6)}
+    assert _tracked(p) == n0 + 3
+    assert sorted(st["consolidated_frame_inds"]["non_cond_frame_outputs"]) == [2, 3]
+    od = st["output_dict"]
+    assert sorted(od["cond_frame_outputs"]) == [0] and sorted(od["non_cond_frame_outputs"]) == [1, 2, 3, 4, 5]
+    assert od["non_cond_frame_outputs"][3]["maskmem_features"] is not None
+    assert all(not d["non_cond_frame_outputs"] and not d["cond_frame_outputs"] for d in st["temp_output_dict_per_obj"].values())
+    assert torch.equal(second[0], first[0]) and torch.equal(second[1], first[1])      # before the corrections: unchanged
+    assert not torch.equal(second[3], first[3]) and not torch.equal(second[4], first[4])   # corrected / downstream of it
+
+
+def test_prompt_on_unencodable_frame_is_a_clear_error():
+    p = fake_predictor()
+    st = p.init_state(_frames(4))
+    p.add_new_points_or_box(st, 0, 0, box=synthetic_box(0, 0, size=64))
+    list(p.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=4))
+    p.release_old_frames(st, 3, 2, 0, release_images=True)                 # frames 0, 1 are gone
+    with pytest.raises(RuntimeError, match="cannot be encoded"):
+        p.add_new_points_or_box(st, 1, 0, points=np.array([[5.0, 5.0]], np.float32), labels=np.array([1], np.int32))
