@@ -55,15 +55,36 @@ def cross_attention_bytes(B, Nk, tokens=4096, d=256, dv=64, precision="bf16x3", 
     return 4.0 * B * (tokens * d + Nk * d + Nk * dv + tokens * dv)
 
 
-def pmc_traffic(B, nk, precision):
-    """HBM bytes per cross-attention launch from the committed PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE, separate runs of this same bench command; PMC cannot be collected from inside the
-    timed run).  None if the file does not match this workload."""
-    path = os.path.join(ROOT, "profiles", {"bf16x3": "r01_pmc_cross_attention.json", "bf16x3k": "r02_pmc_cross_attention.json"}.get(precision, "-"))
-    if B != 16 or nk != 28736 or not os.path.exists(path):
+def committed_pmc_traffic(kernel_key, B, nk, precision):
+    """HBM bytes per launch of a kernel from the COMMITTED PMC passes (tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs of this same bench command - counters cannot be collected from inside the timed run, so
+    the bench line's own `traffic` is null and this number is reported under `traffic_from_committed_pmc` with its
+    source file).  None if no committed file matches this workload."""
+    if B != 16 or nk != 28736 or precision != "bf16x3k":
         return None
-    with open(path) as f:
-        return float(json.load(f)["traffic_bytes_per_launch"])
+    for name in ("r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            d = json.load(f)
+        if kernel_key in d:
+            return {"bytes_per_launch": float(d[kernel_key]["traffic_bytes_per_launch"]), "source": f"profiles/{name}",
+                    "algorithmic_bytes": d[kernel_key].get("algorithmic_bytes")}
+        if kernel_key == "cross_attention" and "traffic_bytes_per_launch" in d:
+            return {"bytes_per_launch": float(d["traffic_bytes_per_launch"]), "source": f"profiles/{name}"}
+    return None
+
+
+# SURVEY.md section 8(d): algorithmic GFLOP of one tracked frame (2 x MAC; matmul + conv + SDPA as torch's FlopCounterMode
+# counts them on the reference): F = F_enc + B * (F_ma(Nk) + 3.64 + 11.61), F_ma(Nk) = 116.0 + 0.017039 * Nk
+F_ENC_GFLOP = {"sam2.1_hiera_t": 207.0, "sam2.1_hiera_b+": 529.3, "sam2.1_hiera_l": 1619.7}
+
+
+def path_flops(model_name, B, nk):
+    if model_name not in F_ENC_GFLOP:
+        return None
+    return (F_ENC_GFLOP[model_name] + B * (116.0 + 0.017039 * nk + 3.64 + 11.61)) * 1e9
 
 
 def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
@@ -100,47 +121,84 @@ def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
                       f"encoder {t_enc:.1f}s + per-object {t_obj:.1f}s; value = 1/(t_enc+16*t_obj)"}
 
 
-def gemm_probe(pred, gen, st, last_tracked, table_path=None):
-    """roofline_gemm: GEMM_PROBE more tracked frames of the same generator with one HIP-event bracket per GEMM
-    (ds2_profile_enable(2), tags "gemm M N K"), outside the timed region so the brackets cannot perturb `value`.
-    Reports the shape with the largest total time: achieved = algorithmic 2*M*N*K / mean bracket time vs the dense bf16
-    MFMA peak (bf16x3 executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3), plus the whole family per frame."""
+def kernel_probe(pred, gen, st, last_tracked, table_path=None):
+    """GEMM_PROBE more tracked frames of the same generator with HIP-event brackets per GEMM shape ("gemm M N K": the GEMM
+    incl. its operand-split pre-pass), per GEMM KERNEL ("kern <name> M N K": the kernel alone) and per attention kernel,
+    outside the timed region so the brackets cannot perturb `value` (ds2_profile_enable(2)).  The async encoder is
+    switched off for these frames, so every duration is the kernel alone on the chip.
+    -> (roofline_gemm: the family + its largest-time shape, by_kernel: {kernel: {ms_per_frame, flops_per_frame, launches}})."""
     for t in [t for t in st["cached_features"] if t > last_tracked]:     # the probe encodes exactly one batch of new frames
         st["cached_features"].pop(t)
     for t in [t for t in (st.get("_pending_features") or {}) if t > last_tracked]:
         st["_pending_features"].pop(t)
+    was_async, pred.async_encode = pred.async_encode, False
+    torch.cuda.synchronize()
+    pred.trace = []
     pred.hip.profile_enable(True, gemm_shapes=True)
     for _ in range(GEMM_PROBE):
         next(gen)
     torch.cuda.synchronize()
     pred.hip.profile_enable(False)
-    rows = []
+    pred.async_encode = was_async
+    B = int(st["output_dict"]["cond_frame_outputs"][0]["obj_ptr"].shape[0])
+    nks = [tr["nk"] for tr in pred.trace]
+    rows, kern = [], {}
     for tag in pred.hip.profile_tags():
         ms, n = pred.hip.profile_read(tag)
-        if tag.startswith("gemm ") and n:
+        if not n:
+            continue
+        if tag.startswith("gemm "):
             M, N, Kd = (int(x) for x in tag.split()[1:4])
             rows.append({"M": M, "N": N, "K": Kd, "calls_per_frame": n / GEMM_PROBE, "ms_per_frame": ms / GEMM_PROBE,
                          "avg_us": ms / n * 1e3, "tflops": 2.0 * M * N * Kd / (ms / n * 1e-3) / 1e12})
+        elif tag.startswith("kern "):
+            name, M, N, Kd = tag.split()[1], *(int(x) for x in tag.split()[2:5])
+            k = kern.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0, "shapes": {}})
+            k["ms"] += ms
+            k["flops"] += 2.0 * M * N * Kd * n          # Kd is K rounded up to 32 (the pad columns are multiplied too)
+            k["launches"] += n
+            k["shapes"][(M, N, Kd)] = (ms, n)
+        elif tag == "kernel.cross_attention":
+            kern["k_attention_w8<64,2> (memory cross-attention)"] = {
+                "ms": ms, "flops": sum(cross_attention_flops(B, nk) for nk in nks) * pred.cfg.mem_attn_layers, "launches": n}
+        elif tag == "kernel.self_attention":
+            kern["k_attention_w8<256,1> (memory self-attention, incl. its V^T split)"] = {
+                "ms": ms, "flops": len(nks) * (1 + (pred.cfg.mem_attn_layers - 1) * B) * 2.0 * 4096 * 4096 * 512, "launches": n}
+        elif tag == "kernel.hiera_attention":
+            kern["Hiera attention (k_attention_bf16x3 / k_attn_smallwin)"] = {"ms": ms, "flops": None, "launches": n}
     if not rows:
-        return None
+        return None, {}
     rows.sort(key=lambda r: -r["ms_per_frame"])
     total = sum(r["ms_per_frame"] for r in rows)
     flops = sum(2.0 * r["M"] * r["N"] * r["K"] * r["calls_per_frame"] for r in rows)
+    by_kernel = {}
+    for name, k in kern.items():
+        by_kernel[name] = {"ms_per_frame": k["ms"] / GEMM_PROBE, "launches_per_frame": k["launches"] / GEMM_PROBE,
+                           "avg_launch_ms": k["ms"] / k["launches"],
+                           "tflops": None if k["flops"] is None else k["flops"] / (k["ms"] * 1e-3) / 1e12,
+                           "flops_per_launch": None if k["flops"] is None else k["flops"] / k["launches"]}
     if table_path:
         with open(table_path, "w") as f:
-            f.write(f"# per-shape GEMM table, HIP events, {GEMM_PROBE} tracked frames; total {total:.3f} ms/frame, "
+            f.write(f"# per-shape GEMM table, HIP events, {GEMM_PROBE} tracked frames, async encoder off; total {total:.3f} ms/frame, "
                     f"{flops / (total * 1e-3) / 1e12:.1f} algorithmic TFLOP/s overall\n")
             f.write(f"{'M':>8s} {'N':>6s} {'K':>6s} {'calls/frame':>12s} {'ms/frame':>9s} {'avg_us':>9s} {'TFLOP/s':>8s}\n")
             for r in rows:
                 f.write(f"{r['M']:8d} {r['N']:6d} {r['K']:6d} {r['calls_per_frame']:12.2f} {r['ms_per_frame']:9.3f} {r['avg_us']:9.1f} {r['tflops']:8.1f}\n")
+            f.write("# per kernel (the kernel alone, K rounded up to 32)\n")
+            for name, k in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms_per_frame"]):
+                f.write(f"# {name:70s} {k['ms_per_frame']:8.3f} ms/frame {k['launches_per_frame']:7.1f} launches/frame "
+                        f"{(k['tflops'] or 0.0):8.1f} TFLOP/s\n")
+                for (M, N, Kd), (ms, n) in sorted(kern[name].get("shapes", {}).items(), key=lambda kv: -kv[1][0]):
+                    f.write(f"#     {M:8d} {N:6d} {Kd:6d} {n / GEMM_PROBE:8.2f}/frame {ms / n * 1e3:9.1f} us {2.0 * M * N * Kd / (ms / n * 1e-3) / 1e12:8.1f} TFLOP/s\n")
     top = rows[0]
     peak = PEAK_TFLOPS[pred.hip.get_precision()]
-    return {"bound": "mfma", "kernel": "bf16x3 GEMM family (k_gemm_split*), largest-time shape", "shape": [top["M"], top["N"], top["K"]],
-            "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": top["tflops"] / peak, "avg_launch_ms": top["avg_us"] * 1e-3,
-            "calls_per_frame": top["calls_per_frame"], "family_ms_per_frame": total, "family_tflops": flops / (total * 1e-3) / 1e12,
-            "family_frac": flops / (total * 1e-3) / 1e12 / peak,
-            "note": "HIP-event bracket per GEMM (incl. its operand-split pre-pass when the producer did not emit planes), "
-                    f"{GEMM_PROBE} frames after the timed region; algorithmic FLOPs 2*M*N*K"}
+    fam = {"bound": "mfma", "kernel": "bf16x3 GEMM family (k_gemm_split*), largest-time shape", "shape": [top["M"], top["N"], top["K"]],
+           "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": top["tflops"] / peak, "avg_launch_ms": top["avg_us"] * 1e-3,
+           "calls_per_frame": top["calls_per_frame"], "family_ms_per_frame": total, "family_tflops": flops / (total * 1e-3) / 1e12,
+           "family_frac": flops / (total * 1e-3) / 1e12 / peak,
+           "note": "HIP-event bracket per GEMM (incl. its operand-split pre-pass when the producer did not emit planes), "
+                   f"{GEMM_PROBE} frames after the timed region with the async encoder off; algorithmic FLOPs 2*M*N*K"}
+    return fam, by_kernel
 
 
 def stream_fps(pred, B, n_frames):
@@ -182,7 +240,7 @@ def bench_sharded(a, pred, cfg, world, rank, dev):
     vp = ShardedVideoProcessor(model_cfg=cfg.name, detector=SyntheticDetector(B), skip_classes=set(), predictor=pred,
                                frame_buffer_size=b, detect_interval=b, max_frame_num_to_track=K, max_inference_state_frames=K)
     per_round = world * b
-    frames = [synthetic_frame(t, 4242) for t in range((warm_rounds + 1) * per_round)]       # host uint8, same on every rank
+    frames = [synthetic_frame(t, 4242) for t in range((warm_rounds + 2) * per_round)]       # host uint8, same on every rank
     t = 0
     for _ in range(warm_rounds * per_round):
         vp.process_frame(t, frames[t])
@@ -203,6 +261,19 @@ def bench_sharded(a, pred, cfg, world, rank, dev):
     pred.hip.profile_enable(False)
     tracked = pred.stats["tracked_frames"] - tracked0
     cond_yield = K - tracked          # conditioning frames inside the window are yielded without tracking
+    # one more round, UNTIMED, with a device synchronisation at every phase boundary: where a round's wall time goes
+    # (ingest / encode / detect / prompt / gather = the all-gathers / ring_wait = what is left of the posted hand-off /
+    # propagate), per rank - so that the first real multi-GPU run explains itself
+    vp.profile_rounds = True
+    for _ in range(per_round):
+        vp.process_frame(t, frames[t])
+        t += 1
+    vp.profile_rounds = False
+    split = vp.round_times[-1] if vp.round_times else {}
+    names = ["ingest", "encode", "detect", "prompt", "gather", "ring_wait", "propagate"]
+    sp = torch.tensor([split.get(k, 0.0) for k in names], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    sp_all = [torch.zeros_like(sp) for _ in range(world)]
+    dist.all_gather(sp_all, sp)
     stats = torch.tensor([dt, tracked, pred.stats["encoder_runs"] - enc0], dtype=torch.float64,
                          device=dev if dist.get_backend() == "nccl" else "cpu")
     tmax = stats.clone()
@@ -235,9 +306,11 @@ def bench_sharded(a, pred, cfg, world, rank, dev):
                                    f"{K - cond_yield} tracked and {cond_yield} conditioning; value counts tracked frames; bank of up to 3 conditioning + 6 "
                                    f"non-conditioning frames (Nk {min(nks) if nks else 0}..{max(nks) if nks else 0}); synthetic checkpoint seed 0",
                        "objects": B, "Nk_max": max(nks) if nks else 0, "frames_per_rank": K, "encode_batch": pred.encode_batch,
-                       "parallelism": f"one stream, pass-sharded over {world} ranks; RCCL: all_gather_object(detections), all_gather(cond entries), "
-                                      f"ring send/recv(feature pyramids)",
+                       "parallelism": f"one stream, pass-sharded over {world} ranks; RCCL per round: 2 small fixed-size all_gathers (detections "
+                                      f"fp64 [256,7], entry metadata int32 [32,2]), 1 all_gather of the new cond entries, 1 posted ring "
+                                      f"send/recv of the feature pyramids (waited for before the propagation)",
                        "comm_bytes_per_round": comm,
+                       "round_time_split_s_by_rank": [{k: round(float(v), 4) for k, v in zip(names, x.tolist())} for x in sp_all],
                        "encoder_runs_per_round_all_ranks": float(tsum[2].item()), "new_frames_per_round": per_round},
             "stream_fps": per_round / dt,
             "roofline": {"bound": "mfma", "kernel": "memory cross-attention (k_attention_w8), 1 launch/layer, per-frame Nk from the bank trace",
@@ -355,13 +428,42 @@ def main():
         ms, n = pred.hip.profile_read(tag)
         stage_ms[tag] = round(ms / max(K, 1), 3)
     st["_encode_order"] = full_order
-    gemm = gemm_probe(pred, gen, st, PREFILL + W + K, a.gemm_table) if rank == 0 else None
+    pred.trace = None
+    gemm, by_kernel = kernel_probe(pred, gen, st, PREFILL + W + K, a.gemm_table) if rank == 0 else (None, {})
     del gen, st
     stream = None
     if rank == 0 and world == 1 and not a.no_stream:
         stream = stream_fps(pred, B, a.stream_frames)
     if rank == 0:
+        peak = PEAK_TFLOPS[a.precision]
         achieved = cross_attention_flops(B, nk) / (ca_ms / max(ca_n, 1) * 1e-3) / 1e12 if ca_n else None
+        cross = {"bound": "mfma",
+                 "kernel": "memory cross-attention (k_attention_w8<64,2> in bf16x3 modes, k_attention<256,64> in fp32 mode), 1 launch/layer",
+                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": None if achieved is None else achieved / peak,
+                 "traffic": None, "traffic_from_committed_pmc": committed_pmc_traffic("cross_attention", B, nk, a.precision),
+                 "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
+                 "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
+                 "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time INSIDE the timed "
+                         "region (with async_encode the next encoder batch shares the CUs for ~60 % of it: reads ~5 % longer than the "
+                         "kernel alone, which `by_kernel` below gives); executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 "
+                         "(frac <= 1/3), bf16x3k 1.0"}
+        # the dominant kernel = the one with the largest total time per tracked frame (HIP events, kernels alone)
+        dom = None
+        cand = {k: v for k, v in by_kernel.items() if v["tflops"] is not None}
+        if cand:
+            name = max(cand, key=lambda k: cand[k]["ms_per_frame"])
+            v = cand[name]
+            is_gemm = name.startswith("k_gemm_split")
+            dom = {"bound": "mfma", "kernel": name, "achieved": v["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": v["tflops"] / peak,
+                   "traffic": None,
+                   "traffic_from_committed_pmc": committed_pmc_traffic(name.split()[0].split("<")[0] if is_gemm else "cross_attention", B, nk, a.precision),
+                   "avg_launch_ms": v["avg_launch_ms"], "launches_per_frame": v["launches_per_frame"], "ms_per_frame": v["ms_per_frame"],
+                   "algorithmic_flops_per_launch_mean": v["flops_per_launch"],
+                   "note": "the kernel with the largest total time per tracked frame (per-kernel HIP-event brackets over one encoder "
+                           f"batch of {GEMM_PROBE} frames right after the timed region, async encoder off = the kernel alone); achieved = "
+                           "sum of algorithmic FLOPs of its launches / sum of their durations"
+                           + ("; a bf16x3 GEMM executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3" if is_gemm else "")}
+        pf = path_flops(cfg.name, B, nk)
         out = {
             "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -376,19 +478,15 @@ def main():
                        "objects": B, "Nk": nk, "frames_per_rank": K, "encode_batch": pred.encode_batch,
                        "async_encode": bool(pred.async_encode),
                        "parallelism": "single GPU" if world == 1 else f"{world} independent replica streams (BASELINE config 5) + one RCCL all-gather of a cond entry"},
-            "roofline": {"bound": "mfma",
-                         "kernel": "memory cross-attention (k_attention_w8 in bf16x3 mode, k_attention<256,64> in fp32 mode), 1 launch/layer",
-                         "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
-                         "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision],
-                         "traffic": pmc_traffic(B, nk, a.precision), "traffic_unit": "bytes/launch",
-                         "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
-                         "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
-                         "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time "
-                                 "(with async_encode the next encoder batch runs concurrently on a second stream for ~60 % of the "
-                                 "timed region and shares the CUs: launch times read ~5 % longer than in isolation, "
-                                 "DS2_ASYNC_ENCODE=0 measures the kernel alone); "
-                                 "executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 (frac <= 1/3), bf16x3k 1.0 (one-term scores, "
-                                 "one-term P.V on the bf16-stored frame tokens)"},
+            "roofline": dom if dom is not None else cross,
+            "roofline_cross_attention": cross,
+            "roofline_path": None if pf is None else {
+                "bound": "mfma", "achieved": pf * world * K / dt / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": pf * world * K / dt / 1e12 / peak,
+                "flops_per_frame": pf,
+                "note": "SURVEY 8(d): F(config) * tracked frames / wall time, F = F_enc + B*(F_ma(Nk) + 3.64 + 11.61) GFLOP as torch's "
+                        "FlopCounterMode counts the reference (it materialises V: 2*(256+256) per score instead of the 2*(256+64) executed here)"},
+            "by_kernel": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                          for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms_per_frame"])},
             "ms_per_step_by_stage": stage_ms,
         }
         if gemm is not None:

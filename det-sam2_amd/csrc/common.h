@@ -138,6 +138,10 @@ struct ds2_precision_scope {
   ~ds2_precision_scope() { t_ds2_precision = prev; }
 };
 
+// per-kernel HIP-event brackets (ds2_profile_enable(2)): tag "kern <kernel> M N K", the kernel alone (no operand pre-pass)
+bool ds2_prof_kernels();
+void ds2_prof_record(const char* tag, hipEvent_t a, hipEvent_t b);   // takes ownership of the two recorded events
+
 int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
                      float eps, int act, hipStream_t st);
 

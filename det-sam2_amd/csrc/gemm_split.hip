@@ -343,7 +343,22 @@ int heuristic_tile(const GemmSplitArgs& g) {
   return tile;
 }
 
-int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
+int launch_tile_impl(const GemmSplitArgs& g_in, int tile, hipStream_t st, const char** kname);
+int launch_tile(const GemmSplitArgs& g, int tile, hipStream_t st) {
+  if (!ds2_prof_kernels()) { const char* k; return launch_tile_impl(g, tile, st, &k); }
+  // the kernel that will run is only known after the fall-backs: bracket with a provisional tag, then rename
+  const char* k = "?";
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return launch_tile_impl(g, tile, st, &k);
+  (void)hipEventRecord(a, st);
+  const int rc = launch_tile_impl(g, tile, st, &k);
+  (void)hipEventRecord(b, st);
+  char tag[96];
+  snprintf(tag, sizeof(tag), "kern %s %d %d %d", k, g.M, g.N, g.Kp);
+  ds2_prof_record(tag, a, b);
+  return rc;
+}
+int launch_tile_impl(const GemmSplitArgs& g_in, int tile, hipStream_t st, const char** kname) {
   GemmSplitArgs g = g_in;
   {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
     static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
@@ -357,9 +372,10 @@ int launch_tile(const GemmSplitArgs& g_in, int tile, hipStream_t st) {
   const bool fits32 = (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32);   // 32-bit DMA offsets
   if (tile == 10 && !(gemm_split_pp256_supported(g) && fits32)) tile = 5;
   if (tile == 5 && !fits32) tile = 3;
-  if (tile == 10) return launch_gemm_split_pp256(g, st);
-  if (tile == 5) return launch_gemm_split_d256(g, st);
-  if (tile == 3) return launch_gemm_split_r3(g, st);
+  if (tile == 10) { *kname = "k_gemm_split_pp256"; return launch_gemm_split_pp256(g, st); }
+  if (tile == 5) { *kname = "k_gemm_split_d256"; return launch_gemm_split_d256(g, st); }
+  if (tile == 3) { *kname = "k_gemm_split_r3"; return launch_gemm_split_r3(g, st); }
+  *kname = "k_gemm_split";
   const int mt = cdiv(g.M, BM), nt = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, BN);
   static const int dbg = [] { const char* e = getenv("DS2_GEMM_DBG"); return e ? atoi(e) : 0; }();
   switch (dbg) {   // ablation builds for profiling only (results are wrong for dbg != 0)
@@ -387,6 +403,17 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   if (tile_env != 0) return launch_tile(g, tile_env, st);
   // K = 64 projections over hundreds of thousands of rows (memory-attention keys): HBM-bound weight-stationary kernel
   static const bool k64 = [] { const char* e = getenv("DS2_GEMM_K64"); return !(e && atoi(e) == 0); }();
-  if (k64 && gemm_split_k64_supported(g)) return launch_gemm_split_k64(g, st);
+  if (k64 && gemm_split_k64_supported(g)) {
+    if (!ds2_prof_kernels()) return launch_gemm_split_k64(g, st);
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return launch_gemm_split_k64(g, st);
+    (void)hipEventRecord(a, st);
+    const int rc = launch_gemm_split_k64(g, st);
+    (void)hipEventRecord(b, st);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "kern k_gemm_split_k64 %d %d %d", g.M, g.N, g.Kp);
+    ds2_prof_record(tag, a, b);
+    return rc;
+  }
   return launch_tile(g, heuristic_tile(g), st);
 }

@@ -57,6 +57,8 @@ struct ProfScope {
   }
 };
 }  // namespace
+bool ds2_prof_kernels() { return g_prof && g_prof_gemm; }
+void ds2_prof_record(const char* tag, hipEvent_t a, hipEvent_t b) { g_recs[tag].push_back(ProfRec{a, b}); }
 extern "C" int ds2_profile_enable(int32_t on) { g_prof = on != 0; g_prof_gemm = on == 2; return DS2_OK; }
 // newline-separated list of the tags that currently hold records (for per-shape GEMM tables: tags "gemm M N K ...")
 extern "C" int ds2_profile_tags(char* buf, int64_t cap) {
@@ -683,7 +685,10 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
       TRY(new_act_planes(m, a, hwq, b.dim_out, &ap, st));
       aa.o_hi = ap.hi; aa.o_lo = ap.lo; aa.ldop = ap.ld;
     }
-    TRY(launch_attention(aa, st));
+    {
+      ProfScope _pa("kernel.hiera_attention", st);
+      TRY(launch_attention(aa, st));
+    }
     TRY(linear(m, st, p + ".attn.proj", hwq, b.dim_out, b.dim_out, a, b.dim_out, xn, b.dim_out, DS2_ACT_NONE, sc, b.dim_out));
     ALLOC(t2, (size_t)hwq * b.dim_out);
     TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f, DS2_ACT_NONE, true));

@@ -9,9 +9,11 @@ pass k -> rank k mod N, and a round is
 
     1. every rank encodes the frames of ITS OWN buffer once and hands the pyramids to the owner of the next pass
        (ring shift over one xGMI link: buffer x 16 MiB) - a frame is encoded exactly once per stream although two passes
-       (on two ranks) track it;
-    2. every rank runs the detector on its buffer; the detections (a few boxes) are all-gathered, so every rank derives
-       the same object table for every pass of the round;
+       (on two ranks) track it.  The shift is POSTED here and waited for only before step 5 (the received pyramids are
+       first read by the propagation), so steps 2-4 run under the transfer;
+    2. every rank runs the detector on its buffer; the detections are all-gathered as ONE fixed-size tensor per rank
+       ([1 + MAX_DET, 7] fp64: frame, xyxy, class, confidence; row 0 = count - no pickling, one collective), so every
+       rank derives the same object table for every pass of the round;
     3. every rank prompts + consolidates ITS conditioning frame(s) - ~50 ms, no dependence on other passes;
     4. ONE all-gather replicates the new conditioning entries (bf16 memory + masks + pointers + the frame's level-2
        feature: ~16 MiB per entry at 16 objects) - the only bank traffic, RCCL over xGMI;
@@ -109,63 +111,65 @@ def install_cond_entry(predictor, inference_state, frame_idx: int, entry: Dict[s
 
 # ------------------------------------------------------------------------------------------------------------------
 # communication back ends.  A round yields requests (op, payload); a back end answers them.
-#   ("all_gather_object", obj)                          -> [obj of rank 0, ..., obj of rank N-1]
-#   ("all_gather_bytes", uint8 tensor, same size/rank)  -> [tensor of rank 0, ...]
-#   ("ring_shift", (send tensors, recv tensors))        -> recv tensors filled by rank-1's send tensors (to rank+1)
+#   ("all_gather_tensor", tensor, same shape/rank)      -> [tensor of rank 0, ..., tensor of rank N-1]   (fixed size)
+#   ("ring_shift_begin", (send tensors, recv tensors))  -> handle; rank r's send tensors travel to rank r+1's recv tensors
+#   ("ring_shift_wait", handle)                         -> the recv tensors, filled
 # ------------------------------------------------------------------------------------------------------------------
 class TorchDistComm:
     """torch.distributed back end.  "nccl" (= RCCL on ROCm) moves device tensors directly over xGMI; under "gloo" (CPU
-    tests, and single-GPU dry runs of the multi-rank code path) device tensors are staged through the host."""
+    tests, and single-GPU dry runs of the multi-rank code path) device tensors are staged through the host.  Small host
+    tensors (detections, entry metadata) are moved to the device for RCCL and back."""
 
     def __init__(self, group=None, device=None):
         self.group, self.device = group, device
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.host_staged = dist.get_backend(group) == "gloo"
 
-    def _out(self, t):
-        return t.cpu() if (self.host_staged and t.is_cuda) else t
+    def _wire(self, t):
+        if self.host_staged:
+            return t.cpu() if t.is_cuda else t
+        return t if t.is_cuda else t.to(self.device)
 
     def execute(self, req):
         op, payload = req
-        if op == "all_gather_object":
-            out = [None] * self.world
-            dist.all_gather_object(out, payload, group=self.group)
-            return out
-        if op == "all_gather_bytes":
-            src = self._out(payload)
-            bufs = [torch.empty_like(src) for _ in range(self.world)]
-            dist.all_gather(bufs, src, group=self.group)
-            return [b.to(payload.device) for b in bufs]
-        if op == "ring_shift":
+        if op == "all_gather_tensor":
+            src = self._wire(payload).contiguous()
+            out = torch.empty(self.world * src.numel(), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(out, src.reshape(-1), group=self.group)     # one fixed-size collective
+            out = out.to(payload.device).reshape((self.world,) + tuple(src.shape))
+            return [out[i] for i in range(self.world)]
+        if op == "ring_shift_begin":
             send, recv = payload
             nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
-            s_ = [self._out(t) for t in send]
+            s_ = [self._wire(t) for t in send]
             r_ = [torch.empty(t.shape, dtype=t.dtype) if (self.host_staged and t.is_cuda) else t for t in recv]
             ops = [dist.P2POp(dist.isend, t, nxt, group=self.group) for t in s_ if t.numel()]
             ops += [dist.P2POp(dist.irecv, t, prv, group=self.group) for t in r_ if t.numel()]
-            if ops:
-                for w in dist.batch_isend_irecv(ops):      # one ncclGroup: every rank sends and receives together
-                    w.wait()
-            for dst, got in zip(recv, r_):
+            works = dist.batch_isend_irecv(ops) if ops else []   # one ncclGroup: every rank sends and receives together
+            return {"works": works, "recv": recv, "staged": r_, "keep": s_}
+        if op == "ring_shift_wait":
+            for w in payload["works"]:
+                w.wait()
+            for dst, got in zip(payload["recv"], payload["staged"]):
                 if dst is not got and dst.numel():
                     dst.copy_(got)
-            return recv
+            payload["keep"] = None
+            return payload["recv"]
         raise ValueError(op)
 
 
 def run_lockstep(generators):
     """In-process stand-in for N ranks: advance every rank's round generator to its next request, answer the N requests
-    together, repeat.  Used by the tests (and usable for a single-GPU dry run of the sharded driver)."""
+    together, repeat.  Used by the tests and by single-GPU runs of the sharded driver (tests/test_hip_fullsize.py)."""
     gens = list(generators)
     reqs = [next(g, None) for g in gens]
     while any(r is not None for r in reqs):
         assert all(r is not None for r in reqs) and len({r[0] for r in reqs}) == 1, "ranks diverged"
         op, n = reqs[0][0], len(gens)
-        if op == "all_gather_object":
-            res = [[r[1] for r in reqs]] * n
-        elif op == "all_gather_bytes":
+        if op == "all_gather_tensor":
+            assert len({(tuple(r[1].shape), r[1].dtype) for r in reqs}) == 1, "all_gather_tensor: ranks disagree on the shape"
             res = [[r[1].clone() for r in reqs] for _ in range(n)]
-        elif op == "ring_shift":
+        elif op == "ring_shift_begin":
             res = []
             for i in range(n):
                 send = reqs[(i - 1) % n][1][0]
@@ -174,7 +178,9 @@ def run_lockstep(generators):
                     assert dst.shape == src.shape and dst.dtype == src.dtype, (dst.shape, src.shape)
                     if dst.numel():
                         dst.copy_(src)
-                res.append(recv)
+                res.append({"recv": recv})
+        elif op == "ring_shift_wait":
+            res = [r[1]["recv"] for r in reqs]
         else:
             raise ValueError(op)
         nxt = []
@@ -233,6 +239,8 @@ def _make_sharded_cls():
             self._host_frames = {}           # absolute index -> host frame (references) of the last rounds
             self.owned_passes = []
             self.comm_log = []               # (round, op, bytes) for the bench / tests
+            self.profile_rounds = False      # bench: wall-time split of every round (device-synchronised phase boundaries)
+            self.round_times = []            # [{"round", "ingest", "encode", "detect", "prompt", "gather", "ring_wait", "propagate"}] seconds
             assert self.detect_interval == -1 or self.detect_interval > 0
 
         # -------------------------------------------------------------- frame intake: a round = world x buffer frames
@@ -358,6 +366,17 @@ def _make_sharded_cls():
         def _like(self, B):
             return entry_template(B, self.predictor.device, **self.predictor.entry_dims())
 
+        def _tick(self, rec, name, t0):
+            """Close phase `name` of the round's time record (only when profiling: it synchronises the device)."""
+            if not self.profile_rounds:
+                return t0
+            import time
+            if self.predictor.device.type == "cuda":
+                torch.cuda.synchronize(self.predictor.device)
+            t1 = time.perf_counter()
+            rec[name] = rec.get(name, 0.0) + (t1 - t0)
+            return t1
+
         # -------------------------------------------------------------- the round
         def round_generator(self, frame_idx):
             """Generator over the communication requests of one round (module docstring, steps 1-5)."""
@@ -370,6 +389,8 @@ def _make_sharded_cls():
             past = self.inference_state["num_frames"] if self.inference_state else 0
             first_abs = past                                   # absolute index of the round's first frame
             mine = r if r < n_pass else None                   # local index of my pass in this round
+            import time
+            rec, tp = {"round": round_idx}, time.perf_counter()
             # ---- frame numbering and eviction are the same on every rank; the images a rank holds are its own buffers
             if N > 1 and self.handoff:
                 lo_, hi_ = self._pass_abs_range(first_abs, mine, n_round) if mine is not None else (0, -1)
@@ -378,41 +399,45 @@ def _make_sharded_cls():
                 self._ingest_buffer()
             st = self.inference_state
             d = p.device
-            # ---- 1. encode my buffer once, hand the pyramids to the owner of the next pass
+            tp = self._tick(rec, "ingest", tp)
+            # ---- 1. encode my buffer once, POST the hand-off of the pyramids to the owner of the next pass
+            ring = None
             if self.handoff and N > 1:
                 lo, hi = self._pass_abs_range(first_abs, mine, n_round) if mine is not None else (0, -1)
                 my_frames = list(range(lo, hi + 1))
                 st["_feature_cache_cap"] = 3 * b + p.encode_batch + 2
                 feats = p.encode_frames(st, my_frames) if my_frames else []
+                tp = self._tick(rec, "encode", tp)
                 # what I receive: the buffer of local pass (r-1) of this round; rank 0 receives the round's last buffer
                 src_local = (r - 1) % N
-                n_recv = 0
+                n_recv, rlo = 0, 0
                 if src_local < n_pass:
                     rlo, rhi = self._pass_abs_range(first_abs, src_local, n_round)
                     n_recv = rhi - rlo + 1
                 shapes = p.feature_shapes()
                 send = [torch.stack([f[i] for f in feats]) if feats else torch.empty((0,) + s, device=d) for i, s in enumerate(shapes)]
                 recv = [torch.empty((n_recv,) + s, dtype=torch.float32, device=d) for s in shapes]
-                recv = yield ("ring_shift", (send, recv))
+                if d.type == "cuda":      # the collective runs on the back end's own stream: the operands must be complete
+                    torch.cuda.current_stream(d).synchronize()
+                ring = yield ("ring_shift_begin", (send, recv))
                 self.comm_log.append((round_idx, "ring_shift", sum(t.numel() * 4 for t in send)))
-                got = {rlo + i: tuple(t[i] for t in recv) for i in range(n_recv)} if n_recv else {}
-                if r == 0:   # what arrives now belongs to my pass of the NEXT round; this round uses the previous arrival
-                    use, self._prev_buffer_feats = self._prev_buffer_feats, got
-                else:
-                    use = got
-                for t, f in use.items():
-                    st["cached_features"][t] = f
-            # ---- 2. detections of my buffer -> everybody
+            # ---- 2. detections of my buffer -> everybody (one fixed-size tensor per rank)
             dets = {}
             if mine is not None:
                 lo, hi = self._pass_abs_range(first_abs, mine, n_round)
                 keep = (self.special_classes_detection, self.special_classes_count)
                 dets = self.detect_predict_range(lo, hi, first_abs)
                 self.special_classes_detection, self.special_classes_count = keep     # applied in pass order in step 5
-            all_dets = (yield ("all_gather_object", _dets_to_wire(dets))) if N > 1 else [_dets_to_wire(dets)]
-            all_dets = [_dets_from_wire(x) for x in all_dets][:n_pass]
+            tp = self._tick(rec, "detect", tp)
+            if N > 1:
+                all_dets = yield ("all_gather_tensor", dets_to_tensor(dets))
+                self.comm_log.append((round_idx, "all_gather_dets", (1 + MAX_DET) * 7 * 8 * N))
+                all_dets = [dets_from_tensor(x) for x in all_dets][:n_pass]
+            else:
+                all_dets = [dets]
             if mine is not None:
                 all_dets[mine] = dets                    # my own detections, not their wire copy
+            tp = self._tick(rec, "gather", tp)
             tables, cur = [], list(st["obj_ids"])
             for j in range(n_pass):
                 for c in self._new_ids(all_dets[j]):
@@ -430,9 +455,15 @@ def _make_sharded_cls():
                     e = st["output_dict"]["cond_frame_outputs"].get(t)
                     if e is not None and e["maskmem_features"] is not None:
                         my_entries[t] = dict(e, fpn2=p._get_image_feature(st, t)[2])
-            # ---- 4. one all-gather of the round's new conditioning entries (padded to the largest pass payload)
+            tp = self._tick(rec, "prompt", tp)
+            # ---- 4. one all-gather of the round's new conditioning entries (padded to the largest pass payload); what each
+            #         pass contributes (frame, batch) travels first as a fixed-size int32 tensor
             meta = {t: int(e["obj_ptr"].shape[0]) for t, e in my_entries.items()}
-            metas = ((yield ("all_gather_object", meta)) if N > 1 else [meta])[:n_pass]
+            if N > 1:
+                metas = yield ("all_gather_tensor", meta_to_tensor(meta))
+                metas = [meta_from_tensor(x) for x in metas][:n_pass]
+            else:
+                metas = [meta]
             if any(metas) and N > 1:
                 sizes = [sum(entry_nbytes(self._like(Bj)) for Bj in m.values()) for m in metas]
                 flat = torch.zeros(max(sizes), dtype=torch.uint8, device=d)
@@ -441,8 +472,10 @@ def _make_sharded_cls():
                     buf = pack_entry(my_entries[t], XFIELDS)
                     flat[off:off + buf.numel()] = buf
                     off += buf.numel()
-                gathered = yield ("all_gather_bytes", flat)
-                self.comm_log.append((round_idx, "all_gather_bytes", int(flat.numel()) * N))
+                if d.type == "cuda":
+                    torch.cuda.current_stream(d).synchronize()
+                gathered = yield ("all_gather_tensor", flat)
+                self.comm_log.append((round_idx, "all_gather_entries", int(flat.numel()) * N))
             else:
                 gathered = [None] * N
             incoming = {}
@@ -453,6 +486,18 @@ def _make_sharded_cls():
                     if j != mine:
                         incoming.setdefault(j, {})[t] = unpack_entry(gathered[j][off:off + entry_nbytes(like)], like, XFIELDS)
                     off += entry_nbytes(like)
+            tp = self._tick(rec, "gather", tp)
+            # ---- the pyramids posted in step 1 are first read by the propagation: wait for them here
+            if ring is not None:
+                recv = yield ("ring_shift_wait", ring)
+                got = {rlo + i: tuple(t[i] for t in recv) for i in range(n_recv)} if n_recv else {}
+                if r == 0:   # what arrives now belongs to my pass of the NEXT round; this round uses the previous arrival
+                    use, self._prev_buffer_feats = self._prev_buffer_feats, got
+                else:
+                    use = got
+                for t, f in use.items():
+                    st["cached_features"][t] = f
+                tp = self._tick(rec, "ring_wait", tp)
             # ---- 5. replay the passes before mine, run mine, replay the rest
             for j in range(n_pass):
                 f_idx = min(first_abs + (j + 1) * b, first_abs + n_round) - 1       # newest frame of pass j
@@ -472,6 +517,9 @@ def _make_sharded_cls():
                     self._propagate_owned(f_idx)
                 self._release(f_idx)
                 self._log_pass(f_idx)
+            tp = self._tick(rec, "propagate", tp)
+            if self.profile_rounds:
+                self.round_times.append(rec)
 
         def _propagate_owned(self, frame_idx):
             """The reverse propagation + host copy of an owned pass (prompts were issued in step 3)."""
@@ -502,19 +550,61 @@ def _make_sharded_cls():
     return ShardedVideoProcessor
 
 
-def _dets_to_wire(dets):
-    return {k: [(np.asarray(d["coordinates"], np.float32).tolist(), float(np.asarray(d["class"]).reshape(-1)[0]),
-                 float(np.asarray(d["confidence"]).reshape(-1)[0])) for d in v] for k, v in (dets or {}).items()}
+MAX_DET = 255         # detections of one pass on the wire (rows of the fixed-size tensor; exceeded => error, not truncation)
+MAX_COND = 31         # new conditioning entries one pass may announce per round
 
 
-def _dets_from_wire(w):
-    return {k: [{"coordinates": np.asarray(c, np.float32), "class": np.array([cl], np.float32), "confidence": np.array([cf], np.float32)}
-                for c, cl, cf in v] for k, v in (w or {}).items()}
+def dets_to_tensor(dets) -> torch.Tensor:
+    """{frame: [detection dict]} (detect_predict's output, det_sam2_RT.py:228-244) -> fp64 [1 + MAX_DET, 7]: row 0 =
+    [count, 0...]; row i = [frame, x0, y0, x1, y1, class, confidence] (the dict keys are "frame_<i>", det_sam2_RT.py:224).  fp32 boxes / classes / confidences and frame
+    indices are exact in fp64; detection order (which decides object-table order) is the row order."""
+    rows = [(float(str(k).rsplit("_", 1)[-1]), *np.asarray(d["coordinates"], np.float32).reshape(4).astype(np.float64).tolist(),
+             float(np.asarray(d["class"], np.float32).reshape(-1)[0]), float(np.asarray(d["confidence"], np.float32).reshape(-1)[0]))
+            for k, v in (dets or {}).items() for d in v]
+    if len(rows) > MAX_DET:
+        raise RuntimeError(f"{len(rows)} detections in one pass exceed the wire format's {MAX_DET}")
+    out = torch.zeros((1 + MAX_DET, 7), dtype=torch.float64)
+    out[0, 0] = len(rows)
+    if rows:
+        out[1:1 + len(rows)] = torch.tensor(rows, dtype=torch.float64)
+    return out
 
 
-def __getattr__(name):   # lazy: det_sam2_RT imports this module's siblings
+def dets_from_tensor(t: torch.Tensor):
+    t = t.cpu()
+    out = {}
+    for row in t[1:1 + int(t[0, 0])].tolist():
+        out.setdefault(f"frame_{int(row[0])}", []).append(
+            {"coordinates": np.asarray(row[1:5], np.float32), "class": np.array([row[5]], np.float32),
+             "confidence": np.array([row[6]], np.float32)})
+    return out
+
+
+def meta_to_tensor(meta) -> torch.Tensor:
+    """{cond frame: batch size} -> int32 [1 + MAX_COND, 2] (row 0 = count)."""
+    if len(meta) > MAX_COND:
+        raise RuntimeError(f"{len(meta)} conditioning frames in one pass exceed the wire format's {MAX_COND}")
+    out = torch.zeros((1 + MAX_COND, 2), dtype=torch.int32)
+    out[0, 0] = len(meta)
+    for i, t in enumerate(sorted(meta)):
+        out[1 + i, 0], out[1 + i, 1] = int(t), int(meta[t])
+    return out
+
+
+def meta_from_tensor(t: torch.Tensor):
+    t = t.cpu()
+    return {int(a): int(b) for a, b in t[1:1 + int(t[0, 0])].tolist()}
+
+
+_SHARDED_CLS = None
+
+
+def __getattr__(name):   # lazy (det_sam2_RT imports this module's siblings); ONE class object, so isinstance works
+    global _SHARDED_CLS
     if name == "ShardedVideoProcessor":
-        return _make_sharded_cls()
+        if _SHARDED_CLS is None:
+            _SHARDED_CLS = _make_sharded_cls()
+        return _SHARDED_CLS
     raise AttributeError(name)
 
 
