@@ -67,7 +67,29 @@ SIGNATURES = {
                                    i32, i32, i32, i32, i32, i32, i32, c_vp, c_vp, c_vp]),
 }
 
+# the PyTorch custom ops csrc/torch_ops.cpp registers (torch.ops.det_sam2.<name>)
+TORCH_OPS = ("ingest_frames", "image_encoder", "bank_assemble", "memory_attention", "sam_heads", "memory_encoder",
+             "memory_encoder_module", "resize_aa", "mask_prompt_prepare", "obj_ptr_gate", "mask_output",
+             "get_connected_componnets", "fill_holes")
+
 _lib = None
+_ops = None
+TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libdetsam2_torch.so")
+
+
+def load_torch_ops():
+    """Register the PyTorch custom ops (csrc/torch_ops.cpp: TORCH_LIBRARY(det_sam2, m) over the C-ABI) and return
+    ``torch.ops.det_sam2``.  Raises if the library is not built - the stages have no other way in."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    import torch
+    load()                                       # libdetsam2_hip.so first (the op library links against it)
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise ImportError(f"{TORCH_LIB_PATH} is missing: build it with: python -c 'import __graft_entry__ as g; g.build()'")
+    torch.ops.load_library(TORCH_LIB_PATH)
+    _ops = torch.ops.det_sam2
+    return _ops
 
 
 class Ds2Error(RuntimeError):

@@ -5,11 +5,13 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#ifndef DS2_OK      /* (the same values as include/detsam2_hip.h) */
 #define DS2_OK 0
 #define DS2_ERR_ARG 1
 #define DS2_ERR_HIP 2
 #define DS2_ERR_STATE 3
 #define DS2_ERR_UNSUPPORTED 4
+#endif
 
 void ds2_set_error(const char* fmt, ...);
 

@@ -207,12 +207,64 @@ class VideoProcessor:
         ``init_preloading_state`` moves it to the GPU."""
         return bank_io.load_bank(load_path)
 
+    def load_frames_from_folder(self, folder_path):
+        """det_sam2_RT.py:507-524: the .png / .jpg / .jpeg files of a folder in sorted order, as RGB uint8 arrays.  The
+        reference decodes with cv2.imread + BGR->RGB; here PIL decodes (PNG: identical pixels; JPEG: both sit on libjpeg,
+        but the decoders' IDCT / chroma-upsampling choices are not pinned against each other offline) and the frames are
+        produced lazily, so a long folder never sits in host memory at once.  Unreadable files are skipped (:516-518)."""
+        from PIL import Image
+        names = sorted(f for f in os.listdir(folder_path) if f.endswith((".png", ".jpg", ".jpeg")))
+
+        def gen():
+            for name in names:
+                try:
+                    with Image.open(os.path.join(folder_path, name)) as im:
+                        yield np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+                except Exception:
+                    print(f"--- cannot read frame file: {os.path.join(folder_path, name)}")
+        return names, gen()
+
+    def _video_frames(self, video_path):
+        """det_sam2_RT.py:558-579: cv2.VideoCapture + BGR->RGB.  OpenCV is an optional dependency of this path only."""
+        try:
+            import cv2
+        except ImportError as e:
+            raise NotImplementedError(
+                "run(video_path=...) needs OpenCV (cv2.VideoCapture), which is not installed; extract the frames to a folder "
+                "(ffmpeg -i <video> -q:v 2 -start_number 0 <dir>/%05d.jpg) and use run(frame_dir=...), or pass frames=") from e
+        cap = cv2.VideoCapture(video_path)
+        if not cap.isOpened():
+            print(f"--- cannot open video file: {video_path}")
+            return None
+
+        def gen():
+            try:
+                while True:
+                    ret, frame = cap.read()
+                    if not ret:
+                        return
+                    yield cv2.cvtColor(frame, cv2.COLOR_BGR2RGB)
+            finally:
+                cap.release()
+        return gen()
+
     def run(self, video_path=None, frame_dir=None, output_video_segments_pkl_path=None,
             output_special_classes_detection_pkl_path=None, frames=None):
-        """det_sam2_RT.py:526-626 for an in-memory iterable of RGB frames (``frames``).  Video files / frame
-        folders need cv2 (not part of the hot path): decode them upstream and pass the frames."""
-        if frames is None:
-            raise NotImplementedError("pass frames=<iterable of HxWx3 uint8 RGB arrays>; cv2 decoding is out of scope")
+        """det_sam2_RT.py:526-626.  Frame sources: ``video_path`` (cv2.VideoCapture, :558-579 - needs OpenCV),
+        ``frame_dir`` (folder of .png / .jpg / .jpeg, :580-598) or ``frames`` (an in-memory iterable of HxWx3 uint8 RGB
+        arrays: what both branches reduce to)."""
+        if frames is None and video_path is not None:
+            frames = self._video_frames(video_path)
+            if frames is None:
+                return None
+        elif frames is None and frame_dir is not None:
+            names, frames = self.load_frames_from_folder(frame_dir)
+            if not names:
+                print(f"--- no frame files found in: {frame_dir}")
+                return None
+        elif frames is None:
+            print("--- no video, frame folder or frames given")       # :600-601
+            return None
         if self.load_inference_state_path is not None:
             self.inference_state = self.load_inference_state(self.load_inference_state_path)
             od = self.inference_state["output_dict"]

@@ -1,7 +1,9 @@
 """SAM 2.1 stages on MI355X: thin host wrapper over the C-ABI (include/detsam2_hip.h).
 
-PyTorch is used here only as plumbing: device allocations (torch tensors) and the current HIP
-stream.  Every number is produced by the kernels in csrc/; nothing falls back to torch ops.
+The STAGES are called as PyTorch-ROCm custom ops (``torch.ops.det_sam2.*``, csrc/torch_ops.cpp: TORCH_LIBRARY over the
+C-ABI - tensors in, tensors out, current HIP stream taken inside the op); model lifetime, parameters, precision,
+profiling and the primitive test ops go through ctypes.  PyTorch is plumbing only (allocations, streams); every number is
+produced by the kernels in csrc/; nothing falls back to ATen arithmetic.
 
 Token-major layout: what the reference holds as [B,C,H,W] is [B,H*W,C] here.
 """
@@ -29,6 +31,7 @@ class HipOps:
 
     def __init__(self, device="cuda:0"):
         self.lib = _capi.load()                     # raises if the HIP library is not built
+        self.ops = _capi.load_torch_ops()           # torch.ops.det_sam2 (raises if the op library is not built)
         if not torch.cuda.is_available():
             raise RuntimeError("det-sam2_amd needs a ROCm GPU: there is no CPU execution path")
         self.device = torch.device(device)
@@ -150,83 +153,51 @@ class HipSam2(HipOps):
         except Exception:
             pass
 
-    # ------------------------------------------------------------------ stages
+    # ------------------------------------------------------------------ stages (torch.ops.det_sam2.*)
+    @property
+    def _h(self):
+        return int(self.h.value)
+
     def ingest(self, frames_u8: torch.Tensor) -> torch.Tensor:
-        """uint8 [n,S,S,3] (device) -> fp16 [n,3,S,S] normalised frames (A3)."""
-        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.is_contiguous()
-        n, hh, ww, _ = frames_u8.shape
-        out = self._empty(n, 3, self.cfg.image_size, self.cfg.image_size, dtype=torch.float16)
-        _capi.check(self.lib.ds2_ingest_frames(self.h, _p(frames_u8), n, hh, ww, _p(out), self._stream()), "ds2_ingest_frames")
-        return out
+        """uint8 [n,H,W,3] (device) -> fp16 [n,3,S,S] normalised frames (A3)."""
+        return self.ops.ingest_frames(self._h, frames_u8)
 
     def image_encoder(self, frame_f16: torch.Tensor):
         """fp16 [3,S,S] -> (fpn0 [65536,32], fpn1 [16384,64], fpn2 [4096,256]) (A4+A5)."""
-        assert frame_f16.dtype == torch.float16 and frame_f16.is_cuda and frame_f16.is_contiguous()
-        f0, f1, f2 = self._empty(65536, 32), self._empty(16384, 64), self._empty(TOK, 256)
-        _capi.check(self.lib.ds2_image_encoder(self.h, _p(frame_f16), _p(f0), _p(f1), _p(f2), self._stream()), "ds2_image_encoder")
-        return f0, f1, f2
+        f0, f1, f2 = self.ops.image_encoder(self._h, frame_f16[None])
+        return f0[0], f1[0], f2[0]
 
     def image_encoder_batch(self, frames_f16: torch.Tensor):
         """fp16 [n,3,S,S] -> list of n (fpn0, fpn1, fpn2) tuples (views of three batched buffers)."""
-        assert frames_f16.dtype == torch.float16 and frames_f16.is_cuda and frames_f16.is_contiguous() and frames_f16.dim() == 4
-        n = frames_f16.shape[0]
-        f0, f1, f2 = self._empty(n, 65536, 32), self._empty(n, 16384, 64), self._empty(n, TOK, 256)
-        _capi.check(self.lib.ds2_image_encoder_batch(self.h, _p(frames_f16), n, _p(f0), _p(f1), _p(f2), self._stream()),
-                    "ds2_image_encoder_batch")
-        return [(f0[i], f1[i], f2[i]) for i in range(n)]
+        f0, f1, f2 = self.ops.image_encoder(self._h, frames_f16)
+        return [(f0[i], f1[i], f2[i]) for i in range(frames_f16.shape[0])]
 
     def bank_assemble(self, B, mem_entries, ptr_entries):
-        """mem_entries: [(bf16 [B,4096,64], tpos_row)], ptr_entries: [(fp32 [B,256], pos/t_diff_max)] (A11)."""
-        n_mem, n_ptr = len(mem_entries), len(ptr_entries)
-        nk = n_mem * TOK + 4 * n_ptr
-        memory, memory_pos = self._empty(B, nk, 64), self._empty(B, nk, 64)
-        feats = (C.c_void_p * max(n_mem, 1))(*[t.data_ptr() for t, _ in mem_entries])
-        rows = (C.c_int32 * max(n_mem, 1))(*[int(r) for _, r in mem_entries])
-        ptrs = (C.c_void_p * max(n_ptr, 1))(*[t.data_ptr() for t, _ in ptr_entries])
-        pos = (C.c_float * max(n_ptr, 1))(*[float(p) for _, p in ptr_entries])
-        for t, _ in mem_entries:
-            assert t.dtype == torch.bfloat16 and tuple(t.shape) == (B, TOK, 64) and t.is_contiguous()
-        for t, _ in ptr_entries:
-            assert t.dtype == torch.float32 and tuple(t.shape) == (B, 256) and t.is_contiguous()
-        _capi.check(self.lib.ds2_bank_assemble(self.h, B, n_mem, feats, rows, n_ptr, ptrs, pos, _p(memory), _p(memory_pos),
-                                               self._stream()), "ds2_bank_assemble")
-        return memory, memory_pos
+        """mem_entries: [(bf16 [B,4096,64], tpos_row)], ptr_entries: [(fp32 [B,256], pos/t_diff_max)] (A11)
+        -> memory, memory_pos fp32 [B,Nk,64]."""
+        return self.ops.bank_assemble(self._h, B, [t for t, _ in mem_entries], [int(r) for _, r in mem_entries],
+                                      [t for t, _ in ptr_entries], [float(p) for _, p in ptr_entries])
 
     def memory_attention(self, B, curr, memory, memory_pos, num_obj_ptr_tokens):
         """curr [4096,256] shared; memory/memory_pos [B,Nk,64] -> [B,4096,256] (A12)."""
-        nk = memory.shape[1]
-        out = self._empty(B, TOK, 256)
-        _capi.check(self.lib.ds2_memory_attention(self.h, B, _p(curr), _p(memory), _p(memory_pos), nk, num_obj_ptr_tokens,
-                                                  _p(out), self._stream()), "ds2_memory_attention")
-        return out
+        return self.ops.memory_attention(self._h, B, curr, None, memory, memory_pos, num_obj_ptr_tokens)
 
     def sam_heads(self, B, pix_feat, fpn0, fpn1, point_coords=None, point_labels=None, multimask=False,
                   pix_bcast=False, add_no_mem_embed=False, mask_inputs=None):
         """-> low_res [B,256,256], obj_ptr [B,256], obj_logits [B], ious [B] (A7+A8).  mask_inputs [B,256,256]:
         optional mask prompt (logits) for the prompt encoder's dense embedding."""
-        P = 0 if point_coords is None else point_coords.shape[1]
-        low, ptr = self._empty(B, 256, 256), self._empty(B, 256)
-        obj, iou = self._empty(B), self._empty(B)
-        if P:
-            assert point_coords.dtype == torch.float32 and point_labels.dtype == torch.int32
+        if point_coords is not None and point_coords.shape[1] == 0:
+            point_coords = point_labels = None
+        if point_coords is not None:
             point_coords, point_labels = point_coords.contiguous(), point_labels.contiguous()
         if mask_inputs is not None:
-            assert mask_inputs.dtype == torch.float32 and tuple(mask_inputs.shape) == (B, 256, 256), mask_inputs.shape
             mask_inputs = mask_inputs.contiguous()
-        _capi.check(self.lib.ds2_sam_heads_mask(self.h, B, _p(pix_feat), int(pix_bcast), int(add_no_mem_embed), _p(fpn0),
-                                                _p(fpn1), _p(point_coords), _p(point_labels), P, _p(mask_inputs),
-                                                int(multimask), _p(low), _p(ptr), _p(obj), _p(iou), self._stream()),
-                    "ds2_sam_heads_mask")
-        return low, ptr, obj, iou
+        return self.ops.sam_heads(self._h, B, pix_feat, bool(pix_bcast), bool(add_no_mem_embed), fpn0, fpn1, point_coords,
+                                  point_labels, mask_inputs, bool(multimask))
 
     def resize_aa(self, x, hout, wout, in_scale=1.0, in_bias=0.0, threshold=float("inf")):
         """F.interpolate(bilinear, antialias=True, align_corners=False) of fp32 [B,Hin,Win] -> [B,hout,wout]."""
-        assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and x.dim() == 3
-        B, hin, win = x.shape
-        work, out = self._empty(B, hin, wout), self._empty(B, hout, wout)
-        _capi.check(self.lib.ds2_resize_aa(_p(x), B, hin, win, hout, wout, in_scale, in_bias, threshold, _p(work), _p(out),
-                                           self._stream()), "ds2_resize_aa")
-        return out
+        return self.ops.resize_aa(x, hout, wout, float(in_scale), float(in_bias), float(threshold))
 
     def use_mask_as_output(self, B, fpn2, fpn0, fpn1, mask):
         """SAM2Base._use_mask_as_output (sam2_base.py:399-448): mask fp32 0/1 [B,S,S] ->
@@ -235,28 +206,17 @@ class HipSam2(HipOps):
         S = self.cfg.image_size
         assert mask.dtype == torch.float32 and tuple(mask.shape) == (B, S, S) and mask.is_contiguous()
         low = self.resize_aa(mask, S // 4, S // 4, 20.0, -10.0)                        # (mask*20-10) -> 256^2, antialiased
-        ds, obj = self._empty(B, S // 4, S // 4), self._empty(B)
-        work = self._empty(B, dtype=torch.int32)
-        _capi.check(self.lib.ds2_mask_prompt_prepare(self.h, B, _p(mask), _p(ds), _p(obj), _p(work), self._stream()),
-                    "ds2_mask_prompt_prepare")
+        ds, obj = self.ops.mask_prompt_prepare(self._h, mask)
         _, ptr, _, _ = self.sam_heads(B, fpn2, fpn0, fpn1, None, None, multimask=False, pix_bcast=True, add_no_mem_embed=False,
                                       mask_inputs=ds)                                  # gated by the decoder's own object score
-        _capi.check(self.lib.ds2_obj_ptr_gate(self.h, B, _p(ptr), _p(obj), self._stream()), "ds2_obj_ptr_gate")  # ... then by the mask's
-        return low, ptr, obj
+        return low, self.ops.obj_ptr_gate(self._h, ptr, obj), obj                      # ... then by the mask's
 
     def memory_encoder(self, B, fpn2, low_res, obj_logits, binarize):
         """-> maskmem bf16 [B,4096,64] (A13)."""
-        out = self._empty(B, TOK, 64, dtype=torch.bfloat16)
-        _capi.check(self.lib.ds2_memory_encoder(self.h, B, _p(fpn2), _p(low_res), _p(obj_logits), int(binarize), _p(out),
-                                                self._stream()), "ds2_memory_encoder")
-        return out
+        return self.ops.memory_encoder(self._h, B, fpn2, low_res, obj_logits, bool(binarize))
 
     def mask_output(self, low_res, hv, wv, want_logits=True, want_packed=True):
         """low_res [B,256,256] -> (logits fp32 [B,1,hv,wv] | None, packed uint8 [B,hv,ceil(wv/8)] | None) (A15);
         packed rows are numpy.packbits rows (MSB first, last byte zero-padded)."""
-        B = low_res.shape[0]
-        logits = self._empty(B, 1, hv, wv) if want_logits else None
-        packed = self._empty(B, hv, (wv + 7) // 8, dtype=torch.uint8) if want_packed else None
-        _capi.check(self.lib.ds2_mask_output(self.h, _p(low_res), B, hv, wv, _p(logits), _p(packed), self._stream()),
-                    "ds2_mask_output")
-        return logits, packed
+        logits, packed = self.ops.mask_output(self._h, low_res, hv, wv, bool(want_logits), bool(want_packed))
+        return (logits if want_logits else None), (packed if want_packed else None)

