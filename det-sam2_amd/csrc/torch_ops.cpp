@@ -9,8 +9,8 @@
 // correctness by construction.  A ds2_model travels as an int64 handle (the pointer ds2_model_create returned).
 // Built into det-sam2_amd/lib/libdetsam2_torch.so by __graft_entry__.build(); loaded with torch.ops.load_library.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // PyTorch-ROCm tensors carry DeviceType::CUDA ("HIP masquerading as
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>      // CUDA"): guard / current stream come from the masquerading forms
 #include <torch/library.h>
 
 #include <cmath>
@@ -27,7 +27,7 @@ ds2_model* model_of(int64_t h) {
   TORCH_CHECK(h != 0, "det_sam2: null model handle");
   return reinterpret_cast<ds2_model*>(static_cast<intptr_t>(h));
 }
-void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream(); }
 void check(int rc, const char* what) {
   TORCH_CHECK(rc == DS2_OK, "det_sam2::", what, " failed (code ", rc, "): ", ds2_last_error());   // c10::Error -> RuntimeError
 }
@@ -44,7 +44,7 @@ constexpr int64_t TOK = 4096;
 Tensor ingest_frames(int64_t model, const Tensor& frames_u8) {
   want(frames_u8, at::kByte, "frames_u8");
   TORCH_CHECK(frames_u8.dim() == 4 && frames_u8.size(3) == 3, "det_sam2::ingest_frames: frames_u8 must be [n,H,W,3]");
-  c10::hip::HIPGuard g(frames_u8.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(frames_u8.device());
   const int64_t n = frames_u8.size(0);
   Tensor out = at::empty({n, 3, 1024, 1024}, frames_u8.options().dtype(at::kHalf));
   check(ds2_ingest_frames(model_of(model), frames_u8.data_ptr<uint8_t>(), (int32_t)n, (int32_t)frames_u8.size(1),
@@ -58,7 +58,7 @@ std::tuple<Tensor, Tensor, Tensor> image_encoder(int64_t model, const Tensor& fr
   TORCH_CHECK(frames.dim() == 4 && frames.size(1) == 3, "det_sam2::image_encoder: frames must be [n,3,S,S]");
   TORCH_CHECK(frames.scalar_type() == at::kHalf || frames.scalar_type() == at::kFloat, "det_sam2::image_encoder: fp16 or fp32 frames");
   want(frames, frames.scalar_type(), "frames");
-  c10::hip::HIPGuard g(frames.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(frames.device());
   const int64_t n = frames.size(0);
   auto o = frames.options().dtype(at::kFloat);
   Tensor f0 = at::empty({n, 65536, 32}, o), f1 = at::empty({n, 16384, 64}, o), f2 = at::empty({n, TOK, 256}, o);
@@ -77,7 +77,7 @@ std::tuple<Tensor, Tensor> bank_assemble(int64_t model, int64_t B, at::TensorLis
   TORCH_CHECK(feats.size() == tpos_rows.size() && ptrs.size() == ptr_pos.size(), "det_sam2::bank_assemble: table lengths differ");
   TORCH_CHECK(feats.size() + ptrs.size() > 0, "det_sam2::bank_assemble: empty bank");
   const Tensor& any = feats.size() ? feats[0] : ptrs[0];
-  c10::hip::HIPGuard g(any.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(any.device());
   std::vector<const void*> fp;
   std::vector<int32_t> rows;
   for (size_t i = 0; i < feats.size(); ++i) {
@@ -122,7 +122,7 @@ Tensor memory_attention(int64_t model, int64_t B, const Tensor& curr, const c10:
     pos_shared = curr_pos->dim() == 2;
     TORCH_CHECK(curr_pos->numel() == (pos_shared ? 1 : B) * TOK * 256, "det_sam2::memory_attention: bad curr_pos shape");
   }
-  c10::hip::HIPGuard g(curr.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(curr.device());
   Tensor out = at::empty({B, TOK, 256}, curr.options());
   check(ds2_memory_attention_ex(model_of(model), (int32_t)B, curr.data_ptr<float>(), curr_shared ? 1 : 0, fptr(curr_pos),
                                 pos_shared ? 1 : 0, memory.data_ptr<float>(), memory_pos.data_ptr<float>(), (int32_t)memory.size(1),
@@ -156,7 +156,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sam_heads(int64_t model, int64_t B, c
     want(*mask_inputs, at::kFloat, "mask_inputs");
     TORCH_CHECK(mask_inputs->numel() == B * 256 * 256, "det_sam2::sam_heads: mask_inputs must be [B,256,256]");
   }
-  c10::hip::HIPGuard g(pix_feat.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(pix_feat.device());
   auto o = pix_feat.options();
   Tensor low = at::empty({B, 256, 256}, o), ptr = at::empty({B, 256}, o), obj = at::empty({B}, o), iou = at::empty({B}, o);
   check(ds2_sam_heads_mask(model_of(model), (int32_t)B, pix_feat.data_ptr<float>(), pix_bcast ? 1 : 0, add_no_mem_embed ? 1 : 0,
@@ -172,7 +172,7 @@ Tensor memory_encoder(int64_t model, int64_t B, const Tensor& fpn2, const Tensor
   want(low_res, at::kFloat, "low_res");
   want(obj_logits, at::kFloat, "obj_logits");
   TORCH_CHECK(fpn2.numel() == TOK * 256 && low_res.numel() == B * 65536 && obj_logits.numel() == B, "det_sam2::memory_encoder: bad shapes");
-  c10::hip::HIPGuard g(fpn2.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(fpn2.device());
   Tensor out = at::empty({B, TOK, 64}, fpn2.options().dtype(at::kBFloat16));
   check(ds2_memory_encoder(model_of(model), (int32_t)B, fpn2.data_ptr<float>(), low_res.data_ptr<float>(), obj_logits.data_ptr<float>(),
                            binarize ? 1 : 0, reinterpret_cast<uint16_t*>(out.data_ptr()), stream_of(fpn2)), "memory_encoder");
@@ -186,7 +186,7 @@ Tensor memory_encoder_module(int64_t model, int64_t B, const Tensor& pix_feat, c
   want(masks, at::kFloat, "masks");
   const bool shared = pix_feat.numel() == TOK * 256 && B != 1;
   TORCH_CHECK(pix_feat.numel() == (shared ? 1 : B) * TOK * 256 && masks.numel() == B * 1024 * 1024, "det_sam2::memory_encoder_module: bad shapes");
-  c10::hip::HIPGuard g(pix_feat.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(pix_feat.device());
   Tensor out = at::empty({B, TOK, 64}, pix_feat.options());
   check(ds2_memory_encoder_ex(model_of(model), (int32_t)B, pix_feat.data_ptr<float>(), shared ? 1 : 0, masks.data_ptr<float>(),
                               skip_mask_sigmoid ? 1 : 0, out.data_ptr<float>(), stream_of(pix_feat)), "memory_encoder_module");
@@ -198,7 +198,7 @@ Tensor memory_encoder_module(int64_t model, int64_t B, const Tensor& pix_feat, c
 Tensor resize_aa(const Tensor& x, int64_t Hout, int64_t Wout, double in_scale, double in_bias, double threshold) {
   want(x, at::kFloat, "x");
   TORCH_CHECK(x.dim() == 3, "det_sam2::resize_aa: x must be [B,Hin,Win]");
-  c10::hip::HIPGuard g(x.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(x.device());
   const int64_t B = x.size(0), Hin = x.size(1), Win = x.size(2);
   Tensor work = at::empty({B, Hin, Wout}, x.options()), out = at::empty({B, Hout, Wout}, x.options());
   check(ds2_resize_aa(x.data_ptr<float>(), (int32_t)B, (int32_t)Hin, (int32_t)Win, (int32_t)Hout, (int32_t)Wout, (float)in_scale,
@@ -211,7 +211,7 @@ Tensor resize_aa(const Tensor& x, int64_t Hout, int64_t Wout, double in_scale, d
 std::tuple<Tensor, Tensor> mask_prompt_prepare(int64_t model, const Tensor& mask) {
   want(mask, at::kFloat, "mask");
   TORCH_CHECK(mask.dim() == 3 && mask.size(1) == 1024 && mask.size(2) == 1024, "det_sam2::mask_prompt_prepare: mask must be [B,1024,1024]");
-  c10::hip::HIPGuard g(mask.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(mask.device());
   const int64_t B = mask.size(0);
   Tensor ds = at::empty({B, 256, 256}, mask.options()), obj = at::empty({B}, mask.options()), work = at::empty({B}, mask.options().dtype(at::kInt));
   check(ds2_mask_prompt_prepare(model_of(model), (int32_t)B, mask.data_ptr<float>(), ds.data_ptr<float>(), obj.data_ptr<float>(),
@@ -224,7 +224,7 @@ Tensor obj_ptr_gate(int64_t model, const Tensor& obj_ptr, const Tensor& obj_logi
   want(obj_ptr, at::kFloat, "obj_ptr");
   want(obj_logits, at::kFloat, "obj_logits");
   TORCH_CHECK(obj_ptr.dim() == 2 && obj_ptr.size(1) == 256 && obj_logits.numel() == obj_ptr.size(0), "det_sam2::obj_ptr_gate: bad shapes");
-  c10::hip::HIPGuard g(obj_ptr.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(obj_ptr.device());
   Tensor out = obj_ptr.clone();
   check(ds2_obj_ptr_gate(model_of(model), (int32_t)out.size(0), out.data_ptr<float>(), obj_logits.data_ptr<float>(), stream_of(out)), "obj_ptr_gate");
   return out;
@@ -235,7 +235,7 @@ std::tuple<Tensor, Tensor> mask_output(int64_t model, const Tensor& low_res, int
   want(low_res, at::kFloat, "low_res");
   TORCH_CHECK(low_res.dim() == 3 && low_res.size(1) == 256 && low_res.size(2) == 256, "det_sam2::mask_output: low_res must be [B,256,256]");
   TORCH_CHECK(want_logits || want_packed, "det_sam2::mask_output: nothing requested");
-  c10::hip::HIPGuard g(low_res.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(low_res.device());
   const int64_t B = low_res.size(0);
   Tensor logits = want_logits ? at::empty({B, 1, Hv, Wv}, low_res.options()) : at::empty({0}, low_res.options());
   Tensor packed = want_packed ? at::empty({B, Hv, (Wv + 7) / 8}, low_res.options().dtype(at::kByte)) : at::empty({0}, low_res.options().dtype(at::kByte));
@@ -252,7 +252,7 @@ std::vector<Tensor> get_connected_componnets(const Tensor& inputs) {
   TORCH_CHECK(inputs.dim() == 4, "inputs must be [N, 1, H, W] shape");
   TORCH_CHECK(inputs.scalar_type() == at::kByte, "inputs must be a uint8 type");
   TORCH_CHECK(inputs.size(1) == 1, "inputs must be [N, 1, H, W] shape");
-  c10::hip::HIPGuard g(inputs.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(inputs.device());
   Tensor in = inputs.contiguous();
   const int64_t N = in.size(0), H = in.size(2), W = in.size(3);
   auto o = in.options().dtype(at::kInt);
@@ -266,7 +266,7 @@ std::vector<Tensor> get_connected_componnets(const Tensor& inputs) {
 Tensor fill_holes(const Tensor& logits, int64_t max_area) {
   want(logits, at::kFloat, "logits");
   TORCH_CHECK(logits.dim() >= 2, "det_sam2::fill_holes: logits must be [..., H, W]");
-  c10::hip::HIPGuard g(logits.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA g(logits.device());
   Tensor out = logits.clone();
   const int64_t H = out.size(-2), W = out.size(-1), N = out.numel() / (H * W);
   Tensor work = at::empty({3 * N * H * W}, out.options().dtype(at::kInt));
