@@ -1,0 +1,328 @@
+// Fused two-layer MLP over pre-split bf16x3 operands:  out = (act(X W1^T + b1) W2^T + b2) * gamma + R,  model width D = 256.
+//
+// Why: with the two GEMMs as separate kernels the hidden activations make a round trip through HBM as two bf16 planes -
+// 2 x rows x H x 4 bytes (memory-attention FFN, 65536 rows x 2048: 1.07 GB per layer against 0.2 GB of everything else) -
+// and each GEMM pays its own per-tile epilogue (LDS-staged plane split, store burst, the next tile's exposed first DMA):
+// at K = 256 the pair is bound by that traffic and those fixed costs, not by the matrix pipe (DESIGN.md "GEMM findings").
+// Here the hidden activations never leave the registers.
+//
+// Formulation (everything transposed so that accumulators ARE operands - the same trick as the attention kernels' P):
+//   a workgroup (4 waves, ONE per SIMD, up to 512 VGPRs each) owns 128 token rows; wave w owns tokens [32 w, 32 w + 32).
+//   phase A:  Hid^T[h, t] = sum_k W1[h, k] X[t, k]     A operand = W1 rows (LDS), B operand = X rows - held in REGISTERS for
+//             the whole row block (16 k-steps x {hi, lo} x 4 VGPRs = 128 VGPRs), accumulator lane = (token, 4 hidden rows)
+//   in registers: + b1, activation, split into bf16 hi / lo -> directly the B operand (token, 8 hidden k) of
+//   phase B:  Out^T[n, t] += sum_h W2[n, h] Hid[t, h]   A operand = W2 rows (LDS), accumulator 256 n x 32 tokens = 128 VGPRs
+//   The accumulator of a 32x32x16 MFMA gives a lane hidden rows {8g + 4h + e}: two g-groups make one 16-deep k-step whose
+//   k-slots (half h, s = 0..7) hold hidden units {4h + s | s < 4} u {8 + 4h + (s - 4)} of the 16-group - so W2 is stored with
+//   its hidden index permuted the same way inside every group of 16 ([0..3, 8..11, 4..7, 12..15]; done once per weight,
+//   launch_mlp256_permute_w2) and its fragments stay plain 16-byte LDS reads.  A sum over k is order-free: exact.
+//   The hidden dimension is walked in chunks of 64: per chunk 4 W1 tiles (64 hidden x 64 k, 16 KB with both planes) and
+//   2 W2 tiles (256 n x 32 hidden, 32 KB) stream through a 3-slot LDS ring by LDS-DMA (XOR-swizzled source addresses, the
+//   GEMM kernels' image), one barrier per tile, counted vmcnt; 24 resp. 48 MFMAs per wave per tile.  Register budget per
+//   lane: X 128 + out 128 + hidden accumulators 32 + their bf16 fragments 32 = 320 of 512, the rest buys fragment prefetch.
+//   Epilogue: a lane holds 4 consecutive output columns of its token: + b2, * gamma, + R, one 16-byte store - no LDS round trip.
+// Product terms and their order as in the GEMM kernels: a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulation.
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int MD = 256;            // model width (k of phase A, n of phase B)
+constexpr int MBR = 128;           // token rows per workgroup
+constexpr int MHC = 64;            // hidden units per chunk
+constexpr int MSLOT = 32768;       // one ring slot: hi plane at +0, lo plane at +16384; rows of 64 bytes (32 k)
+constexpr int MLO = 16384;
+constexpr int MNS = 3;             // ring slots (the tile after next is in flight while a tile is computed)
+constexpr int MTA = MD / 64;       // W1 tiles per chunk: 64 hidden x 64 k (two 32-k sub-tiles of 4 KB per plane)
+constexpr int MTB = MHC / 32;      // W2 tiles per chunk: 256 n x 32 hidden
+constexpr int MT_PER_CHUNK = MTA + MTB;
+static_assert(MT_PER_CHUNK % MNS == 0, "the ring slot of a tile must depend on its position in the chunk only");
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// hidden index permutation inside a group of 16 (see the header): new position p holds old index perm16(p)
+__host__ __device__ inline int perm16(int p) { return (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1); }
+
+__global__ void k_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_rows * H) return;
+  const int c = (int)(i % H), r = (int)(i / H);
+  out[(size_t)r * H + c] = w2[(size_t)r * ldw + (c & ~15) + perm16(c & 15)];
+}
+
+// DMA instructions one wave issues for a tile (both planes): W1 tile 16 pieces / 4 waves, W2 tile 32 pieces / 4 waves
+__host__ __device__ constexpr int tile_dma(int pos) { return (pos % MT_PER_CHUNK) < MTA ? 4 : 8; }
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm() {   // s_waitcnt needs an immediate
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else static_assert(N == 4 || N == 8, "unexpected DMA count");
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  float* b1s = reinterpret_cast<float*>(lds + MNS * MSLOT);   // [H]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  for (int i = tid; i < a.H; i += 256) b1s[i] = a.b1 ? a.b1[i] : 0.f;
+
+  const char* w1h = reinterpret_cast<const char*>(a.W1_hi);
+  const char* w1l = reinterpret_cast<const char*>(a.W1_lo);
+  const char* w2h = reinterpret_cast<const char*>(a.W2_hi);
+  const char* w2l = reinterpret_cast<const char*>(a.W2_lo);
+  const int nchunk = a.H / MHC;
+  // DMA: a piece = 16 rows x 64 B of one plane (1 KiB, one wave instruction); lane -> (row = lane >> 2, physical 16-byte
+  // chunk = lane & 3) fetching the logical chunk (lane & 3) ^ ((lane >> 4) & 3)
+  const int drow = lane >> 2;
+  const int dlc = (lane & 3) ^ ((lane >> 4) & 3);
+  const int sw = (l31 >> 2) & 3;   // reader side of the same involution
+  // per-lane source offsets (bytes) of this wave's pieces, chunk 0 / tile 0
+  unsigned offA[2], offB[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {   // W1 piece pc = 2 wave + j: sub-tile u = pc >> 2 (k + 32 u), rows (pc & 3) * 16 ..
+    const int pc = wave * 2 + j;
+    offA[j] = ((unsigned)((pc & 3) * 16 + drow) * (unsigned)a.ldw1 + (pc >> 2) * 32 + dlc * 8) * 2u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offB[j] = ((unsigned)((wave * 4 + j) * 16 + drow) * (unsigned)a.ldw2 + dlc * 8) * 2u;
+  const unsigned strideA = (unsigned)MHC * (unsigned)a.ldw1 * 2u;   // bytes between chunks of W1 (64 hidden rows)
+
+  // tile at chunk position POS of chunk c -> ring slot POS % MNS
+#define MLP_DMA(POS, c)                                                                                                   \
+  {                                                                                                                       \
+    unsigned char* base_ = lds + ((POS) % MNS) * MSLOT;                                                                   \
+    if constexpr ((POS) < MTA) {                                                                                          \
+      const unsigned o_ = (unsigned)(c) * strideA + (POS) * 128u;                                                         \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                     \
+        __builtin_amdgcn_global_load_lds(w1h + (offA[j] + o_), (lds_ptr)(base_ + (wave * 2 + j) * 1024), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds(w1l + (offA[j] + o_), (lds_ptr)(base_ + MLO + (wave * 2 + j) * 1024), 16, 0, 0); \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      const unsigned o_ = ((unsigned)(c) * MHC + ((POS) - MTA) * 32u) * 2u;                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                     \
+        __builtin_amdgcn_global_load_lds(w2h + (offB[j] + o_), (lds_ptr)(base_ + (wave * 4 + j) * 1024), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds(w2l + (offB[j] + o_), (lds_ptr)(base_ + MLO + (wave * 4 + j) * 1024), 16, 0, 0); \
+      }                                                                                                                   \
+    }                                                                                                                     \
+  }
+  // end of the step at chunk position POS: the next tile must have landed (the one after it may stay in flight), this
+  // wave's fragment reads are retired, then everybody meets
+#define MLP_STEP_END(POS)                                      \
+  __builtin_amdgcn_sched_barrier(0);                           \
+  wait_vm_lgkm<tile_dma((POS) + 2)>();                         \
+  __builtin_amdgcn_s_barrier();                                \
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int nrb = (a.rows + MBR - 1) / MBR;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int tok = rb * MBR + wave * 32 + l31;
+    const int tokc = tok < a.rows ? tok : a.rows - 1;   // clamp: rows beyond the end are computed but never stored
+    // ---- X fragments of this wave's 32 tokens: B operand (token = lane & 31, k = 16 s + 8 half .. + 7), both planes
+    bf16x8 xh[MD / 16], xl[MD / 16];
+    {
+      const uint4* ph = reinterpret_cast<const uint4*>(a.X_hi + (size_t)tokc * a.ldx + half * 8);
+      const uint4* pl = reinterpret_cast<const uint4*>(a.X_lo + (size_t)tokc * a.ldx + half * 8);
+#pragma unroll
+      for (int s = 0; s < MD / 16; ++s) {
+        xh[s] = __builtin_bit_cast(bf16x8, ph[s * 2]);
+        xl[s] = __builtin_bit_cast(bf16x8, pl[s * 2]);
+      }
+    }
+    f32x16 out[MD / 32];
+#pragma unroll
+    for (int i = 0; i < MD / 32; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) out[i][e] = 0.f;
+
+    // ---- ring prologue: tiles 0 and 1 of chunk 0 (the X loads above are ordinary loads: drained with them)
+    MLP_DMA(0, 0)
+    MLP_DMA(1, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();        // (also publishes b1s on the first row block)
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int c = 0; c < nchunk; ++c) {
+      const int cn = (c + 1 < nchunk) ? c + 1 : 0;   // (the tail prefetches wrap around: uniform DMA accounting)
+      f32x16 hid[MHC / 32];
+#pragma unroll
+      for (int i = 0; i < MHC / 32; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hid[i][e] = 0.f;
+      // ---- phase A: MTA tiles of W1 (64 hidden x 64 k)
+#define MLP_A(POS)                                                                                                        \
+  {                                                                                                                       \
+    if constexpr ((POS) + 2 < MT_PER_CHUNK) MLP_DMA((POS) + 2, c) else MLP_DMA((POS) + 2 - MT_PER_CHUNK, cn)              \
+    const unsigned char* base_ = lds + ((POS) % MNS) * MSLOT;                                                             \
+    bf16x8 wh_[4][MHC / 32], wl_[4][MHC / 32];                                                                            \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
+      _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
+        const unsigned char* r_ = base_ + (ks >> 1) * 4096 + (hb * 32 + l31) * 64 + ((((ks & 1) * 2 + half) ^ sw) << 4);  \
+        wh_[ks][hb] = *reinterpret_cast<const bf16x8*>(r_);                                                               \
+        wl_[ks][hb] = *reinterpret_cast<const bf16x8*>(r_ + MLO);                                                         \
+      }                                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
+      _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
+        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[ks][hb], xh[(POS) * 4 + ks], hid[hb], 0, 0, 0);             \
+        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xl[(POS) * 4 + ks], hid[hb], 0, 0, 0);             \
+        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xh[(POS) * 4 + ks], hid[hb], 0, 0, 0);             \
+      }                                                                                                                   \
+    MLP_STEP_END(POS)                                                                                                     \
+  }
+      MLP_A(0) MLP_A(1) MLP_A(2) MLP_A(3)
+      static_assert(MTA == 4, "phase A is unrolled by hand");
+      // ---- bias + activation + split: hid[hb] registers 8t .. 8t+7 (g = 2t, 2t+1) -> k-step t of hidden block hb.
+      //      b1 comes from LDS by inline asm: a plain LDS read here makes hipcc drain the DMA ring (s_waitcnt vmcnt(0)).
+      bf16x8 fh[MHC / 32][2], fl[MHC / 32][2];
+      {
+        f32x4 bb[MHC / 32][4];
+        const unsigned baddr = (unsigned)(MNS * MSLOT) + (unsigned)(c * MHC + 4 * half) * 4u;
+#pragma unroll
+        for (int hb = 0; hb < MHC / 32; ++hb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bb[hb][g]) : "v"(baddr), "n"((hb * 32 + 8 * g) * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hb = 0; hb < MHC / 32; ++hb) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+              const int g = 2 * t + gg;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[gg * 4 + e] = ds2_act(hid[hb][g * 4 + e] + bb[hb][g][e], ACT);
+            }
+            uint4 h, l;
+            h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);
+            h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);
+            l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
+            l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
+            l.z = cvt_pk_bf16(v[4] - bf_lo(h.z), v[5] - bf_hi(h.z));
+            l.w = cvt_pk_bf16(v[6] - bf_lo(h.w), v[7] - bf_hi(h.w));
+            fh[hb][t] = __builtin_bit_cast(bf16x8, h);
+            fl[hb][t] = __builtin_bit_cast(bf16x8, l);
+          }
+        }
+      }
+      // ---- phase B: MTB tiles of W2 (256 n x 32 permuted hidden units = hidden block Q)
+#define MLP_B(Q)                                                                                                          \
+  {                                                                                                                       \
+    if constexpr (MTA + (Q) + 2 < MT_PER_CHUNK) MLP_DMA(MTA + (Q) + 2, c) else MLP_DMA(MTA + (Q) + 2 - MT_PER_CHUNK, cn)  \
+    const unsigned char* base_ = lds + ((MTA + (Q)) % MNS) * MSLOT;                                                       \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                       \
+      bf16x8 wh_[MD / 32], wl_[MD / 32];                                                                                  \
+      _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
+        const unsigned char* r_ = base_ + (nb * 32 + l31) * 64 + (((t * 2 + half) ^ sw) << 4);                            \
+        wh_[nb] = *reinterpret_cast<const bf16x8*>(r_);                                                                   \
+        wl_[nb] = *reinterpret_cast<const bf16x8*>(r_ + MLO);                                                             \
+      }                                                                                                                   \
+      _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
+        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[nb], fh[Q][t], out[nb], 0, 0, 0);                           \
+        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fl[Q][t], out[nb], 0, 0, 0);                           \
+        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fh[Q][t], out[nb], 0, 0, 0);                           \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    MLP_STEP_END(MTA + (Q))                                                                                               \
+  }
+      MLP_B(0) MLP_B(1)
+      static_assert(MTB == 2, "phase B is unrolled by hand");
+    }
+    // ---- the ring still holds the (wrapped-around) prefetches: drain them before the ordinary loads / stores of the
+    //      epilogue and before the next row block restarts the ring
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue: lane (token, half) holds out[token][nb*32 + 8g + 4 half + e], e = 0..3: one float4 per (nb, g)
+    if (tok < a.rows) {
+#pragma unroll
+      for (int nb = 0; nb < MD / 32; ++nb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb * 32 + 8 * g + 4 * half;
+          float4 v = make_float4(out[nb][g * 4 + 0], out[nb][g * 4 + 1], out[nb][g * 4 + 2], out[nb][g * 4 + 3]);
+          if (a.b2) {
+            const float4 b = *reinterpret_cast<const float4*>(a.b2 + n);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          if (a.gamma) {
+            const float4 gm = *reinterpret_cast<const float4*>(a.gamma + n);
+            v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
+          }
+          if (a.R) {
+            const float4 r = *reinterpret_cast<const float4*>(a.R + (size_t)tok * a.ldr + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          *reinterpret_cast<float4*>(a.out + (size_t)tok * a.ldo + n) = v;
+        }
+      }
+    }
+  }
+#undef MLP_A
+#undef MLP_B
+#undef MLP_DMA
+#undef MLP_STEP_END
+}
+
+}  // namespace
+
+bool mlp256_supported(const MlpArgs& a) {
+  return a.D == MD && a.H % MHC == 0 && a.H >= MHC && a.H <= 4096 /* b1 in LDS */ && a.rows > 0 && a.ldx % 8 == 0 && a.ldw1 % 8 == 0 &&
+         a.ldw2 % 8 == 0 && a.ldo % 4 == 0 && (a.R == nullptr || a.ldr % 4 == 0) &&
+         (size_t)a.H * a.ldw1 * 2 < (1ull << 32) && (size_t)MD * a.ldw2 * 2 < (1ull << 32);
+}
+
+// W2 [n_rows = 256, H] fp32 -> the same matrix with the hidden index permuted inside every group of 16 (fp32; the caller
+// splits it into planes).  Once per weight.
+int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st) {
+  DS2_REQUIRE(H % 16 == 0, "mlp256: H must be a multiple of 16");
+  const size_t n = (size_t)n_rows * H;
+  hipLaunchKernelGGL(k_mlp256_permute_w2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w2, ldw, n_rows, H, out);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
+int launch_mlp256(const MlpArgs& a, hipStream_t st) {
+  DS2_REQUIRE(mlp256_supported(a), "mlp256: unsupported shape rows=%d D=%d H=%d", a.rows, a.D, a.H);
+  DS2_REQUIRE(a.X_hi && a.X_lo && a.W1_hi && a.W1_lo && a.W2_hi && a.W2_lo && a.out, "mlp256: null operand");
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  const int nrb = cdiv(a.rows, MBR);
+  const int grid = nrb < ncu ? nrb : ncu;
+  const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4;
+  void (*kern)(MlpArgs) = nullptr;
+  switch (a.act) {
+    case DS2_ACT_NONE: kern = k_mlp256<DS2_ACT_NONE>; break;
+    case DS2_ACT_RELU: kern = k_mlp256<DS2_ACT_RELU>; break;
+    case DS2_ACT_GELU: kern = k_mlp256<DS2_ACT_GELU>; break;
+    default: DS2_REQUIRE(false, "mlp256: unsupported activation %d", a.act);
+  }
+  static bool attr_done[4] = {false, false, false, false};
+  if (!attr_done[a.act]) {
+    DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[a.act] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}

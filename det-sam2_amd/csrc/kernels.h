@@ -115,6 +115,23 @@ bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);
 
+// fused two-layer MLP, model width 256 (gemm_mlp256.hip): out = (act(X W1^T + b1) W2^T + b2) * gamma + R; the hidden
+// activations stay in registers.  W2 planes must be built from launch_mlp256_permute_w2's output.
+struct MlpArgs {
+  int rows, D, H;                                  // D = 256; H a multiple of 128
+  const unsigned short *X_hi, *X_lo; int ldx;      // bf16 planes [rows, ldx]
+  const unsigned short *W1_hi, *W1_lo; int ldw1;   // [H, ldw1]
+  const float* b1;                                 // [H] (nullable)
+  const unsigned short *W2_hi, *W2_lo; int ldw2;   // [D, ldw2], hidden index permuted inside groups of 16
+  const float* b2; const float* gamma;             // [D] (nullable)
+  const float* R; int ldr;                         // residual fp32 [rows, ldr] (nullable)
+  float* out; int ldo;                             // fp32 [rows, ldo]
+  int act;                                         // DS2_ACT_NONE | RELU | GELU
+};
+bool mlp256_supported(const MlpArgs& a);
+int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st);
+int launch_mlp256(const MlpArgs& a, hipStream_t st);
+
 // 8-wave variant on v_mfma_f32_16x16x32_bf16 (attention_w8.hip); V^T tiles use a different key permutation
 // n_exact_keys/flag (optional): the leading n_exact_keys keys are expected to be bf16-exact; *flag (device int) is
 // zeroed and then raised by the kernel if any of them has a non-zero lo part (see launch_attention_w8)

@@ -109,6 +109,7 @@ constexpr int TOK = 4096;  // 64x64 tokens at stride 16
 struct GemmPlanes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
 struct GemmCtx {
   std::unordered_map<const float*, GemmPlanes> wcache;
+  std::unordered_map<const float*, GemmPlanes> w2perm;   // fused MLP: second-layer weights, hidden index permuted (gemm_mlp256.hip)
   char* scratch = nullptr;
   size_t scratch_cap = 0;
   int require(size_t bytes, hipStream_t st) {
@@ -124,6 +125,8 @@ struct GemmCtx {
   void release() {
     for (auto& kv : wcache) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     wcache.clear();
+    for (auto& kv : w2perm) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    w2perm.clear();
     if (scratch) (void)hipFree(scratch);
     scratch = nullptr; scratch_cap = 0;
   }
@@ -346,6 +349,82 @@ static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int
                   const float* gamma = nullptr, bool planes_out = false) {
   return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma, true, m,
               planes_out);
+}
+// weight planes of a static weight [N, K] (split once, cached)
+static int weight_planes(GemmCtx& ctx, const float* W, int N, int K, GemmPlanes* out, hipStream_t st) {
+  auto it = ctx.wcache.find(W);
+  if (it != ctx.wcache.end()) { *out = it->second; return DS2_OK; }
+  const int Kp = round32i(K);
+  GemmPlanes wp;
+  DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.hi), (size_t)N * Kp * 2));
+  DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), (size_t)N * Kp * 2));
+  wp.ld = Kp;
+  TRY(launch_split_rows(W, K, N, K, wp.hi, wp.lo, Kp, st));
+  ctx.wcache[W] = wp;
+  *out = wp;
+  return DS2_OK;
+}
+// DS2_MLP_FUSED=0 keeps the two-GEMM form (A/B runs)
+static bool mlp_fused_enabled() {
+  static const bool v = [] { const char* e = getenv("DS2_MLP_FUSED"); return !(e && atoi(e) == 0); }();
+  return v;
+}
+// out = (act(A W1^T + b1) W2^T + b2) * gamma + R with the hidden activations kept in registers (gemm_mlp256.hip); bf16x3
+// modes, model width 256 only - the caller falls back to two GEMMs when this returns DS2_ERR_UNSUPPORTED.
+// A's operand planes must be registered (its producer emitted them) or are split here.
+static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H, const float* A, int lda, const float* W1,
+                     const float* b1, const float* W2, const float* b2, const float* gamma, const float* R, int ldr, float* out,
+                     int ldo, int act) {
+  if (!ds2_split_mode() || !mlp_fused_enabled() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
+  MlpArgs a{};
+  a.rows = rows; a.D = 256; a.H = H; a.ldx = 256; a.ldw1 = 256; a.ldw2 = H;
+  a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.R = R; a.ldr = ldr; a.out = out; a.ldo = ldo; a.act = act;
+  if (!mlp256_supported(a) || !(act == DS2_ACT_NONE || act == DS2_ACT_RELU || act == DS2_ACT_GELU)) return DS2_ERR_UNSUPPORTED;
+  char ptag[96] = "";
+  if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_mlp256 %d %d %d", rows, 256, 2 * H);   // (2*M*N*K with K = 2H: both layers)
+  GemmPlanes w1p, w2p;
+  TRY(weight_planes(ctx, W1, H, 256, &w1p, st));
+  auto it = ctx.w2perm.find(W2);
+  if (it != ctx.w2perm.end()) {
+    w2p = it->second;
+  } else {   // once per weight: permute the hidden index inside groups of 16, then split
+    float* tmp = nullptr;
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)256 * H * 4));
+    TRY(launch_mlp256_permute_w2(W2, H, 256, H, tmp, st));
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.hi), (size_t)256 * H * 2));
+    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.lo), (size_t)256 * H * 2));
+    w2p.ld = H;
+    TRY(launch_split_rows(tmp, H, 256, H, w2p.hi, w2p.lo, H, st));
+    DS2_CHECK_HIP(hipStreamSynchronize(st));
+    DS2_CHECK_HIP(hipFree(tmp));
+    ctx.w2perm[W2] = w2p;
+  }
+  const unsigned short *xh = nullptr, *xl = nullptr;
+  if (m) {
+    auto ia = m->act_planes.find(A);
+    if (ia != m->act_planes.end() && ia->second.ld == 256) { xh = ia->second.hi; xl = ia->second.lo; }
+  }
+  if (!xh) {
+    TRY(ctx.require((size_t)rows * 256 * 4 + 512, st));
+    unsigned short* sh = reinterpret_cast<unsigned short*>(ctx.scratch);
+    unsigned short* sl = sh + (size_t)rows * 256;
+    TRY(launch_split_rows(A, lda, rows, 256, sh, sl, 256, st));
+    xh = sh; xl = sl;
+  }
+  a.X_hi = xh; a.X_lo = xl;
+  a.W1_hi = w1p.hi; a.W1_lo = w1p.lo; a.ldw1 = w1p.ld;
+  a.W2_hi = w2p.hi; a.W2_lo = w2p.lo; a.ldw2 = w2p.ld;
+  ProfScope _gp(ptag, st, g_prof_gemm);
+  return launch_mlp256(a, st);
+}
+// two-layer MLP by state_dict prefixes: fused when the shape allows it, else the two GEMMs (hidden planes in `hbuf`)
+static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::string& p2, int rows, int H, const float* A,
+                float* hbuf, float* out, int act, const float* R, const float* gamma) {
+  const int rc = mlp_fused(m, m->gctx, st, rows, H, A, 256, m->P(p1 + ".weight"), m->P(p1 + ".bias"), m->P(p2 + ".weight"),
+                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act);
+  if (rc != DS2_ERR_UNSUPPORTED) return rc;
+  TRY(linear(m, st, p1, rows, H, 256, A, 256, hbuf, H, act, nullptr, 0, 0, nullptr, true));
+  return linear(m, st, p2, rows, 256, H, hbuf, H, out, 256, DS2_ACT_NONE, R, 256, 0, gamma);
 }
 // planes_out (bf16x3 mode only): the result is emitted as GEMM operand planes registered under key y; the fp32
 // buffer y is not written, so every consumer of y must be a gemm()/linear().
@@ -921,8 +1000,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     // -- FFN
     TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
-    TRY(linear(m, st, p + ".linear1", rows, F, 256, t, 256, h, F, DS2_ACT_RELU, nullptr, 0, 0, nullptr, true));
-    TRY(linear(m, st, p + ".linear2", rows, 256, F, h, F, x, 256, DS2_ACT_NONE, x, 256));
+    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr));
     m->release(layer_mark);
   }
   TRY(layernorm(m, st, "memory_attention.norm", x, out, rows, 256, 1e-5f));
@@ -1188,8 +1266,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
     const std::string p = me + ".fuser.layers." + std::to_string(l);
     TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
     TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
-    TRY(linear(m, st, p + ".pwconv1", rows, 1024, 256, t, 256, h, 1024, DS2_ACT_GELU, nullptr, 0, 0, nullptr, true));
-    TRY(linear(m, st, p + ".pwconv2", rows, 256, 1024, h, 1024, x, 256, DS2_ACT_NONE, x, 256, 0, m->P(p + ".gamma")));
+    TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma")));
   }
   if (out_f32) {      // MemoryEncoder.forward's own output (no no_obj_embed_spatial, no bf16 storage rounding)
     TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, out_f32, 64));
@@ -1239,6 +1316,13 @@ extern "C" int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int3
                            const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
                            int32_t ldr, int32_t r_mod, void* stream) {
   return gemm((hipStream_t)stream, M, N, K, A, lda, W, ldw, bias, C, ldc, act, R, ldr, r_mod, gamma);
+}
+extern "C" int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
+                          const float* gamma, const float* R, float* out, int32_t act, void* stream) {
+  DS2_REQUIRE(rows > 0 && H > 0 && X && W1 && W2 && out, "ds2_op_mlp: bad argument");
+  const int rc = mlp_fused(nullptr, g_gemm_ctx, (hipStream_t)stream, rows, H, X, 256, W1, b1, W2, b2, gamma, R, 256, out, 256, act);
+  DS2_REQUIRE(rc != DS2_ERR_UNSUPPORTED, "ds2_op_mlp: needs a bf16x3 mode, width 256, H a multiple of 64 (<= 4096), act none / relu / gelu");
+  return rc;
 }
 extern "C" int ds2_op_layernorm(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t C, float eps,
                                 int32_t act, void* stream) {

@@ -87,6 +87,14 @@ class HipOps:
                                          _p(R), 0 if R is None else R.stride(0), r_mod, self._stream()), "ds2_op_gemm")
         return out
 
+    def op_mlp(self, X, W1, b1, W2, b2, gamma=None, R=None, act=1):
+        """Fused two-layer MLP of width 256 (ds2_op_mlp): X [rows,256], W1 [H,256], W2 [256,H] -> [rows,256]."""
+        rows, H = X.shape[0], W1.shape[0]
+        out = self._empty(rows, 256)
+        _capi.check(self.lib.ds2_op_mlp(rows, H, _p(X), _p(W1), _p(b1), _p(W2), _p(b2), _p(gamma), _p(R), _p(out), act, self._stream()),
+                    "ds2_op_mlp")
+        return out
+
     def op_layernorm(self, x, w, b, eps, act=0):
         out = torch.empty_like(x)
         _capi.check(self.lib.ds2_op_layernorm(_p(x), _p(w), _p(b), _p(out), x.shape[0], x.shape[1], eps, act, self._stream()),

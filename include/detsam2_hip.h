@@ -218,6 +218,11 @@ int ds2_profile_tags(char* buf, int64_t cap);
 int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
                 const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
                 int32_t ldr, int32_t r_mod, void* stream);
+/* fused two-layer MLP of width 256: out = (act(X W1^T + b1) W2^T + b2) * gamma + R with X [rows,256], W1 [H,256], W2 [256,H],
+ * R / out [rows,256]; b1, b2, gamma, R may be NULL.  The kernel behind MemoryAttentionLayer's FFN (memory_attention.py:93-98)
+ * and CXBlock's pwconv1 / pwconv2 (memory_encoder.py:104-117) in the bf16x3 modes. */
+int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
+               const float* gamma, const float* R, float* out, int32_t act, void* stream);
 int ds2_op_layernorm(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t C, float eps,
                      int32_t act, void* stream);
 int ds2_op_attention(const float* q, const float* k, const float* v, float* o, int32_t ldq, int32_t ldk, int32_t ldv,

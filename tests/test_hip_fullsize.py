@@ -50,7 +50,8 @@ def test_config3_preloaded_bank_bplus_16_objects(bplus, P, tmp_path):
     dt = time.perf_counter() - t0
     trace, pred.trace = pred.trace, None
     assert pred.stats["encoder_runs"] - enc0 == n       # every stream frame encoded exactly once although it is tracked twice
-    assert pred.stats["tracked_frames"] - trk0 == 2 * n - 15
+    # no conditioning frames in the new stream: every visited frame is tracked; pass k visits min(30, frames so far)
+    assert pred.stats["tracked_frames"] - trk0 == sum(min(30, min(15 * (k + 1), n)) for k in range(-(-n // 15)))
     assert b.pre_frames == P and len(b.inference_state["images"]) <= 30            # the bank file carries no frames
     assert sorted(segs) == list(range(n))
     for t in range(n):
