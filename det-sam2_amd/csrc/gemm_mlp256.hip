@@ -17,7 +17,7 @@
 //   its hidden index permuted the same way inside every group of 16 ([0..3, 8..11, 4..7, 12..15]; done once per weight,
 //   launch_mlp256_permute_w2) and its fragments stay plain 16-byte LDS reads.  A sum over k is order-free: exact.
 //   The hidden dimension is walked in chunks of 64: per chunk 4 W1 tiles (64 hidden x 64 k, 16 KB with both planes) and
-//   2 W2 tiles (256 n x 32 hidden, 32 KB) stream through a 3-slot LDS ring by LDS-DMA (XOR-swizzled source addresses, the
+//   2 W2 tiles (256 n x 32 hidden, 32 KB) stream through a 4-slot LDS ring by LDS-DMA (XOR-swizzled source addresses, the
 //   GEMM kernels' image), one barrier per tile, counted vmcnt; 24 resp. 48 MFMAs per wave per tile.  Register budget per
 //   lane: X 128 + out 128 + hidden accumulators 32 + their bf16 fragments 32 = 320 of 512, the rest buys fragment prefetch.
 //   Epilogue: a lane holds 4 consecutive output columns of its token: + b2, * gamma, + R, one 16-byte store - no LDS round trip.
@@ -35,11 +35,12 @@ constexpr int MBR = 128;           // token rows per workgroup
 constexpr int MHC = 64;            // hidden units per chunk
 constexpr int MSLOT = 32768;       // one ring slot: hi plane at +0, lo plane at +16384; rows of 64 bytes (32 k)
 constexpr int MLO = 16384;
-constexpr int MNS = 3;             // ring slots (the tile after next is in flight while a tile is computed)
+constexpr int MNS = 4;             // ring slots: three tiles ahead of the one being computed are in flight
 constexpr int MTA = MD / 64;       // W1 tiles per chunk: 64 hidden x 64 k (two 32-k sub-tiles of 4 KB per plane)
 constexpr int MTB = MHC / 32;      // W2 tiles per chunk: 256 n x 32 hidden
-constexpr int MT_PER_CHUNK = MTA + MTB;
-static_assert(MT_PER_CHUNK % MNS == 0, "the ring slot of a tile must depend on its position in the chunk only");
+constexpr int MT_PER_CHUNK = MTA + MTB;   // 6
+constexpr int MT_PAIR = 2 * MT_PER_CHUNK; // the loop body covers a PAIR of chunks: 12 tiles, a multiple of the ring size
+static_assert(MT_PAIR % MNS == 0, "the ring slot of a tile must depend on its position in the chunk pair only");
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   unsigned r;
@@ -64,9 +65,10 @@ __host__ __device__ constexpr int tile_dma(int pos) { return (pos % MT_PER_CHUNK
 
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm() {   // s_waitcnt needs an immediate
-  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-  else static_assert(N == 4 || N == 8, "unexpected DMA count");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+  else static_assert(N == 8 || N == 12 || N == 16, "unexpected DMA count");
 }
 
 template <int ACT>
@@ -103,30 +105,47 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   for (int j = 0; j < 4; ++j) offB[j] = ((unsigned)((wave * 4 + j) * 16 + drow) * (unsigned)a.ldw2 + dlc * 8) * 2u;
   const unsigned strideA = (unsigned)MHC * (unsigned)a.ldw1 * 2u;   // bytes between chunks of W1 (64 hidden rows)
 
-  // tile at chunk position POS of chunk c -> ring slot POS % MNS
-#define MLP_DMA(POS, c)                                                                                                   \
+  // tile at position P6 (0..5) of chunk `c` into the ring slot of pair position PP (slot = PP % MNS)
+#define MLP_DMA(P6, c, PP)                                                                                                \
   {                                                                                                                       \
-    unsigned char* base_ = lds + ((POS) % MNS) * MSLOT;                                                                   \
-    if constexpr ((POS) < MTA) {                                                                                          \
-      const unsigned o_ = (unsigned)(c) * strideA + (POS) * 128u;                                                         \
+    unsigned char* base_ = lds + ((PP) % MNS) * MSLOT;                                                                    \
+    if constexpr ((P6) < MTA) {                                                                                           \
+      const unsigned o_ = (unsigned)(c) * strideA + (P6) * 128u;                                                          \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                     \
         __builtin_amdgcn_global_load_lds(w1h + (offA[j] + o_), (lds_ptr)(base_ + (wave * 2 + j) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds(w1l + (offA[j] + o_), (lds_ptr)(base_ + MLO + (wave * 2 + j) * 1024), 16, 0, 0); \
       }                                                                                                                   \
     } else {                                                                                                              \
-      const unsigned o_ = ((unsigned)(c) * MHC + ((POS) - MTA) * 32u) * 2u;                                               \
+      const unsigned o_ = ((unsigned)(c) * MHC + ((P6) - MTA) * 32u) * 2u;                                                \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                     \
         __builtin_amdgcn_global_load_lds(w2h + (offB[j] + o_), (lds_ptr)(base_ + (wave * 4 + j) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds(w2l + (offB[j] + o_), (lds_ptr)(base_ + MLO + (wave * 4 + j) * 1024), 16, 0, 0); \
       }                                                                                                                   \
     }                                                                                                                     \
   }
-  // end of the step at chunk position POS: the next tile must have landed (the one after it may stay in flight), this
+  // prefetch issued at pair position PP: the tile MNS - 1 positions ahead (in this pair, or in the next one)
+#define MLP_PREFETCH(PP)                                                                                                  \
+  if constexpr ((PP) + MNS - 1 < MT_PAIR) MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, c2 + ((PP) + MNS - 1) / MT_PER_CHUNK, (PP) + MNS - 1) \
+  else MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, cn2 + ((PP) + MNS - 1 - MT_PAIR) / MT_PER_CHUNK, (PP) + MNS - 1)
+  // order of a step's instructions (one wave per SIMD: nobody else hides the LDS latency): the DMA issue first, then the
+  // fragment pairs (hi, lo) in groups of two = 6 MFMAs.  Three register sets: groups g and g + 1 are resident, group g + 2
+  // is fetched into the third set after the first two MFMAs of group g - hipcc's wait before group g + 1 is an
+  // lgkmcnt(0), so the youngest read in flight must be old by then (4 MFMAs = 128 cycles).  NP = pairs of the step.
+#define MLP_INTERLEAVE(NP)                                                                    \
+  __builtin_amdgcn_sched_group_barrier(0x010, 16, 0);   /* VMEM: the prefetch DMA */           \
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    /* DS read: groups 0, 1 */             \
+  _Pragma("unroll") for (int i_ = 0; i_ < (NP) / 2 - 2; ++i_) {                               \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                         \
+  }                                                                                           \
+  __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+  // end of the step at pair position PP: the next tile must have landed (the two after it may stay in flight), this
   // wave's fragment reads are retired, then everybody meets
-#define MLP_STEP_END(POS)                                      \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  wait_vm_lgkm<tile_dma((POS) + 2)>();                         \
-  __builtin_amdgcn_s_barrier();                                \
+#define MLP_STEP_END(PP)                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  wait_vm_lgkm<tile_dma((PP) + 2) + tile_dma((PP) + 3)>();                       \
+  __builtin_amdgcn_s_barrier();                                                  \
   __builtin_amdgcn_sched_barrier(0);
 
   const int nrb = (a.rows + MBR - 1) / MBR;
@@ -136,12 +155,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     // ---- X fragments of this wave's 32 tokens: B operand (token = lane & 31, k = 16 s + 8 half .. + 7), both planes
     bf16x8 xh[MD / 16], xl[MD / 16];
     {
-      const uint4* ph = reinterpret_cast<const uint4*>(a.X_hi + (size_t)tokc * a.ldx + half * 8);
-      const uint4* pl = reinterpret_cast<const uint4*>(a.X_lo + (size_t)tokc * a.ldx + half * 8);
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4* ph = reinterpret_cast<const u32x4*>(a.X_hi + (size_t)tokc * a.ldx + half * 8);
+      const u32x4* pl = reinterpret_cast<const u32x4*>(a.X_lo + (size_t)tokc * a.ldx + half * 8);
 #pragma unroll
       for (int s = 0; s < MD / 16; ++s) {
-        xh[s] = __builtin_bit_cast(bf16x8, ph[s * 2]);
-        xl[s] = __builtin_bit_cast(bf16x8, pl[s * 2]);
+        xh[s] = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(ph + s * 2));   // streamed once: keep the weights in L2
+        xl[s] = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(pl + s * 2));
       }
     }
     f32x16 out[MD / 32];
@@ -150,25 +170,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) out[i][e] = 0.f;
 
-    // ---- ring prologue: tiles 0 and 1 of chunk 0 (the X loads above are ordinary loads: drained with them)
-    MLP_DMA(0, 0)
-    MLP_DMA(1, 0)
+    // ---- ring prologue: tiles 0..2 of chunk 0 (the X loads above are ordinary loads: drained with them)
+    MLP_DMA(0, 0, 0)
+    MLP_DMA(1, 0, 1)
+    MLP_DMA(2, 0, 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // (also publishes b1s on the first row block)
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int c = 0; c < nchunk; ++c) {
-      const int cn = (c + 1 < nchunk) ? c + 1 : 0;   // (the tail prefetches wrap around: uniform DMA accounting)
-      f32x16 hid[MHC / 32];
-#pragma unroll
-      for (int i = 0; i < MHC / 32; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) hid[i][e] = 0.f;
-      // ---- phase A: MTA tiles of W1 (64 hidden x 64 k)
-#define MLP_A(POS)                                                                                                        \
+    for (int c2 = 0; c2 < nchunk; c2 += 2) {
+      const int cn2 = (c2 + 2 < nchunk) ? c2 + 2 : 0;   // (the tail prefetches wrap around: uniform DMA accounting)
+      // phase A step at pair position PP (tile T = PP % 6 of chunk c2 + PP / 6): W1 tile, 64 hidden x 64 k
+#define MLP_A(PP)                                                                                                         \
   {                                                                                                                       \
-    if constexpr ((POS) + 2 < MT_PER_CHUNK) MLP_DMA((POS) + 2, c) else MLP_DMA((POS) + 2 - MT_PER_CHUNK, cn)              \
-    const unsigned char* base_ = lds + ((POS) % MNS) * MSLOT;                                                             \
+    MLP_PREFETCH(PP)                                                                                                      \
+    const unsigned char* base_ = lds + ((PP) % MNS) * MSLOT;                                                              \
     bf16x8 wh_[4][MHC / 32], wl_[4][MHC / 32];                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
       _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
@@ -178,55 +194,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
       }                                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
       _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
-        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[ks][hb], xh[(POS) * 4 + ks], hid[hb], 0, 0, 0);             \
-        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xl[(POS) * 4 + ks], hid[hb], 0, 0, 0);             \
-        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xh[(POS) * 4 + ks], hid[hb], 0, 0, 0);             \
+        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[ks][hb], xh[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb], 0, 0, 0); \
+        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xl[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb], 0, 0, 0); \
+        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xh[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb], 0, 0, 0); \
       }                                                                                                                   \
-    MLP_STEP_END(POS)                                                                                                     \
+    MLP_INTERLEAVE(8)                                                                                                     \
+    MLP_STEP_END(PP)                                                                                                      \
   }
-      MLP_A(0) MLP_A(1) MLP_A(2) MLP_A(3)
-      static_assert(MTA == 4, "phase A is unrolled by hand");
-      // ---- bias + activation + split: hid[hb] registers 8t .. 8t+7 (g = 2t, 2t+1) -> k-step t of hidden block hb.
-      //      b1 comes from LDS by inline asm: a plain LDS read here makes hipcc drain the DMA ring (s_waitcnt vmcnt(0)).
-      bf16x8 fh[MHC / 32][2], fl[MHC / 32][2];
-      {
-        f32x4 bb[MHC / 32][4];
-        const unsigned baddr = (unsigned)(MNS * MSLOT) + (unsigned)(c * MHC + 4 * half) * 4u;
-#pragma unroll
-        for (int hb = 0; hb < MHC / 32; ++hb)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bb[hb][g]) : "v"(baddr), "n"((hb * 32 + 8 * g) * 4));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int hb = 0; hb < MHC / 32; ++hb) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            float v[8];
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-              const int g = 2 * t + gg;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[gg * 4 + e] = ds2_act(hid[hb][g * 4 + e] + bb[hb][g][e], ACT);
-            }
-            uint4 h, l;
-            h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);
-            h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);
-            l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
-            l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
-            l.z = cvt_pk_bf16(v[4] - bf_lo(h.z), v[5] - bf_hi(h.z));
-            l.w = cvt_pk_bf16(v[6] - bf_lo(h.w), v[7] - bf_hi(h.w));
-            fh[hb][t] = __builtin_bit_cast(bf16x8, h);
-            fl[hb][t] = __builtin_bit_cast(bf16x8, l);
-          }
-        }
-      }
-      // ---- phase B: MTB tiles of W2 (256 n x 32 permuted hidden units = hidden block Q)
-#define MLP_B(Q)                                                                                                          \
+      // phase B step at pair position PP: W2 tile (256 n x 32 permuted hidden units = hidden block Q = PP % 6 - 4)
+#define MLP_B(PP)                                                                                                         \
   {                                                                                                                       \
-    if constexpr (MTA + (Q) + 2 < MT_PER_CHUNK) MLP_DMA(MTA + (Q) + 2, c) else MLP_DMA(MTA + (Q) + 2 - MT_PER_CHUNK, cn)  \
-    const unsigned char* base_ = lds + ((MTA + (Q)) % MNS) * MSLOT;                                                       \
+    MLP_PREFETCH(PP)                                                                                                      \
+    const unsigned char* base_ = lds + ((PP) % MNS) * MSLOT;                                                              \
+    constexpr int Q_ = (PP) % MT_PER_CHUNK - MTA;                                                                         \
     _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                       \
       bf16x8 wh_[MD / 32], wl_[MD / 32];                                                                                  \
       _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
@@ -235,15 +215,56 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
         wl_[nb] = *reinterpret_cast<const bf16x8*>(r_ + MLO);                                                             \
       }                                                                                                                   \
       _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
-        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[nb], fh[Q][t], out[nb], 0, 0, 0);                           \
-        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fl[Q][t], out[nb], 0, 0, 0);                           \
-        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fh[Q][t], out[nb], 0, 0, 0);                           \
+        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[nb], fh[Q_][t], out[nb], 0, 0, 0);                          \
+        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fl[Q_][t], out[nb], 0, 0, 0);                          \
+        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fh[Q_][t], out[nb], 0, 0, 0);                          \
       }                                                                                                                   \
     }                                                                                                                     \
-    MLP_STEP_END(MTA + (Q))                                                                                               \
+    MLP_INTERLEAVE(16)                                                                                                    \
+    MLP_STEP_END(PP)                                                                                                      \
   }
-      MLP_B(0) MLP_B(1)
-      static_assert(MTB == 2, "phase B is unrolled by hand");
+      // bias + activation + split of chunk c: hid[hb] registers 8t .. 8t+7 (g = 2t, 2t+1) -> k-step t of hidden block hb.
+      // b1 comes from LDS by inline asm: a plain LDS read here makes hipcc drain the DMA ring (s_waitcnt vmcnt(0)).
+#define MLP_ACT(c)                                                                                                        \
+  {                                                                                                                       \
+    f32x4 bb[MHC / 32][4];                                                                                                \
+    const unsigned baddr = (unsigned)(MNS * MSLOT) + (unsigned)((c) * MHC + 4 * half) * 4u;                               \
+    _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb)                                                               \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bb[hb][g]) : "v"(baddr), "n"((hb * 32 + 8 * g) * 4));         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb)                                                               \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
+        float v[8];                                                                                                       \
+        _Pragma("unroll") for (int gg = 0; gg < 2; ++gg)                                                                  \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                   \
+            v[gg * 4 + e] = ds2_act(hid[hb][(2 * t + gg) * 4 + e] + bb[hb][2 * t + gg][e], ACT);                          \
+        uint4 h, l;                                                                                                       \
+        h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);                                                     \
+        h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);                                                     \
+        l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));                                                          \
+        l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));                                                          \
+        l.z = cvt_pk_bf16(v[4] - bf_lo(h.z), v[5] - bf_hi(h.z));                                                          \
+        l.w = cvt_pk_bf16(v[6] - bf_lo(h.w), v[7] - bf_hi(h.w));                                                          \
+        fh[hb][t] = __builtin_bit_cast(bf16x8, h);                                                                        \
+        fl[hb][t] = __builtin_bit_cast(bf16x8, l);                                                                        \
+      }                                                                                                                   \
+  }
+#define MLP_ZERO_HID()                                                   \
+  _Pragma("unroll") for (int i = 0; i < MHC / 32; ++i)                   \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) hid[i][e] = 0.f;
+      static_assert(MTA == 4 && MTB == 2, "the chunk pair is unrolled by hand");
+      f32x16 hid[MHC / 32];
+      bf16x8 fh[MHC / 32][2], fl[MHC / 32][2];
+      MLP_ZERO_HID()
+      MLP_A(0) MLP_A(1) MLP_A(2) MLP_A(3)
+      MLP_ACT(c2)
+      MLP_B(4) MLP_B(5)
+      MLP_ZERO_HID()
+      MLP_A(6) MLP_A(7) MLP_A(8) MLP_A(9)
+      MLP_ACT(c2 + 1)
+      MLP_B(10) MLP_B(11)
     }
     // ---- the ring still holds the (wrapped-around) prefetches: drain them before the ordinary loads / stores of the
     //      epilogue and before the next row block restarts the ring
@@ -267,8 +288,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
             v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
           }
           if (a.R) {
-            const float4 r = *reinterpret_cast<const float4*>(a.R + (size_t)tok * a.ldr + n);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.R + (size_t)tok * a.ldr + n));
+            v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
           }
           *reinterpret_cast<float4*>(a.out + (size_t)tok * a.ldo + n) = v;
         }
@@ -277,6 +298,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   }
 #undef MLP_A
 #undef MLP_B
+#undef MLP_ACT
+#undef MLP_ZERO_HID
+#undef MLP_PREFETCH
+#undef MLP_INTERLEAVE
 #undef MLP_DMA
 #undef MLP_STEP_END
 }
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
 }  // namespace
 
 bool mlp256_supported(const MlpArgs& a) {
-  return a.D == MD && a.H % MHC == 0 && a.H >= MHC && a.H <= 4096 /* b1 in LDS */ && a.rows > 0 && a.ldx % 8 == 0 && a.ldw1 % 8 == 0 &&
+  return a.D == MD && a.H % (2 * MHC) == 0 && a.H <= 4096 /* chunk pairs; b1 in LDS */ && a.rows > 0 && a.ldx % 8 == 0 && a.ldw1 % 8 == 0 &&
          a.ldw2 % 8 == 0 && a.ldo % 4 == 0 && (a.R == nullptr || a.ldr % 4 == 0) &&
          (size_t)a.H * a.ldw1 * 2 < (1ull << 32) && (size_t)MD * a.ldw2 * 2 < (1ull << 32);
 }

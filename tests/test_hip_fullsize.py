@@ -146,6 +146,7 @@ def test_config4_large_16_objects_1000_frames_sharded_over_8_ranks_equals_sequen
     for r in range(world):
         p = SAM2VideoPredictor(cfg, sd, "cuda:0", max_batch=B)
         p.async_encode = False                 # a sharded rank encodes its whole buffer up front (encode_frames)
+        p.encode_batch = 5                     # 8 predictors share ONE GPU here: keep each encoder arena at ~10 GB (same results)
         vps.append(P.ShardedVideoProcessor(model_cfg=cfg.name, detector=SyntheticDetector(B), skip_classes=set(), predictor=p,
                                            rank=r, world_size=world))
     free = []
