@@ -116,11 +116,31 @@ def ingest_lut(mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     return out
 
 
+def fold_out_v(w_out, b_out, w_v, b_v):
+    """out_proj(v_proj(z)) = z (Wo Wv)^T + (Wo bv + bo): two Linear layers with nothing in between collapse into one
+    (RoPEAttention / Attention.forward, sam/transformer.py:259-284: out_proj is applied to softmax(QK^T) V and the softmax
+    rows sum to 1, so with V = M Wv^T + bv the product P V carries the bias through unchanged).  Folded in float64,
+    rounded once to float32.  -> (W [256, kv_in], b [256])."""
+    wo, wv = np.asarray(w_out, np.float64), np.asarray(w_v, np.float64)
+    w = wo @ wv
+    b = wo @ np.asarray(b_v, np.float64) + np.asarray(b_out, np.float64)
+    return np.ascontiguousarray(w.astype(F32)), np.ascontiguousarray(b.astype(F32))
+
+
 def model_constants(cfg, sd):
     """All '#'-named constants for ``cfg`` given the checkpoint ``sd`` (name -> numpy array)."""
     g = lambda k: np.asarray(sd[k], F32)  # noqa: E731
     hw = cfg.feat_hw
+    folded = {}
+    for l in range(cfg.mem_attn_layers):   # memory cross-attention: out_proj o v_proj as ONE 64 -> 256 projection
+        p = f"memory_attention.layers.{l}.cross_attn_image."
+        folded[f"#ma_cross_vo_w.{l}"], folded[f"#ma_cross_vo_b.{l}"] = fold_out_v(
+            g(p + "out_proj.weight"), g(p + "out_proj.bias"), g(p + "v_proj.weight"), g(p + "v_proj.bias"))
+        p = f"memory_attention.layers.{l}.self_attn."      # self-attention: the values are projected straight into the
+        folded[f"#ma_self_vo_w.{l}"], folded[f"#ma_self_vo_b.{l}"] = fold_out_v(     # residual stream (no out_proj GEMM)
+            g(p + "out_proj.weight"), g(p + "out_proj.bias"), g(p + "v_proj.weight"), g(p + "v_proj.bias"))
     return {
+        **folded,
         "#pos_embed": hiera_pos_embed(g("image_encoder.trunk.pos_embed"), g("image_encoder.trunk.pos_embed_window"),
                                       cfg.image_size // 4),
         "#rope_cis": rope_cis(cfg.d_model, hw, hw, cfg.rope_theta),

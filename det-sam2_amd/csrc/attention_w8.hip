@@ -120,6 +120,8 @@ struct W8Args {
   // optional: apply_rotary_enc (position_encoding.py:196-220) to the queries while they are loaded (query t of a batch item
   // is rotated with cis[t % rope_grid]) - replaces a separate in-place k_rope pass over q
   const float* rope_cis; int rope_grid, rope_w;   // rope_w > 0: compact table rows (GemmSplitArgs::rope_w)
+  // optional, fp32 output only: o = res + attention (the residual stream; used when out_proj is folded into the values)
+  const float* res; int ldres;
 };
 
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
@@ -419,9 +421,16 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       }
     } else {
       float* op = a.o + orow * a.ldo + 4 * grp;
+      const float* rp = a.res ? a.res + orow * a.ldres + 4 * grp : nullptr;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        *reinterpret_cast<float4*>(op + 16 * t) = make_float4(o[g][t][0] * inv, o[g][t][1] * inv, o[g][t][2] * inv, o[g][t][3] * inv);
+      for (int t = 0; t < NT; ++t) {
+        float4 v = make_float4(o[g][t][0] * inv, o[g][t][1] * inv, o[g][t][2] * inv, o[g][t][3] * inv);
+        if (rp) {
+          const float4 r = *reinterpret_cast<const float4*>(rp + 16 * t);
+          v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        *reinterpret_cast<float4*>(op + 16 * t) = v;
+      }
     }
   }
 }
@@ -479,7 +488,7 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
-                        int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid) {
+                        int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid, const float* res, int ldres) {
   const bool klo = ds2_precision() != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
@@ -487,7 +496,8 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
-           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0};
+           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0, res, ldres};
+  DS2_REQUIRE(!res || (o && !o_hi && ldres % 4 == 0), "attention_w8: a residual needs the fp32 output");
   for (int w = 1; w * w <= q_rope_grid; ++w)
     if (w * w == q_rope_grid) a.rope_w = w;   // square axial grid (compute_axial_cis with end_x = end_y)
   DS2_REQUIRE(!q_rope_cis || q_rope_grid > 0, "attention_w8: rope grid");

@@ -158,6 +158,7 @@ struct ds2_model {
   ds2_config cfg;
   int device = 0;              // the device that was current at ds2_model_create
   int precision = DS2_PREC_BF16X3K;   // arithmetic mode of this model's stages (ds2_model_set_precision)
+  bool ma_fold_vo = false;            // memory attention: out_proj folded into the value projections (set at finalize)
   GemmCtx gctx;
   std::vector<BlockCfg> blocks;
   std::vector<int> stage_ends;
@@ -221,6 +222,11 @@ struct ds2_model {
 };
 
 static int model_precision(const ds2_model* m) { return m->precision; }
+// DS2_MA_FOLD_VO=0: keep out_proj of the memory attention's two attentions as its own GEMM (A/B runs)
+static bool ma_fold_vo_enabled() {
+  static const bool v = [] { const char* e = getenv("DS2_MA_FOLD_VO"); return !(e && atoi(e) == 0); }();
+  return v;
+}
 ModelScope::ModelScope(const ds2_model* m) : dg(m->device), ps(m->precision) {}
 
 #define ALLOC(var, n)                                                        \
@@ -560,11 +566,17 @@ extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
     TRY(m->add_derived("@ma_qkv_w." + std::to_string(l), 768 * 256, &fw));
     TRY(m->add_derived("@ma_qkv_b." + std::to_string(l), 768, &fb));
     const char* names[3] = {"q_proj", "k_proj", "v_proj"};
+    // (fold: the value rows are out_proj o v_proj, constants.py fold_out_v - the attention output then IS the out_proj result)
+    m->ma_fold_vo = ma_fold_vo_enabled() && m->Pbytes("#ma_self_vo_w." + std::to_string(l)) == 256 * 256 * 4 &&
+                    m->Pbytes("#ma_cross_vo_w." + std::to_string(l)) == 256 * 64 * 4;
     for (int j = 0; j < 3; ++j) {
       TRY(expect(m, p + names[j] + ".weight", 256 * 256));
       TRY(expect(m, p + names[j] + ".bias", 256));
-      DS2_CHECK_HIP(hipMemcpyAsync(fw + j * 256 * 256, m->P(p + names[j] + ".weight"), 256 * 256 * 4, hipMemcpyDeviceToDevice, st));
-      DS2_CHECK_HIP(hipMemcpyAsync(fb + j * 256, m->P(p + names[j] + ".bias"), 256 * 4, hipMemcpyDeviceToDevice, st));
+      const bool fold = j == 2 && m->ma_fold_vo;
+      const float* wsrc = fold ? m->P("#ma_self_vo_w." + std::to_string(l)) : m->P(p + names[j] + ".weight");
+      const float* bsrc = fold ? m->P("#ma_self_vo_b." + std::to_string(l)) : m->P(p + names[j] + ".bias");
+      DS2_CHECK_HIP(hipMemcpyAsync(fw + j * 256 * 256, wsrc, 256 * 256 * 4, hipMemcpyDeviceToDevice, st));
+      DS2_CHECK_HIP(hipMemcpyAsync(fb + j * 256, bsrc, 256 * 4, hipMemcpyDeviceToDevice, st));
     }
   }
   // ConvTranspose2d(2x2,s2) as GEMM: weight [Cin,Cout,2,2] -> [(dy,dx,cout), cin]; bias tiled 4x
@@ -947,10 +959,15 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st));
       ProfScope _p("kernel.self_attention", st);
       ds2_model::ActPlanes sa_p{};
-      TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
+      float* xs = once ? x1 : x;               // the residual stream this self-attention updates
+      if (!m->ma_fold_vo) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
       TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));   // all 256 value columns in one pass
-      TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
-                              sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK));
+      if (m->ma_fold_vo)   // values already carry out_proj: the kernel adds its result to the residual stream in place
+        TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, xs, 256, Bs, TOK, TOK, sc, 256, st, nullptr,
+                                nullptr, 0, 0, nullptr, cis, TOK, xs, 256));
+      else
+        TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
+                                sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK));
     } else {
       TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
       AttnArgs sa{};
@@ -959,12 +976,16 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       sa.batch = Bs; sa.heads = 1; sa.D = 256; sa.DV = 256; sa.Lq = sa.Lk = TOK; sa.scale = sc;
       ProfScope _p("kernel.self_attention", st);
       TRY(launch_attention(sa, st));
+      if (m->ma_fold_vo) {   // fp32 mode: x += attention (the values carry out_proj)
+        float* xs = once ? x1 : x;
+        TRY(launch_add_bcast(xs, 256, a, 256, 0, 1.0f, xs, 256, Bs * TOK, 256, st));
+      }
     }
     if (once) {
-      TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
+      if (!m->ma_fold_vo) TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
       for (int b = 0; b < B; ++b)
         DS2_CHECK_HIP(hipMemcpyAsync(x + (size_t)b * TOK * 256, x1, (size_t)TOK * 256 * 4, hipMemcpyDeviceToDevice, st));
-    } else {
+    } else if (!m->ma_fold_vo) {
       TRY(linear(m, st, p + ".self_attn.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     }
     // -- cross attention to the memory bank.  V = v_proj(memory) is never materialised:
@@ -995,9 +1016,16 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       ProfScope _p("kernel.cross_attention", st);
       TRY(launch_attention(ca, st));
     }
-    TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr,
-               true));   // only consumer: out_proj GEMM
-    TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
+    // out_proj(v_proj(P M)) folded on the host into ONE 64 -> 256 projection (constants.py fold_out_v: exact in real
+    // arithmetic): x += (P M) (Wo Wv)^T + (Wo bv + bo) - one K = 64 GEMM instead of a K = 64 and a K = 256 one
+    if (m->ma_fold_vo) {
+      TRY(gemm(st, rows, 256, 64, a64, 64, m->P("#ma_cross_vo_w." + ls), 64, m->P("#ma_cross_vo_b." + ls), x, 256, DS2_ACT_NONE, x, 256,
+               0, nullptr, true, m));
+    } else {
+      TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr,
+                 true));   // only consumer: out_proj GEMM
+      TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
+    }
     // -- FFN
     TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr));

@@ -57,7 +57,7 @@ def test_gemm(ops, M, N, K, act, use_r, r_mod, use_g):
 
 
 @pytest.mark.parametrize("rows,H,act,use_r,use_g", [
-    (128, 64, 1, False, False),          # one row block, one chunk
+    (128, 128, 1, False, False),         # one row block, one chunk pair
     (300, 256, 0, True, False),          # ragged last row block (300 = 2 x 128 + 44)
     (1000, 1024, 2, True, True),         # CXBlock shape: GELU, layer scale, residual
     (40000, 2048, 1, True, False),       # memory-attention FFN shape, more row blocks than CUs (persistent loop)
