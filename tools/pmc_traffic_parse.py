@@ -1,34 +1,41 @@
-"""FETCH_SIZE / WRITE_SIZE (KB, rocprofv3 derived counters) of the cross-attention launches with the full bank ->
-JSON for bench.py.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide
-coalesced read stream (128-byte requests tallied at 64 B) => the read side is doubled; WRITE_SIZE is taken as is."""
+"""FETCH_SIZE / WRITE_SIZE (KB, rocprofv3 derived counters) of the bench's dominant kernels -> JSON for bench.py
+(`traffic_from_committed_pmc`).  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of
+a wide coalesced read stream (128-byte requests tallied at 64 B) => the read side is doubled; WRITE_SIZE is taken as is.
+Per kernel the launches of the steady state are the longest ones (full 7-frame bank / full 16-object batch)."""
 import json
 import sqlite3
 import sys
 
+B, NK, TOK = 16, 28736, 4096
+KERNELS = {   # key -> (name pattern, algorithmic bytes per launch)
+    # Q fp32 + K hi plane + V^T planes (lo only for the 64 pointer tokens) read once, output planes written once
+    "cross_attention": ("%k_attention_w8<64%", B * (4.0 * TOK * 256 + 2.0 * NK * 256 + 2.0 * NK * 64 + 2.0 * 64 * 64 + 4.0 * TOK * 64)),
+    # memory-attention FFN, fused: X planes in, residual in, result out (fp32) + the weights once
+    "k_mlp256": ("%k_mlp256<1>%", B * TOK * 256 * (4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
+}
 
-def per_dispatch(db, counter):
+
+def per_dispatch(db, counter, pattern):
     c = sqlite3.connect(db)
-    rows = c.execute("select dispatch_id, sum(value), max(duration) from counters_collection where kernel_name like "
-                     "'%k_attention_w8<64%' and counter_name = ? group by dispatch_id", (counter,)).fetchall()
-    return rows
+    return c.execute("select dispatch_id, sum(value), max(duration) from counters_collection where kernel_name like ? "
+                     "and counter_name = ? group by dispatch_id", (pattern, counter)).fetchall()
 
 
-f = per_dispatch(sys.argv[1], "FETCH_SIZE")
-w = per_dispatch(sys.argv[2], "WRITE_SIZE")
-
-
-def steady(rows):   # launches with the full 7-frame bank = the longest ones
+def steady(rows):
     dmax = max(r[2] for r in rows)
     sel = [r[1] for r in rows if r[2] >= 0.9 * dmax]
     return sum(sel) / len(sel), len(sel)
 
 
-fk, nf = steady(f)
-wk, nw = steady(w)
-out = {"kernel": "k_attention_w8<64,2,*> (memory cross-attention, Nk=28736, 16 objects; default arithmetic mode of the run)",
-       "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk, "launches_averaged": [nf, nw],
-       "read_correction": 2.0,
-       "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
-       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on "
-                 "`python bench.py --steps 4 --warmup 1 --no-cpu-baseline`; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024"}
-print(json.dumps(out))
+out = {"method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only, DS2_ASYNC_ENCODE=0) on "
+                 "`python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stream`; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+       "read_correction": 2.0}
+for key, (pat, alg) in KERNELS.items():
+    f, w = per_dispatch(sys.argv[1], "FETCH_SIZE", pat), per_dispatch(sys.argv[2], "WRITE_SIZE", pat)
+    if not f or not w:
+        continue
+    fk, nf = steady(f)
+    wk, nw = steady(w)
+    out[key] = {"kernel": pat.strip("%"), "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk,
+                "launches_averaged": [nf, nw], "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0, "algorithmic_bytes": alg}
+print(json.dumps(out, indent=1))
