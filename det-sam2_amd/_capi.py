@@ -75,7 +75,9 @@ TORCH_OPS = ("ingest_frames", "image_encoder", "bank_assemble", "memory_attentio
 
 _lib = None
 _ops = None
-TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libdetsam2_torch.so")
+# (an A/B build selected with DS2_LIB=<dir>/ab_X.so brings its own op library <dir>/ab_X_torch.so, linked against it:
+# tools/ab.py build)
+TORCH_LIB_PATH = (LIB_PATH[:-3] + "_torch.so") if os.environ.get("DS2_LIB") else os.path.join(os.path.dirname(LIB_PATH), "libdetsam2_torch.so")
 
 
 def load_torch_ops():

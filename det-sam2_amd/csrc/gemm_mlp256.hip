@@ -27,6 +27,12 @@
 #include "common.h"
 #include "kernels.h"
 
+// ablation builds for profiling only (tools/ab.py build NAME -DDS2_MLP_ABL=n; results are WRONG for n != 0):
+// 1 = no bias / activation (split only), 2 = no workgroup barrier per step, 3 = no prefetch DMA inside the loop
+#ifndef DS2_MLP_ABL
+#define DS2_MLP_ABL 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   }
   // prefetch issued at pair position PP: the tile MNS - 1 positions ahead (in this pair, or in the next one)
 #define MLP_PREFETCH(PP)                                                                                                  \
-  if constexpr ((PP) + MNS - 1 < MT_PAIR) MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, c2 + ((PP) + MNS - 1) / MT_PER_CHUNK, (PP) + MNS - 1) \
+  if constexpr (DS2_MLP_ABL == 3) {} else if constexpr ((PP) + MNS - 1 < MT_PAIR) MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, c2 + ((PP) + MNS - 1) / MT_PER_CHUNK, (PP) + MNS - 1) \
   else MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, cn2 + ((PP) + MNS - 1 - MT_PAIR) / MT_PER_CHUNK, (PP) + MNS - 1)
   // order of a step's instructions (one wave per SIMD: nobody else hides the LDS latency): the DMA issue first, then the
   // fragment pairs (hi, lo) in groups of two = 6 MFMAs.  Three register sets: groups g and g + 1 are resident, group g + 2
@@ -144,8 +150,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   // wave's fragment reads are retired, then everybody meets
 #define MLP_STEP_END(PP)                                                         \
   __builtin_amdgcn_sched_barrier(0);                                             \
-  wait_vm_lgkm<tile_dma((PP) + 2) + tile_dma((PP) + 3)>();                       \
-  __builtin_amdgcn_s_barrier();                                                  \
+  if constexpr (DS2_MLP_ABL == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
+  else wait_vm_lgkm<tile_dma((PP) + 2) + tile_dma((PP) + 3)>();                  \
+  if constexpr (DS2_MLP_ABL != 2) __builtin_amdgcn_s_barrier();                  \
   __builtin_amdgcn_sched_barrier(0);
 
   const int nrb = (a.rows + MBR - 1) / MBR;
@@ -239,7 +246,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
         float v[8];                                                                                                       \
         _Pragma("unroll") for (int gg = 0; gg < 2; ++gg)                                                                  \
           _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                   \
-            v[gg * 4 + e] = ds2_act(hid[hb][(2 * t + gg) * 4 + e] + bb[hb][2 * t + gg][e], ACT);                          \
+            v[gg * 4 + e] = DS2_MLP_ABL == 1 ? hid[hb][(2 * t + gg) * 4 + e]                                              \
+                                             : ds2_act(hid[hb][(2 * t + gg) * 4 + e] + bb[hb][2 * t + gg][e], ACT);       \
         uint4 h, l;                                                                                                       \
         h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);                                                     \
         h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);                                                     \

@@ -19,6 +19,7 @@ def build(name, flags):
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-o", out] + flags + [os.path.join(g.PKG, "csrc", s) for s in g.SOURCES]
     subprocess.run(cmd, check=True)
+    g._build_torch_ops(True, out, out[:-3] + "_torch.so")     # the op library of this variant, linked against it
     print(out)
 
 
