@@ -47,6 +47,8 @@ SIGNATURES = {
     "ds2_memory_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
     "ds2_connected_components": (C.c_int, [c_vp, i32, i32, i32, c_vp, c_vp, c_vp, c_vp]),
     "ds2_fill_holes": (C.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
+    "ds2_yolo_postprocess_work_bytes": (C.c_int64, [i32, i32]),
+    "ds2_yolo_postprocess": (C.c_int, [c_vp, i32, i32, i32, C.c_float, C.c_float, i32, c_vp, c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "ds2_image_encoder_f32": (C.c_int, [c_vp, c_vp, i32, c_vp, c_vp, c_vp, c_vp]),
     "ds2_memory_attention_ex": (C.c_int, [c_vp, i32, c_vp, i32, c_vp, i32, c_vp, c_vp, i32, i32, c_vp, c_vp]),
     "ds2_memory_encoder_ex": (C.c_int, [c_vp, i32, c_vp, i32, c_vp, i32, c_vp, c_vp]),
@@ -71,7 +73,7 @@ SIGNATURES = {
 # the PyTorch custom ops csrc/torch_ops.cpp registers (torch.ops.det_sam2.<name>)
 TORCH_OPS = ("ingest_frames", "image_encoder", "bank_assemble", "memory_attention", "sam_heads", "memory_encoder",
              "memory_encoder_module", "resize_aa", "mask_prompt_prepare", "obj_ptr_gate", "mask_output",
-             "get_connected_componnets", "fill_holes")
+             "get_connected_componnets", "fill_holes", "yolo_postprocess")
 
 _lib = None
 _ops = None

@@ -275,6 +275,27 @@ Tensor fill_holes(const Tensor& logits, int64_t max_area) {
   return out;
 }
 
+// F4 detector half: ultralytics ops.non_max_suppression + scale_boxes / clip_boxes on the raw YOLOv8 head output
+// pred fp32 [nb, 4+nc, N] -> (dets fp32 [nb, max_det, 6] = xyxy, conf, cls; counts int32 [nb], -1 = candidate overflow)
+std::tuple<Tensor, Tensor> yolo_postprocess(const Tensor& pred, double conf_thres, double iou_thres, int64_t max_det,
+                                            const c10::optional<Tensor>& scale5) {
+  want(pred, at::kFloat, "pred");
+  TORCH_CHECK(pred.dim() == 3 && pred.size(1) > 4, "det_sam2::yolo_postprocess: pred must be [nb, 4+nc, N]");
+  if (scale5.has_value()) {
+    want(*scale5, at::kFloat, "scale5");
+    TORCH_CHECK(scale5->numel() == 5, "det_sam2::yolo_postprocess: scale5 = gain, pad_x, pad_y, orig_w, orig_h");
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA g(pred.device());
+  const int64_t nb = pred.size(0), nc = pred.size(1) - 4, N = pred.size(2);
+  const int64_t wb = ds2_yolo_postprocess_work_bytes((int32_t)nb, (int32_t)N);
+  Tensor work = at::empty({wb}, pred.options().dtype(at::kByte));
+  Tensor dets = at::zeros({nb, max_det, 6}, pred.options()), counts = at::empty({nb}, pred.options().dtype(at::kInt));
+  check(ds2_yolo_postprocess(pred.data_ptr<float>(), (int32_t)nb, (int32_t)nc, (int32_t)N, (float)conf_thres, (float)iou_thres,
+                             (int32_t)max_det, fptr(scale5), dets.data_ptr<float>(), counts.data_ptr<int32_t>(), work.data_ptr(), wb,
+                             stream_of(pred)), "yolo_postprocess");
+  return {dets, counts};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(det_sam2, m) {
@@ -292,6 +313,7 @@ TORCH_LIBRARY(det_sam2, m) {
   m.def("mask_output(int model, Tensor low_res, int Hv, int Wv, bool want_logits, bool want_packed) -> (Tensor, Tensor)");
   m.def("get_connected_componnets(Tensor inputs) -> Tensor[]");
   m.def("fill_holes(Tensor logits, int max_area) -> Tensor");
+  m.def("yolo_postprocess(Tensor pred, float conf_thres, float iou_thres, int max_det, Tensor? scale5) -> (Tensor, Tensor)");
 }
 
 // GPU tensors on PyTorch-ROCm dispatch under the CUDA key (HIP masquerades as CUDA); a CPU tensor finds no kernel and the
@@ -310,4 +332,5 @@ TORCH_LIBRARY_IMPL(det_sam2, CUDA, m) {
   m.impl("mask_output", &mask_output);
   m.impl("get_connected_componnets", &get_connected_componnets);
   m.impl("fill_holes", &fill_holes);
+  m.impl("yolo_postprocess", &yolo_postprocess);
 }

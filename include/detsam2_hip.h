@@ -146,6 +146,18 @@ int ds2_connected_components(const uint8_t* mask, int32_t N, int32_t H, int32_t 
  * work: int32 scratch of 3*N*H*W elements.  max_area <= 0 is an error (misc.py:371). */
 int ds2_fill_holes(float* logits, int32_t N, int32_t H, int32_t W, int32_t max_area, int32_t* work, void* stream);
 
+/* ---- F4, detector half: what ultralytics 8.2.82 does between the YOLOv8 head and `result.boxes`, which
+ * VideoProcessor.detect_predict reads (det_sam2_RT.py:228-244): ops.non_max_suppression (best class per anchor, conf
+ * threshold, xywh -> xyxy, per-class offset 7680, torchvision-style greedy NMS with IoU > iou_thres suppressing, max_det)
+ * + scale_boxes / clip_boxes.  pred fp32 [nb, 4+nc, N] (device) -> dets fp32 [nb, max_det, 6] = x1, y1, x2, y2, conf, cls
+ * in confidence order (ties: ascending anchor) and counts int32 [nb] (-1: more than 8192 anchors over the threshold).
+ * scale5 (device, may be NULL) = gain, pad_x, pad_y, orig_w, orig_h of the letterbox to undo.  work: device scratch of
+ * ds2_yolo_postprocess_work_bytes(nb, N) bytes.  Third-party algorithm, absent offline: parity unpinned (oracle/yolo_post.py). */
+int64_t ds2_yolo_postprocess_work_bytes(int32_t nb, int32_t N);
+int ds2_yolo_postprocess(const float* pred, int32_t nb, int32_t nc, int32_t N, float conf_thres, float iou_thres,
+                         int32_t max_det, const float* scale5, float* dets, int32_t* counts, void* work, int64_t work_bytes,
+                         void* stream);
+
 /* ---- module-level forms (det_sam2_amd/modules.py: nn.Modules with the reference's signatures).  Same
  * kernels as the stage entry points above, without the tracking loop's sharing assumptions:
  *  ds2_image_encoder_f32: forward_image on fp32 frames [n,3,S,S] (the reference feeds `.float()`-ed frames,
