@@ -40,11 +40,22 @@ def iou_f32(a, b):
 
 
 def nms_greedy(boxes, order, iou_thres):
-    """Greedy NMS over `boxes` visited in `order`: a box is dropped if its IoU with an earlier KEPT box is > iou_thres."""
+    """Greedy NMS over `boxes` visited in `order`: a box is dropped if its IoU with an earlier KEPT box is > iou_thres.
+    (iou_f32 applied to all kept boxes at once: the same fp32 operations element by element.)"""
+    boxes = np.asarray(boxes, F32)
+    area = ((boxes[:, 2] - boxes[:, 0]).astype(F32) * (boxes[:, 3] - boxes[:, 1]).astype(F32)).astype(F32)
     keep = []
     for i in order:
-        if all(not (iou_f32(boxes[i], boxes[k]) > F32(iou_thres)) for k in keep):
-            keep.append(int(i))
+        if keep:
+            k = boxes[keep]
+            w = np.maximum((np.minimum(boxes[i, 2], k[:, 2]) - np.maximum(boxes[i, 0], k[:, 0])).astype(F32), F32(0))
+            h = np.maximum((np.minimum(boxes[i, 3], k[:, 3]) - np.maximum(boxes[i, 1], k[:, 1])).astype(F32), F32(0))
+            inter = (w * h).astype(F32)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                iou = (inter / ((area[i] + area[keep]).astype(F32) - inter).astype(F32)).astype(F32)
+            if (iou > F32(iou_thres)).any():
+                continue
+        keep.append(int(i))
     return keep
 
 

@@ -10,10 +10,15 @@ from oracle import yolo_post as Y
 pytestmark = pytest.mark.gpu
 
 
-def _random_pred(rng, nb, nc, N, quant=None):
+def _random_pred(rng, nb, nc, N, quant=None, hot=1500):
+    """Background scores < 0.05 everywhere; `hot` random anchors per image carry one confident class (so that the
+    candidate set stays in the low thousands - the oracle's NMS is a Python loop)."""
     xy = rng.uniform(0, 640, (nb, 2, N))
     wh = rng.uniform(8, 200, (nb, 2, N))
-    sc = rng.uniform(0, 1, (nb, nc, N)) ** 4
+    sc = rng.uniform(0, 0.05, (nb, nc, N))
+    for b in range(nb):
+        a = rng.choice(N, size=min(hot, N), replace=False)
+        sc[b, rng.integers(0, nc, a.size), a] = rng.uniform(0.1, 1.0, a.size)
     if quant:                                   # exact ties between confidences
         sc = np.round(sc * quant) / quant
     return np.concatenate([xy, wh, sc], 1).astype(np.float32)
@@ -55,6 +60,6 @@ def test_python_wrapper_emits_the_detection_contract_and_flags_overflow():
         assert d["coordinates"].dtype == np.float32 and d["coordinates"].shape == (4,) and d["class"].shape == (1,)
         assert np.array_equal(d["coordinates"], r[:4]) and d["class"][0] == r[5] and d["confidence"][0] == r[4]
     with pytest.raises(RuntimeError, match="8192"):                  # every anchor over the threshold: more than the NMS stage holds
-        yolo_postprocess(torch.from_numpy(_random_pred(rng, 1, 1, 20000)).to("cuda:0") + 10.0, 0.0)
+        yolo_postprocess(torch.from_numpy(_random_pred(rng, 1, 1, 20000, hot=10)).to("cuda:0") + 10.0, 0.0)
     with pytest.raises(RuntimeError, match="GPU"):
         yolo_postprocess(pred.cpu(), 0.5)
