@@ -36,6 +36,7 @@ SIGNATURES = {
     "ds2_model_destroy": (None, [c_vp]),
     "ds2_model_set_param": (C.c_int, [c_vp, C.c_char_p, c_vp, C.c_int64]),
     "ds2_model_finalize": (C.c_int, [c_vp, c_vp]),
+    "ds2_model_create_view": (C.c_int, [c_vp, C.POINTER(c_vp)]),
     "ds2_ingest_frames": (C.c_int, [c_vp, c_vp, i32, i32, i32, c_vp, c_vp]),
     "ds2_image_encoder": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ds2_image_encoder_batch": (C.c_int, [c_vp, c_vp, i32, c_vp, c_vp, c_vp, c_vp]),

@@ -108,8 +108,14 @@ constexpr int TOK = 4096;  // 64x64 tokens at stride 16
 // ops (ds2_op_gemm), which have no model, use one process-wide context.
 struct GemmPlanes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
 struct GemmCtx {
-  std::unordered_map<const float*, GemmPlanes> wcache;
-  std::unordered_map<const float*, GemmPlanes> w2perm;   // fused MLP: second-layer weights, hidden index permuted (gemm_mlp256.hip)
+  typedef std::unordered_map<const float*, GemmPlanes> PlaneMap;
+  PlaneMap own_wcache, own_w2perm;
+  GemmCtx* share = nullptr;   // a VIEW model (ds2_model_create_view) uses its parent's weight planes; the scratch is its own
+  PlaneMap& wc() { return share ? share->own_wcache : own_wcache; }        // weights split into planes (once)
+  PlaneMap& w2p() { return share ? share->own_w2perm : own_w2perm; }      // fused MLP: W2 with the hidden index permuted
+  // a weight's planes may be consumed on another stream than the one that split it (view models): the creating call waits
+  // for its split kernels once (first use only)
+  int publish(hipStream_t st) { DS2_CHECK_HIP(hipStreamSynchronize(st)); return DS2_OK; }
   char* scratch = nullptr;
   size_t scratch_cap = 0;
   int require(size_t bytes, hipStream_t st) {
@@ -123,10 +129,10 @@ struct GemmCtx {
     return DS2_OK;
   }
   void release() {
-    for (auto& kv : wcache) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
-    wcache.clear();
-    for (auto& kv : w2perm) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
-    w2perm.clear();
+    for (auto& kv : own_wcache) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    own_wcache.clear();
+    for (auto& kv : own_w2perm) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+    own_w2perm.clear();
     if (scratch) (void)hipFree(scratch);
     scratch = nullptr; scratch_cap = 0;
   }
@@ -159,6 +165,7 @@ struct ds2_model {
   int device = 0;              // the device that was current at ds2_model_create
   int precision = DS2_PREC_BF16X3K;   // arithmetic mode of this model's stages (ds2_model_set_precision)
   bool ma_fold_vo = false;            // memory attention: out_proj folded into the value projections (set at finalize)
+  ds2_model* parent = nullptr;        // VIEW of another model (ds2_model_create_view): its parameters and weight planes, own workspace
   GemmCtx gctx;
   std::vector<BlockCfg> blocks;
   std::vector<int> stage_ends;
@@ -179,6 +186,11 @@ struct ds2_model {
   }
 
   const float* P(const std::string& name) {
+    if (parent) {
+      const float* p = parent->P(name);
+      if (!p && missing.empty()) missing = name;
+      return p;
+    }
     auto it = params.find(name);
     if (it == params.end()) {
       if (missing.empty()) missing = name;
@@ -187,6 +199,7 @@ struct ds2_model {
     return reinterpret_cast<const float*>(it->second.ptr);
   }
   size_t Pbytes(const std::string& name) {
+    if (parent) return parent->Pbytes(name);
     auto it = params.find(name);
     return it == params.end() ? 0 : it->second.bytes;
   }
@@ -212,6 +225,7 @@ struct ds2_model {
     return DS2_OK;
   }
   int add_derived(const std::string& name, size_t n_floats, float** out) {
+    if (parent) return parent->add_derived(name, n_floats, out);
     Blob b;
     b.bytes = n_floats * sizeof(float);
     DS2_CHECK_HIP(hipMalloc(&b.ptr, b.bytes));
@@ -310,8 +324,8 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   const size_t a_bytes = ahi ? 0 : (size_t)M * Kp * 2;
   GemmCtx& ctx = m ? m->gctx : g_gemm_ctx;
   GemmPlanes wp;
-  auto it = w_static ? ctx.wcache.find(W) : ctx.wcache.end();
-  if (it != ctx.wcache.end()) {
+  auto it = w_static ? ctx.wc().find(W) : ctx.wc().end();
+  if (it != ctx.wc().end()) {
     wp = it->second;
     TRY(ctx.require(2 * a_bytes + 512, st));
   } else if (w_static) {
@@ -319,7 +333,8 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), w_bytes));
     wp.ld = Kp;
     TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
-    ctx.wcache[W] = wp;
+    TRY(ctx.publish(st));
+    ctx.wc()[W] = wp;
     TRY(ctx.require(2 * a_bytes + 512, st));
   } else {
     TRY(ctx.require(2 * a_bytes + 2 * w_bytes + 1024, st));
@@ -358,15 +373,16 @@ static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int
 }
 // weight planes of a static weight [N, K] (split once, cached)
 static int weight_planes(GemmCtx& ctx, const float* W, int N, int K, GemmPlanes* out, hipStream_t st) {
-  auto it = ctx.wcache.find(W);
-  if (it != ctx.wcache.end()) { *out = it->second; return DS2_OK; }
+  auto it = ctx.wc().find(W);
+  if (it != ctx.wc().end()) { *out = it->second; return DS2_OK; }
   const int Kp = round32i(K);
   GemmPlanes wp;
   DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.hi), (size_t)N * Kp * 2));
   DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), (size_t)N * Kp * 2));
   wp.ld = Kp;
   TRY(launch_split_rows(W, K, N, K, wp.hi, wp.lo, Kp, st));
-  ctx.wcache[W] = wp;
+  TRY(ctx.publish(st));
+  ctx.wc()[W] = wp;
   *out = wp;
   return DS2_OK;
 }
@@ -390,8 +406,8 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
   if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_mlp256 %d %d %d", rows, 256, 2 * H);   // (2*M*N*K with K = 2H: both layers)
   GemmPlanes w1p, w2p;
   TRY(weight_planes(ctx, W1, H, 256, &w1p, st));
-  auto it = ctx.w2perm.find(W2);
-  if (it != ctx.w2perm.end()) {
+  auto it = ctx.w2p().find(W2);
+  if (it != ctx.w2p().end()) {
     w2p = it->second;
   } else {   // once per weight: permute the hidden index inside groups of 16, then split
     float* tmp = nullptr;
@@ -403,7 +419,7 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     TRY(launch_split_rows(tmp, H, 256, H, w2p.hi, w2p.lo, H, st));
     DS2_CHECK_HIP(hipStreamSynchronize(st));
     DS2_CHECK_HIP(hipFree(tmp));
-    ctx.w2perm[W2] = w2p;
+    ctx.w2p()[W2] = w2p;
   }
   const unsigned short *xh = nullptr, *xl = nullptr;
   if (m) {
@@ -481,6 +497,25 @@ extern "C" int ds2_model_create(const ds2_config* cfg, ds2_model** out) {
   return DS2_OK;
 }
 
+// A second execution context over the SAME weights: its own workspace arena, activation-plane table, GEMM scratch and
+// arithmetic mode; parameters, derived constants and the bf16 planes of the weights are the parent's (which must outlive
+// it).  For running one stage (e.g. the image encoder of the NEXT frames) on another stream concurrently with the parent.
+extern "C" int ds2_model_create_view(ds2_model* parent, ds2_model** out) {
+  DS2_REQUIRE(parent && out && parent->finalized && !parent->parent, "ds2_model_create_view: needs a finalized, non-view model");
+  ds2_model* m = new ds2_model();
+  m->cfg = parent->cfg;
+  m->device = parent->device;
+  m->precision = parent->precision;
+  m->blocks = parent->blocks;
+  m->stage_ends = parent->stage_ends;
+  m->ma_fold_vo = parent->ma_fold_vo;
+  m->parent = parent;
+  m->gctx.share = &parent->gctx;
+  m->finalized = true;
+  *out = m;
+  return DS2_OK;
+}
+
 extern "C" void ds2_model_destroy(ds2_model* m) {
   if (!m) return;
   ModelScope _dg(m);
@@ -503,7 +538,7 @@ extern "C" int ds2_model_get_precision(const ds2_model* m) { return m ? m->preci
 extern "C" int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_t nbytes) {
   DS2_REQUIRE(m && name && data && nbytes > 0, "ds2_model_set_param: bad argument");
   ModelScope _dg(m);
-  DS2_REQUIRE(!m->finalized, "ds2_model_set_param: model already finalized");
+  DS2_REQUIRE(!m->finalized && !m->parent, "ds2_model_set_param: model already finalized (or a view)");
   Blob b;
   b.bytes = (size_t)nbytes;
   DS2_CHECK_HIP(hipMalloc(&b.ptr, b.bytes));

@@ -153,6 +153,19 @@ class HipSam2(HipOps):
         _capi.check(self.lib.ds2_model_finalize(self.h, self._stream()), "ds2_model_finalize")
         self.no_obj_ptr = torch.from_numpy(sd_np["no_obj_ptr"]).to(self.device)           # [1,256]
 
+    @classmethod
+    def view_of(cls, parent: "HipSam2") -> "HipSam2":
+        """A second execution context over ``parent``'s weights (ds2_model_create_view): no parameter copies, no second set
+        of weight planes - its own workspace arena only.  Keeps ``parent`` alive."""
+        self = cls.__new__(cls)
+        HipOps.__init__(self, parent.device)
+        self.cfg, self._parent = parent.cfg, parent
+        h = C.c_void_p()
+        _capi.check(self.lib.ds2_model_create_view(parent.h, C.byref(h)), "ds2_model_create_view")
+        self.h = h
+        self.no_obj_ptr = parent.no_obj_ptr
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "h", None):

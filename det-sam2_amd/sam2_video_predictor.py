@@ -49,14 +49,13 @@ class SAM2VideoPredictor:
         # Upper bound 16 (the C-ABI's limit); the actual batch splits the frames still to encode evenly (20 -> 10 + 10,
         # 30 -> 15 + 15): at 16 frames every Hiera stage-3 GEMM of hiera_l is a whole number of 256-CU rounds.
         self.encode_batch = int(os.environ.get("DS2_ENCODE_BATCH", "16"))
-        # The next encoder batch is launched AHEAD of need on a second HIP stream, through a second ds2_model (same weights,
-        # its own workspace arena), so that its large GEMMs fill the CUs the small kernels of the tracking chain (SAM
+        # The next encoder batch is launched AHEAD of need on a second HIP stream, through a VIEW of the model (the same weights,
+        # its own workspace arena: ds2_model_create_view), so that its large GEMMs fill the CUs the small kernels of the tracking chain (SAM
         # heads, memory encoder) leave idle: +4.5 % frames/s at hiera_l / 16 objects.  Same kernels, same results.
         # Overlapped kernels share CUs, so every per-kernel duration (and the bench's roofline fraction) reads ~5 %
         # worse than in isolation; DS2_ASYNC_ENCODE=0 switches it off.
         self.async_encode = hip is None and os.environ.get("DS2_ASYNC_ENCODE", "1") not in ("", "0")
         self.async_lookahead = int(os.environ.get("DS2_ASYNC_LOOKAHEAD", "12"))
-        self._sd_for_enc = state_dict if self.async_encode else None
         self._hip_enc, self._enc_stream = None, None
 
     # ------------------------------------------------------------------ frame ingest (A3)
@@ -238,8 +237,8 @@ class SAM2VideoPredictor:
         n_batches = -(-len(missing) // self.encode_batch)
         todo = missing[: -(-len(missing) // n_batches)]
         if self._hip_enc is None:
-            # a second ds2_model: same weights (+0.9 GB fp32 and +0.9 GB of bf16 planes at hiera_l), its own workspace arena
-            self._hip_enc = HipSam2(self.cfg, self._sd_for_enc, self.device, 16)
+            # a VIEW of the model: the same weights and weight planes (no copies), its own workspace arena
+            self._hip_enc = HipSam2.view_of(self.hip)
             self._enc_stream = torch.cuda.Stream(device=self.device)
         if self._hip_enc.get_precision() != self.hip.get_precision():     # the mode is per model: keep the twin in step
             self._hip_enc.set_precision(self.hip.get_precision())

@@ -68,6 +68,11 @@ int ds2_model_create(const ds2_config* cfg, ds2_model** out);
 void ds2_model_destroy(ds2_model* m);
 int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_t nbytes);
 int ds2_model_finalize(ds2_model* m, void* stream);
+/* A second execution context over the SAME weights (parameters, derived constants, bf16 weight planes are the parent's, which
+ * must outlive the view); own workspace arena, GEMM scratch and arithmetic mode.  For running a stage on another stream
+ * concurrently with the parent (the predictor encodes the next frames ahead of need this way).  Destroy with
+ * ds2_model_destroy. */
+int ds2_model_create_view(ds2_model* parent, ds2_model** out);
 
 /* ---- A3: frame ingest.  load_video_frames, list-of-ndarray branch (sam2/utils/misc.py:280-284,
  * 328-342, 358-359): rgb_u8 [n,height,width,3] -> cv2.resize to S x S (8-bit INTER_LINEAR, OpenCV's fixed-point

@@ -272,3 +272,33 @@ def test_mask_output():
         mism = float((bits != (logits.cpu().numpy()[:, 0] > 0)).mean())
         record("mask_output", hv=hv, wv=wv, err=e, mism=mism)
         assert e < 1e-5 and mism == 0.0, (e, mism)
+
+
+def test_model_view_shares_weights_and_gives_identical_results():
+    """ds2_model_create_view (the async encoder's execution context): no parameter copies, own workspace; the image encoder
+    through the view - also on a side stream, concurrently with work on the parent - is bit-identical to the parent's."""
+    from det_sam2_amd.hip_model import HipSam2
+    from det_sam2_amd.synth import synthetic_frame
+    cfg = resolve_config(TINY)
+    hm = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=2)
+    frames = hm.ingest(torch.from_numpy(np.stack([synthetic_frame(t) for t in range(3)])).to(hm.device))
+    view = HipSam2.view_of(hm)
+    assert view.get_precision() == hm.get_precision()
+    ref = hm.image_encoder_batch(frames)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = view.image_encoder_batch(frames)
+    again = hm.image_encoder_batch(frames)              # the parent keeps working on its own stream meanwhile
+    torch.cuda.synchronize()
+    for a, b, c in zip(ref, got, again):
+        for x, y, z in zip(a, b, c):
+            assert torch.equal(x, y) and torch.equal(x, z)
+    view.set_precision("fp32")
+    assert hm.get_precision() != "fp32"                  # the arithmetic mode is per context
+    with pytest.raises(Exception, match="view"):         # parameters belong to the parent
+        from det_sam2_amd import _capi
+        import ctypes as C
+        a = np.zeros(4, np.float32)
+        _capi.check(view.lib.ds2_model_set_param(view.h, b"x", a.ctypes.data_as(C.c_void_p), a.nbytes), "ds2_model_set_param")
