@@ -279,8 +279,8 @@ def test_model_view_shares_weights_and_gives_identical_results():
     through the view - also on a side stream, concurrently with work on the parent - is bit-identical to the parent's."""
     from det_sam2_amd.hip_model import HipSam2
     from det_sam2_amd.synth import synthetic_frame
-    cfg = resolve_config(TINY)
-    hm = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=2)
+    cfg = resolve_config("sam2.1_hiera_t")
+    hm = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=4)
     frames = hm.ingest(torch.from_numpy(np.stack([synthetic_frame(t) for t in range(3)])).to(hm.device))
     view = HipSam2.view_of(hm)
     assert view.get_precision() == hm.get_precision()
