@@ -47,6 +47,38 @@ __device__ __forceinline__ void split8(float v0, float v1, float v2, float v3, f
   p0 = __builtin_bit_cast(bf16x8, h);
   p1 = __builtin_bit_cast(bf16x8, l);
 }
+// Eight fp32 -> one bf16x8 fragment (round to nearest even: four v_cvt_pk_bf16_f32, the instruction split8 issues for its hi
+// plane).  Written as a vector conversion, not inline assembly, so that the instruction scheduler can classify and place it.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  const bf16x2 a = __builtin_convertvector((f32x2{v0, v1}), bf16x2), b = __builtin_convertvector((f32x2{v2, v3}), bf16x2);
+  const bf16x2 c = __builtin_convertvector((f32x2{v4, v5}), bf16x2), d = __builtin_convertvector((f32x2{v6, v7}), bf16x2);
+  return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+}
+// DS2_ATTN_ILV (bf16x3k instantiations): the softmax of tile t is interleaved instruction by instruction with the score MFMAs
+// of tile t+1 (sched_group_barrier pipeline).  Left to itself hipcc issues the 32 MFMAs back to back and then ~85 VALU
+// instructions in a row with the matrix pipe idle; both waves of a SIMD do that in step because of the per-tile barrier.
+#ifndef DS2_ATTN_ILV
+#define DS2_ATTN_ILV 1
+#endif
+#ifndef DS2_ATTN_PRIO
+#define DS2_ATTN_PRIO 0
+#endif
+#ifndef DS2_ATTN_ILV_VALU
+#define DS2_ATTN_ILV_VALU 2
+#endif
+constexpr int ILV_VALU = DS2_ATTN_ILV_VALU;
+// timing ablations (tools/ab.py build x -DDS2_ABL=n; WRONG results): 1 no softmax arithmetic, 2 one K fragment pair per tile,
+// 4 no global loads / LDS staging, 8 no per-tile barrier
+#ifndef DS2_ABL
+#define DS2_ABL 0
+#endif
+#if DS2_ABL & 16   // 16: a multiply-add in place of every exponential; 32: p = 2^-6 * score (bounded stand-in for ablation 1)
+#define W8_EXP2(x) __builtin_fmaf((x), 0.001f, 0.5f)
+#else
+#define W8_EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
 // max over lanes {l, l ^ 16} resp. {l, l ^ 32} with gfx950's row / half swaps: v_permlane16_swap exchanges the odd 16-lane
 // rows of its first operand with the even rows of its second, so with both operands = x one result holds the partner's
 // value in the even rows and the other in the odd rows - their maximum is the pair maximum in every lane.
@@ -143,6 +175,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   // ahead of V for this; two score register sets).  (Tried before and left out: running waves 4-7 half a tile behind waves
   // 0-3 with three V buffers - bit-identical but 4 % slower, profiles/r02an_ab_stag.txt.)
   constexpr int NVB = 2, VPL = (DV == 256 && !KLO) ? 1 : 2;
+  // (DV = 256, the self-attention, keeps the compiler's own order: with 64 accumulator registers on top the interleaved
+  // schedule spills the staged K rows to scratch inside the loop - measured 1.39 -> 1.89 ms/frame)
+  constexpr bool ILV = DS2_ATTN_ILV && !KLO && DV == 64;
   __shared__ __attribute__((aligned(16))) unsigned char Kp[2][KLO ? 2 : 1][KPLANE];
   __shared__ __attribute__((aligned(16))) unsigned char Vp[NVB][VPL][VPLANE];
 
@@ -211,17 +246,26 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   // V^T tile = 2 planes x DV rows x 4 uint4 = 8*DV uint4; thread loads uint4 #(tid + 512 j), j < DV/64
   const size_t kbase = (size_t)b * a.Lk;
   const uint4* vbase = a.vt + (size_t)b * nkt * (8 * DV);
+  const char* kbytes = reinterpret_cast<const char*>(a.k_hi + kbase * 32);
   const int kso0 = krow * KROWB + kpart * 16, kso1 = (krow + 16) * KROWB + kpart * 16;
 
   uint4 rk0, rk1, rk2, rk3, rv[NVLD];
+  // ILV: block-uniform base + 32-bit lane offset (one v_min and one shift-add per row instead of 64-bit index arithmetic),
+  // and no divergent branch around the V loads - for tiles without a lo plane threads >= 256 re-read the hi plane (the lines
+  // their neighbours fetch) into the unused lo slot, so the whole step stays straight-line code for the scheduler
 #define W8_LOAD_K(KT)                                                         \
   {                                                                           \
     const int kt_ = (KT);                                                     \
     int k0_ = kt_ * BKEYS + krow, k1_ = k0_ + 16;                             \
     k0_ = k0_ < a.Lk ? k0_ : a.Lk - 1;                                        \
     k1_ = k1_ < a.Lk ? k1_ : a.Lk - 1;                                        \
-    rk0 = a.k_hi[(kbase + k0_) * 32 + kpart];                                 \
-    rk1 = a.k_hi[(kbase + k1_) * 32 + kpart];                                 \
+    if constexpr (ILV) {                                                      \
+      rk0 = *reinterpret_cast<const uint4*>(kbytes + (unsigned)(k0_ * 512 + kpart * 16)); \
+      rk1 = *reinterpret_cast<const uint4*>(kbytes + (unsigned)(k1_ * 512 + kpart * 16)); \
+    } else {                                                                  \
+      rk0 = a.k_hi[(kbase + k0_) * 32 + kpart];                               \
+      rk1 = a.k_hi[(kbase + k1_) * 32 + kpart];                               \
+    }                                                                         \
     if (KLO) {                                                                \
       rk2 = a.k_lo[(kbase + k0_) * 32 + kpart];                               \
       rk3 = a.k_lo[(kbase + k1_) * 32 + kpart];                               \
@@ -230,9 +274,14 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #define W8_LOAD_V(KT)                                                         \
   {                                                                           \
     const int kt_ = (KT);                                                     \
-    _Pragma("unroll") for (int j = 0; j < NVLD; ++j)                          \
-      if ((DV != 64 || kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) /* DV=64: threads >= 256 stage the lo plane; DV=256 in bf16x3k: no lo plane */ \
-        rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j]; \
+    if constexpr (ILV && DV == 64) {                                          \
+      const unsigned u_ = (kt_ >= n_hi || tid < 256) ? tid : tid - 256;       \
+      rv[0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vbase + (size_t)kt_ * (8 * DV)) + u_ * 16u); \
+    } else {                                                                  \
+      _Pragma("unroll") for (int j = 0; j < NVLD; ++j)                        \
+        if ((DV != 64 || kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) /* DV=64: threads >= 256 stage the lo plane; DV=256 in bf16x3k: no lo plane */ \
+          rv[j] = vbase[(size_t)kt_ * (8 * DV) + tid + 512 * j];              \
+    }                                                                         \
   }
 #define W8_STORE_K(BUF)                                                       \
   {                                                                           \
@@ -249,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     _Pragma("unroll") for (int j = 0; j < NVLD; ++j) {                        \
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
-      if ((DV != 64 || st_kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) \
+      if (((ILV && DV == 64) || DV != 64 || st_kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) \
         *reinterpret_cast<uint4*>(&Vp[VBUF][pl_ < VPL ? pl_ : 0][rw_ * VROWB + pt_ * 16]) = rv[j]; \
     }                                                                         \
   }
@@ -264,8 +313,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     const unsigned char* kp1 = &Kp[kb][KLO ? 1 : 0][l15 * KROWB + grp * 16];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + ks * 64);
-      const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + ks * 64);
+      const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + ((DS2_ABL & 2) ? 0 : ks * 64));
+      const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + ((DS2_ABL & 2) ? 0 : ks * 64));
       if constexpr (KLO) {
         const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + ks * 64);
         const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
@@ -298,37 +347,83 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }
   };
   // ---- online softmax of the scores in s0 / s1, then O^T += V^T P^T with tile kt_ in V buffer vb
-  auto softmax_pv = [&](int vb, int kt_, f32x4 (&s0)[QG], f32x4 (&s1)[QG]) {
+  // lo_tag: std::false_type = the caller guarantees kt_ < n_hi (no V lo plane; no test, no branch in the step)
+  auto softmax_pv = [&](auto lo_tag, int vb, int kt_, f32x4 (&s0)[QG], f32x4 (&s1)[QG]) {
+    constexpr bool MAYLO = decltype(lo_tag)::value;
     bf16x8 pb0[QG], pb1[QG];
     float alpha[QG];
+    [[maybe_unused]] bf16x8 vh[NT <= 4 ? NT : 1];
+    if constexpr (ILV && NT <= 4) {   // the V^T fragments of this tile are in LDS since the last barrier: read them under the scores
+#pragma unroll
+      for (int t = 0; t < NT; ++t) vh[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
+    }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
+#if DS2_ABL & 1
+      alpha[g] = 1.f;
+      l_run[g] += s0[g][0];
+      pb0[g] = pack8(s0[g][0] * 0.015625f, s0[g][1] * 0.015625f, s0[g][2] * 0.015625f, s0[g][3] * 0.015625f, s1[g][0] * 0.015625f,
+                     s1[g][1] * 0.015625f, s1[g][2] * 0.015625f, s1[g][3] * 0.015625f);
+      continue;
+#endif
       float tmax = fmaxf(fmaxf(fmaxf(s0[g][0], s0[g][1]), fmaxf(s0[g][2], s0[g][3])),
                          fmaxf(fmaxf(s1[g][0], s1[g][1]), fmaxf(s1[g][2], s1[g][3])));
       tmax = xmax16(tmax);   // the four lane groups of a query column: VALU lane swaps, not two LDS round trips (ds_bpermute)
       tmax = xmax32(tmax);
       const float m_new = fmaxf(m_run[g], tmax);
       alpha[g] = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-      const float p0 = __builtin_amdgcn_exp2f(s0[g][0] - m_new), p1 = __builtin_amdgcn_exp2f(s0[g][1] - m_new), p2 = __builtin_amdgcn_exp2f(s0[g][2] - m_new), p3 = __builtin_amdgcn_exp2f(s0[g][3] - m_new);
-      const float p4 = __builtin_amdgcn_exp2f(s1[g][0] - m_new), p5 = __builtin_amdgcn_exp2f(s1[g][1] - m_new), p6 = __builtin_amdgcn_exp2f(s1[g][2] - m_new), p7 = __builtin_amdgcn_exp2f(s1[g][3] - m_new);
+      const float p0 = W8_EXP2(s0[g][0] - m_new), p1 = W8_EXP2(s0[g][1] - m_new), p2 = W8_EXP2(s0[g][2] - m_new), p3 = W8_EXP2(s0[g][3] - m_new);
+      const float p4 = W8_EXP2(s1[g][0] - m_new), p5 = W8_EXP2(s1[g][1] - m_new), p6 = W8_EXP2(s1[g][2] - m_new), p7 = W8_EXP2(s1[g][3] - m_new);
       l_run[g] = l_run[g] * alpha[g] + (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)));
       m_run[g] = m_new;
-      split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0[g], pb1[g]);
+      if constexpr (KLO) split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0[g], pb1[g]);
+      else pb0[g] = pack8(p0, p1, p2, p3, p4, p5, p6, p7);
+    }
+    if constexpr (ILV) {
+      // (an empty volatile statement that consumes P: keeps the exponentials in THIS basic block - they are only used after
+      // the rescale branch below and would otherwise be sunk past it, out of the shadow of the score MFMAs)
+#pragma unroll
+      for (int g = 0; g < QG; ++g) asm volatile("" ::"v"(pb0[g]), "v"(l_run[g]));
+      // Issue order of this basic block (scores of tile t+1 + softmax of tile t, independent of each other): the first K
+      // fragments, then per score MFMA three VALU / transcendental instructions and, after every QG-th MFMA, the next fragment
+      // read.  An MFMA occupies the matrix pipe for 4 issue slots, so the VALU work rides in its shadow.
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * KS * QG; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x402, ILV_VALU, 0);
+        if (i % QG == QG - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
     }
     // One 32-key MFMA k-step per 16-row dv block (each V^T fragment serves QG groups).  The running-max rescale is
     // skipped when no lane of the wave raised its maximum (alpha == 1 exactly; after the first ~100 key tiles that is the
     // common case), and the product terms are issued term-major so that consecutive MFMAs never target the same accumulator.
+    if constexpr (ILV) {   // one test for all query groups of the wave
+      bool ch = false;
 #pragma unroll
-    for (int g = 0; g < QG; ++g)
-      if (__any(alpha[g] != 1.f)) {
+      for (int g = 0; g < QG; ++g) ch |= alpha[g] != 1.f;
+      if (__any(ch)) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) o[g][t] *= alpha[g];
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) o[g][t] *= alpha[g];
       }
+    } else {
+#pragma unroll
+      for (int g = 0; g < QG; ++g)
+        if (__any(alpha[g] != 1.f)) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) o[g][t] *= alpha[g];
+        }
+    }
     if constexpr (NT <= 4) {
       bf16x8 v0[NT], v1[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
-      if (kt_ >= n_hi) {   // V lo plane present: third product term
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (ILV) v0[t] = vh[t];
+        else v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
+      }
+      if (MAYLO && kt_ >= n_hi) {   // V lo plane present: third product term
 #pragma unroll
         for (int t = 0; t < NT; ++t) v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][VPL - 1][(t * 16 + l15) * VROWB + grp * 16]);
 #pragma unroll
@@ -363,6 +458,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }
   };
 
+#if DS2_ATTN_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md)
+#endif
   W8_LOAD_K(0)
   W8_LOAD_V(0)
   W8_STORE_K(0)
@@ -372,32 +470,46 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   __syncthreads();
   // one iteration: [global loads of K(kt+2), V(kt+1)] [scores of tile kt+1 -> nxt] [softmax + P.V of tile kt <- cur] [stage] [barrier]
   // (the scores of a tile past the end are computed on the clamped K buffer and ignored: no branch inside the block)
-#define W8_STEP(MT, KT, C0, C1, N0, N1)                                       \
+#define W8_STEP(MT, LT, KT, C0, C1, N0, N1)                                   \
   {                                                                           \
     const int kt_s = (KT);                                                    \
+    if constexpr (!(DS2_ABL & 4)) {                                           \
     W8_LOAD_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1)                            \
     W8_LOAD_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1)                            \
+    }                                                                         \
+    if constexpr (ILV) __builtin_amdgcn_sched_barrier(0);   /* the global loads leave first, not at the end of the pipeline */ \
     scores(MT, (kt_s + 1) & 1, kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, N0, N1);  \
-    softmax_pv(kt_s & 1, kt_s, C0, C1);                                       \
+    softmax_pv(LT, kt_s & 1, kt_s, C0, C1);                                   \
+    if constexpr (!(DS2_ABL & 4)) {                                           \
     W8_STORE_K(kt_s & 1)                                                      \
     W8_STORE_V((kt_s + 1) & 1, (kt_s + 1 < nkt ? kt_s + 1 : nkt - 1))         \
-    __syncthreads();                                                          \
+    }                                                                         \
+    if constexpr (!(DS2_ABL & 8)) __syncthreads();                            \
   }
+  const std::true_type maylo{};
+  const std::false_type nolo{};
+  // ILV: the tiles below n_hi (frame tokens: no V lo plane) run in a loop of their own without the lo-plane test
+  const int n_fast = ILV && DV == 64 ? ((n_hi < nkt ? n_hi : nkt) & ~1) : 0;
   if (a.Lk % BKEYS == 0) {
     const std::false_type nm{};
     scores(nm, 0, 0, sa0, sa1);
     __syncthreads();   // every wave has read K(0) before iteration 0 overwrites it with K(2)
-    for (int kt = 0; kt < nkt; kt += 2) {
-      W8_STEP(nm, kt, sa0, sa1, sb0, sb1)
-      if (kt + 1 < nkt) W8_STEP(nm, kt + 1, sb0, sb1, sa0, sa1)
+    int kt = 0;
+    for (; kt < n_fast; kt += 2) {
+      W8_STEP(nm, nolo, kt, sa0, sa1, sb0, sb1)
+      W8_STEP(nm, nolo, kt + 1, sb0, sb1, sa0, sa1)
+    }
+    for (; kt < nkt; kt += 2) {
+      W8_STEP(nm, maylo, kt, sa0, sa1, sb0, sb1)
+      if (kt + 1 < nkt) W8_STEP(nm, maylo, kt + 1, sb0, sb1, sa0, sa1)
     }
   } else {
     const std::true_type wm{};
     scores(wm, 0, 0, sa0, sa1);
     __syncthreads();
     for (int kt = 0; kt < nkt; kt += 2) {
-      W8_STEP(wm, kt, sa0, sa1, sb0, sb1)
-      if (kt + 1 < nkt) W8_STEP(wm, kt + 1, sb0, sb1, sa0, sa1)
+      W8_STEP(wm, maylo, kt, sa0, sa1, sb0, sb1)
+      if (kt + 1 < nkt) W8_STEP(wm, maylo, kt + 1, sb0, sb1, sa0, sa1)
     }
   }
 

@@ -15,10 +15,12 @@ sys.path.insert(0, ROOT)
 
 def build(name, flags):
     import __graft_entry__ as g
+    from concurrent.futures import ThreadPoolExecutor
     out = os.path.join(g.PKG, "lib", f"ab_{name}.so")
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-o", out] + flags + [os.path.join(g.PKG, "csrc", s) for s in g.SOURCES]
-    subprocess.run(cmd, check=True)
+    obj_dir = os.path.join(g.PKG, "lib", f"obj_ab_{name}")
+    with ThreadPoolExecutor(max_workers=6) as ex:      # per source, with the per-source flags of the default build
+        objs = list(ex.map(lambda s: g._compile_one(os.path.join(g.PKG, "csrc", s), True, obj_dir, flags), g.SOURCES))
+    subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs, check=True)
     g._build_torch_ops(True, out, out[:-3] + "_torch.so")     # the op library of this variant, linked against it
     print(out)
 
