@@ -114,6 +114,20 @@ bool gemm_split_pp256_supported(const GemmSplitArgs& g);
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);
+// gemm_skinny.hip: fp32 linear layer for M <= 128 rows over the transposed weight Wt[K,N]
+struct SkinnyArgs {
+  int M, N, K;
+  const float* A; int lda;
+  const float* Wt;
+  const float* bias; const float* gamma;
+  const float* R; int ldr; int r_mod;
+  float* C; int ldc; int act;
+};
+int launch_skinny_linear(const SkinnyArgs& g, hipStream_t st);
+int launch_mask_up_conv1(const float* low, int hin, int Hin, int mode, float scale, float mbias, const float* w, const float* bias,
+                         const float* lnw, const float* lnb, float* out, int B, hipStream_t st);
+int launch_bcast_rows(const float* x, float* out, int n, int B, hipStream_t st);
+int launch_transpose_w(const float* W, int ldw, int N, int K, float* Wt, hipStream_t st);
 
 // fused two-layer MLP, model width 256 (gemm_mlp256.hip): out = (act(X W1^T + b1) W2^T + b2) * gamma + R; the hidden
 // activations stay in registers.  W2 planes must be built from launch_mlp256_permute_w2's output.

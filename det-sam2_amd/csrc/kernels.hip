@@ -460,6 +460,57 @@ __global__ void k_conv3x3s2_small(const float* in, const float* w, const float* 
   for (int o = 0; o < COUT; ++o) po[o] = ds2_act((acc[o] - mean) * rstd * lnw[o] + lnb[o], DS2_ACT_GELU);
 }
 
+// k_mask_upsample_transform + k_conv3x3s2_small<1, 4> in one pass (memory_encoder.py:36-52 on sam2_base.py:355-360,713-725):
+// a thread computes the nine high-res mask values under its 3x3 window from the low-res logits (bilinear taps + sigmoid /
+// binarise, the same expressions in the same order, so the result is bit-identical to the two-kernel path), then conv ->
+// LayerNorm2d -> GELU.  The 1024^2 mask (4 MiB per object written and read back) never exists in HBM; the 256^2 logits stay in
+// L2.  Neighbouring threads share a window column: 2.25x the minimum arithmetic, all of it VALU in an HBM-write-bound kernel.
+__global__ void k_mask_up_conv1(const float* __restrict__ low, int hin, int Hin, int mode, float scale, float mbias,
+                                const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ lnw,
+                                const float* __restrict__ lnb, float* __restrict__ out, int B) {
+  constexpr int COUT = 4;
+  __shared__ float ws[COUT * 9];
+  for (int i = threadIdx.x; i < COUT * 9; i += blockDim.x) ws[i] = w[i];
+  __syncthreads();
+  const int Ho = Hin / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Ho * Ho) return;
+  const int ox = (int)(i % Ho), oy = (int)((i / Ho) % Ho), b = (int)(i / ((size_t)Ho * Ho));
+  const float* img = low + (size_t)b * hin * hin;
+  const float s = (float)hin / (float)Hin;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+    const Lerp ly = lerp_coef(iy, s, hin);
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = 2 * ox - 1 + kx;
+      if (ix < 0 || ix >= Hin) continue;
+      float v = bilerp(img, hin, ly, lerp_coef(ix, s, hin));
+      if (mode == 0) v = (1.f / (1.f + expf(-v))) * scale + mbias;
+      else if (mode == 1) v = (v > 0.f ? 1.f : 0.f) * scale + mbias;
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) acc[o] += v * ws[o * 9 + ky * 3 + kx];
+    }
+  }
+  float mean = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) mean += acc[o];
+  mean /= (float)COUT;
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) { const float d = acc[o] - mean; var += d * d; }
+  const float rstd = 1.f / sqrtf(var / (float)COUT + 1e-6f);
+  float4 r;
+  r.x = ds2_act((acc[0] - mean) * rstd * lnw[0] + lnb[0], DS2_ACT_GELU);
+  r.y = ds2_act((acc[1] - mean) * rstd * lnw[1] + lnb[1], DS2_ACT_GELU);
+  r.z = ds2_act((acc[2] - mean) * rstd * lnw[2] + lnb[2], DS2_ACT_GELU);
+  r.w = ds2_act((acc[3] - mean) * rstd * lnw[3] + lnb[3], DS2_ACT_GELU);
+  *reinterpret_cast<float4*>(out + i * COUT) = r;
+}
+
 // im2col for conv3x3/s2/p1 on NHWC input; column = (ky*3+kx)*Cin + c (weights are repacked to match).
 __global__ void k_im2col3x3s2(const float* in, float* out, int B, int Hin, int Cin) {
   const int Ho = Hin / 2, c4n = Cin / 4;
@@ -911,6 +962,20 @@ int launch_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
+// out[b][i] = x[i], b < B (n % 4 == 0): the shared layer-0 result of the memory attention replicated per object
+__global__ void k_bcast_rows(const f32x4* __restrict__ x, f32x4* __restrict__ out, int n4, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = x[i];
+  for (int b = 0; b < B; ++b) __builtin_nontemporal_store(v, out + (size_t)b * n4 + i);
+}
+int launch_bcast_rows(const float* x, float* out, int n, int B, hipStream_t st) {
+  DS2_REQUIRE(n % 4 == 0, "bcast_rows: n must be a multiple of 4");
+  hipLaunchKernelGGL(k_bcast_rows, dim3((n / 4 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const f32x4*>(x),
+                     reinterpret_cast<f32x4*>(out), n / 4, B);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
 int launch_add_rowvec(const float* a, int lda, const float* vec, float* out, int ldo, int rows, int C, hipStream_t st) {
   hipLaunchKernelGGL(k_add_rowvec, grid1((size_t)rows * C), dim3(256), 0, st, a, lda, vec, out, ldo, rows, C);
   DS2_CHECK_LAUNCH();
@@ -968,6 +1033,13 @@ int launch_mask_upsample_transform(const float* low, float* high, int B, int hin
                                    float bias, hipStream_t st) {
   hipLaunchKernelGGL(k_mask_upsample_transform, grid1((size_t)B * hout * hout), dim3(256), 0, st, low, high, B, hin, hout,
                      mode, scale, bias);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_mask_up_conv1(const float* low, int hin, int Hin, int mode, float scale, float mbias, const float* w, const float* bias,
+                         const float* lnw, const float* lnb, float* out, int B, hipStream_t st) {
+  const size_t n = (size_t)B * (Hin / 2) * (Hin / 2);
+  hipLaunchKernelGGL(k_mask_up_conv1, grid1(n), dim3(256), 0, st, low, hin, Hin, mode, scale, mbias, w, bias, lnw, lnb, out, B);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

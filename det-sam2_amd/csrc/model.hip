@@ -110,6 +110,8 @@ struct GemmPlanes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
 struct GemmCtx {
   typedef std::unordered_map<const float*, GemmPlanes> PlaneMap;
   PlaneMap own_wcache, own_w2perm;
+  std::unordered_map<const float*, float*> own_wt;   // skinny linear layers: fp32 weights transposed to [K, N] (once)
+  std::unordered_map<const float*, float*>& wt() { return share ? share->own_wt : own_wt; }
   GemmCtx* share = nullptr;   // a VIEW model (ds2_model_create_view) uses its parent's weight planes; the scratch is its own
   PlaneMap& wc() { return share ? share->own_wcache : own_wcache; }        // weights split into planes (once)
   PlaneMap& w2p() { return share ? share->own_w2perm : own_w2perm; }      // fused MLP: W2 with the hidden index permuted
@@ -133,6 +135,8 @@ struct GemmCtx {
     own_wcache.clear();
     for (auto& kv : own_w2perm) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     own_w2perm.clear();
+    for (auto& kv : own_wt) (void)hipFree(kv.second);
+    own_wt.clear();
     if (scratch) (void)hipFree(scratch);
     scratch = nullptr; scratch_cap = 0;
   }
@@ -300,6 +304,28 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
+  }
+  // a handful of rows against a model weight (token side of the two-way transformer, small heads): spread over the chip in
+  // exact fp32 instead of one or two latency-bound tiles (gemm_skinny.hip; DS2_GEMM_SKINNY=0 restores the tile kernels)
+  static const bool skinny_on = [] { const char* e = getenv("DS2_GEMM_SKINNY"); return !e || atoi(e) != 0; }();
+  if (skinny_on && M <= 128 && w_static && m && !planes_out && !rope_cis && K % 4 == 0 && lda % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && !m->act_planes.count(A)) {
+    char ptag[96] = "";
+    if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "gemm %d %d %d", M, N, K);
+    ProfScope _gp(ptag, st, g_prof_gemm);
+    GemmCtx& ctx = m->gctx;
+    float* wt = nullptr;
+    auto it = ctx.wt().find(W);
+    if (it != ctx.wt().end()) {
+      wt = it->second;
+    } else {
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wt), (size_t)N * K * 4));
+      TRY(launch_transpose_w(W, ldw, N, K, wt, st));
+      TRY(ctx.publish(st));
+      ctx.wt()[W] = wt;
+    }
+    SkinnyArgs g{M, N, K, A, lda, wt, bias, gamma, R, ldr, r_mod, C, ldc, act};
+    return launch_skinny_linear(g, st);
   }
   if (!ds2_split_mode()) {
     GemmArgs g{M, N, K, A, lda, W, ldw, bias, C, ldc, act, gamma, R, ldr, r_mod};
@@ -1018,8 +1044,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     }
     if (once) {
       if (!m->ma_fold_vo) TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
-      for (int b = 0; b < B; ++b)
-        DS2_CHECK_HIP(hipMemcpyAsync(x + (size_t)b * TOK * 256, x1, (size_t)TOK * 256 * 4, hipMemcpyDeviceToDevice, st));
+      TRY(launch_bcast_rows(x1, x, TOK * 256, B, st));   // one launch instead of B device copies
     } else if (!m->ma_fold_vo) {
       TRY(linear(m, st, p + ".self_attn.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     }
@@ -1288,18 +1313,26 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (size_t)rows * (256 * 3 + 1024 * 2) * 4 + (8u << 20);
   TRY(m->require(need, st));
   const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
-  ALLOC(high, (size_t)B * 1048576);
-  if (masks_hi && !hi_sigmoid) {
-    DS2_CHECK_HIP(hipMemcpyAsync(high, masks_hi, (size_t)B * 1048576 * 4, hipMemcpyDeviceToDevice, st));
-  } else if (masks_hi) {   // identity resample + sigmoid (memory_encoder.py:166-167)
-    TRY(launch_mask_upsample_transform(masks_hi, high, B, 1024, 1024, 0, 1.f, 0.f, st));
-  } else {
-    TRY(launch_mask_upsample_transform(low_res, high, B, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc,
-                                       m->cfg.sigmoid_bias_for_mem_enc, st));
-  }
   ALLOC(c1, (size_t)B * 262144 * 4);
-  TRY(launch_conv3x3s2_small(high, m->P(ds + "0.weight"), m->P(ds + "0.bias"), m->P(ds + "1.weight"), m->P(ds + "1.bias"), c1,
-                             B, 1024, 1, 4, st));
+  // low-res logits: upsample + sigmoid / binarise + first conv stage in one kernel - the 1024^2 mask is never materialised
+  // (DS2_ME_FUSE_UP=0: the two-kernel path, bit-identical)
+  static const bool fuse_up = [] { const char* e = getenv("DS2_ME_FUSE_UP"); return !e || atoi(e) != 0; }();
+  if (!masks_hi && fuse_up) {
+    TRY(launch_mask_up_conv1(low_res, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc, m->cfg.sigmoid_bias_for_mem_enc,
+                             m->P(ds + "0.weight"), m->P(ds + "0.bias"), m->P(ds + "1.weight"), m->P(ds + "1.bias"), c1, B, st));
+  } else {
+    ALLOC(high, (size_t)B * 1048576);
+    if (masks_hi && !hi_sigmoid) {
+      DS2_CHECK_HIP(hipMemcpyAsync(high, masks_hi, (size_t)B * 1048576 * 4, hipMemcpyDeviceToDevice, st));
+    } else if (masks_hi) {   // identity resample + sigmoid (memory_encoder.py:166-167)
+      TRY(launch_mask_upsample_transform(masks_hi, high, B, 1024, 1024, 0, 1.f, 0.f, st));
+    } else {
+      TRY(launch_mask_upsample_transform(low_res, high, B, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc,
+                                         m->cfg.sigmoid_bias_for_mem_enc, st));
+    }
+    TRY(launch_conv3x3s2_small(high, m->P(ds + "0.weight"), m->P(ds + "0.bias"), m->P(ds + "1.weight"), m->P(ds + "1.bias"), c1,
+                               B, 1024, 1, 4, st));
+  }
   ALLOC(c2, (size_t)B * 65536 * 16);
   TRY(launch_conv3x3s2_small(c1, m->P(ds + "3.weight"), m->P(ds + "3.bias"), m->P(ds + "4.weight"), m->P(ds + "4.bias"), c2, B,
                              512, 4, 16, st));
@@ -1379,6 +1412,17 @@ extern "C" int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int3
                            const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
                            int32_t ldr, int32_t r_mod, void* stream) {
   return gemm((hipStream_t)stream, M, N, K, A, lda, W, ldw, bias, C, ldc, act, R, ldr, r_mod, gamma);
+}
+extern "C" int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
+                                   const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
+                                   int32_t ldr, int32_t r_mod, void* stream) {
+  DS2_REQUIRE(M > 0 && M <= 128 && N > 0 && K > 0 && A && W && C, "ds2_op_linear_small: bad argument (1 <= M <= 128)");
+  hipStream_t st = (hipStream_t)stream;
+  TRY(g_gemm_ctx.require((size_t)N * K * 4, st));           // the model path caches the transposed weight; a primitive call redoes it
+  float* wt = reinterpret_cast<float*>(g_gemm_ctx.scratch);
+  TRY(launch_transpose_w(W, ldw, N, K, wt, st));
+  SkinnyArgs g{M, N, K, A, lda, wt, bias, gamma, R, ldr, r_mod, C, ldc, act};
+  return launch_skinny_linear(g, st);
 }
 extern "C" int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
                           const float* gamma, const float* R, float* out, int32_t act, void* stream) {

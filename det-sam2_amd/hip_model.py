@@ -87,6 +87,16 @@ class HipOps:
                                          _p(R), 0 if R is None else R.stride(0), r_mod, self._stream()), "ds2_op_gemm")
         return out
 
+    def op_linear_small(self, A, W, bias=None, act=0, gamma=None, R=None, r_mod=0):
+        """Few-row Linear layer in exact fp32 (ds2_op_linear_small): A [M<=128,K], W [N,K] -> [M,N]."""
+        M, K = A.shape
+        N = W.shape[0]
+        out = self._empty(M, N)
+        _capi.check(self.lib.ds2_op_linear_small(M, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), N, act,
+                                                 _p(gamma), _p(R), 0 if R is None else R.stride(0), r_mod, self._stream()),
+                    "ds2_op_linear_small")
+        return out
+
     def op_mlp(self, X, W1, b1, W2, b2, gamma=None, R=None, act=1):
         """Fused two-layer MLP of width 256 (ds2_op_mlp): X [rows,256], W1 [H,256], W2 [256,H] -> [rows,256]."""
         rows, H = X.shape[0], W1.shape[0]

@@ -240,6 +240,12 @@ int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, co
  * and CXBlock's pwconv1 / pwconv2 (memory_encoder.py:104-117) in the bf16x3 modes. */
 int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
                const float* gamma, const float* R, float* out, int32_t act, void* stream);
+/* Linear layer with 1 <= M <= 128 rows in exact fp32 (gemm_skinny.hip): C[M,N] = act(A W[N,K]^T + bias) * gamma + R.  The kernel
+ * behind the token side of the two-way transformer (sam/transformer.py:139-236: 8 tokens per object) and the other few-row
+ * Linear layers of ds2_sam_heads in every arithmetic mode; K, lda multiples of 4, A 16-byte aligned. */
+int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
+                        const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
+                        int32_t ldr, int32_t r_mod, void* stream);
 int ds2_op_layernorm(const float* x, const float* w, const float* b, float* y, int32_t rows, int32_t C, float eps,
                      int32_t act, void* stream);
 int ds2_op_attention(const float* q, const float* k, const float* v, float* o, int32_t ldq, int32_t ldk, int32_t ldv,

@@ -90,6 +90,41 @@ def test_fused_mlp(rows, H, act, use_r, use_g):
     assert torch.equal(got, again)                 # run-to-run bit identity (DMA ring hazards show up here)
 
 
+@pytest.mark.parametrize("M,N,K,act,use_r,r_mod", [
+    (128, 256, 256, 0, True, 0),       # token-side projection, 16 objects x 8 tokens, residual
+    (128, 2048, 256, 1, False, 0),     # two-way transformer MLP, first layer (ReLU)
+    (128, 256, 2048, 0, True, 0),      # ... second layer: K split over 16 waves
+    (9, 128, 256, 0, False, 0),        # one object, ragged row group
+    (24, 4, 256, 3, False, 0),         # fewer columns than a wave (sigmoid head)
+    (40, 100, 64, 2, True, 8),         # ragged columns, GELU, broadcast residual
+    (1, 256, 128, 0, False, 0),
+])
+def test_linear_small(ops, M, N, K, act, use_r, r_mod):
+    """gemm_skinny.hip against the fp64 formula: exact fp32 arithmetic, so the bound is fp32 rounding; run-to-run and
+    batch-composition bit identity (a row's result must not depend on the rows around it: sharded streams)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K), torch.randn(N, generator=g)
+    gam = torch.randn(N, generator=g)
+    R = torch.randn(r_mod if r_mod else M, N, generator=g) if use_r else None
+    ref = A.double() @ W.double().T + b.double()
+    ref = [lambda x: x, F.relu, F.gelu, torch.sigmoid][act](ref) * gam.double()
+    if use_r:
+        ref = ref + (R.double()[torch.arange(M) % r_mod] if r_mod else R.double())
+    d = ops.device
+    dev = lambda t: None if t is None else t.to(d)
+    got = ops.op_linear_small(dev(A), dev(W), dev(b), act, dev(gam), dev(R), r_mod)
+    again = ops.op_linear_small(dev(A), dev(W), dev(b), act, dev(gam), dev(R), r_mod)
+    torch.cuda.synchronize()
+    e = rel_err(got, ref)
+    record("linear_small", M=M, N=N, K=K, act=act, err=e)
+    assert e < 2e-6, e
+    assert torch.equal(got, again)
+    if M > 1 and not use_r:     # the second half of the rows alone: same bits
+        sub = ops.op_linear_small(dev(A[M // 2:].contiguous()), dev(W), dev(b), act, dev(gam))
+        torch.cuda.synchronize()
+        assert torch.equal(sub, got[M // 2:])
+
+
 @pytest.mark.parametrize("rows,C,act", [(37, 96, 0), (1000, 256, 2), (5, 1152, 0), (64, 4, 2)])
 def test_layernorm(ops, rows, C, act):
     g = torch.Generator().manual_seed(rows)
