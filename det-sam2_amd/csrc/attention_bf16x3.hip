@@ -41,6 +41,12 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1) {
   p1 = __builtin_bit_cast(bf16x8, l);
 }
 
+#ifndef DS2_HATT_CRESCALE
+#define DS2_HATT_CRESCALE 1
+#endif
+#ifndef DS2_HATT_V8
+#define DS2_HATT_V8 0
+#endif
 // DS2_ATT_TRACE (profiling builds only): wave 0 / 4 of workgroup (0,0,0) stamp s_memtime along their key tiles; =1 traces the
 // global-attention launches (Lk = 4096), =2 the 256-key window launches (tools/att_trace.py)
 #ifdef DS2_ATT_TRACE
@@ -143,6 +149,12 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   float4 rk[NK4], rv[NV4];
+  // DS2_HATT_V8: V is fetched per (dv, octet of V^T positions) - 8 dword loads along the key axis, lanes along dv (coalesced) -
+  // and staged with ONE 16-byte LDS store per plane instead of eight 2-byte ones per float4 (tried for the "V stage" share of a tile, 11 % in the
+  // trace of tools/att_trace.py; SLOWER - image encoder 9.21 -> 9.51 ms/frame: eight key cursors and eight 64-bit addresses per
+  // slot cost more VALU than the 2-byte stores - so off by default)
+  constexpr int NV8 = DS2_HATT_V8 ? (4 * DV + NTHR - 1) / NTHR : 0;
+  float rv8[NV8 > 0 ? NV8 : 1][8];
   // Key rows.  The tiles are fetched in order, so each staging slot keeps a cursor (key index + position inside the key
   // window) that advances by one tile per fetch: no divisions in the loop (RowMap::row costs four per key; the trace of
   // tools/att_trace.py showed the address arithmetic of the fetches at 30-50 % of a windowed tile).
@@ -192,7 +204,36 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
       }
     }
   };
+  KeyCur v8cur[NV8 > 0 ? NV8 : 1][8];
+  if constexpr (DS2_HATT_V8) {
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int oct = (tid + NTHR * i) / DV;            // position octet 0..3 = (s, h): keys 16 s + 4 h + {0..3, 8..11}
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v8cur[i][j] = cur_init(16 * (oct >> 1) + 4 * (oct & 1) + (j & 3) + 8 * (j >> 2));
+    }
+  }
   auto load_v = [&](int) {
+    if constexpr (DS2_HATT_V8) {
+#pragma unroll
+      for (int i = 0; i < NV8; ++i) {
+        const int idx = tid + NTHR * i;
+        const int dv = idx % DV;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          rv8[i][j] = 0.f;
+          if (idx < 4 * DV) {
+            if (v8cur[i][j].ki < a.Lk) {
+              const long row = cur_row(v8cur[i][j]);
+              const float* p = row >= 0 ? a.v + row * a.ldv + h * DV : (a.v_pad ? a.v_pad + h * DV : nullptr);
+              if (p) rv8[i][j] = p[dv];
+            }
+            cur_next(v8cur[i][j]);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
       const int idx = tid + NTHR * i;
@@ -226,6 +267,20 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
     }
   };
   auto store_v = [&](int buf) {   // transposed + key-permuted
+    if constexpr (DS2_HATT_V8) {
+#pragma unroll
+      for (int i = 0; i < NV8; ++i) {
+        const int idx = tid + NTHR * i;
+        if (idx < 4 * DV) {
+          const int dv = idx % DV, oct = idx / DV;
+          bf16x8 hi, lo;
+          split8(rv8[i], hi, lo);
+          *reinterpret_cast<bf16x8*>(&Vp[buf][0][dv * VROWB + oct * 16]) = hi;
+          *reinterpret_cast<bf16x8*>(&Vp[buf][1][dv * VROWB + oct * 16]) = lo;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
       const int idx = tid + NTHR * i;
@@ -313,10 +368,14 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
     }
     ATT_T()   // 4: K staged, V loads issued
     if (wave_active) {
+      if (!DS2_HATT_CRESCALE || __any(alpha != 1.f)) {   // (exact: alpha == 1 leaves o unchanged; after the first tiles the common case)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
         const unsigned char* v0p = &Vp[cur][0][(t * 32 + l31) * VROWB + half * 16];
         const unsigned char* v1p = &Vp[cur][1][(t * 32 + l31) * VROWB + half * 16];
 #pragma unroll
