@@ -44,6 +44,9 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1) {
 #ifndef DS2_HATT_CRESCALE
 #define DS2_HATT_CRESCALE 1
 #endif
+#ifndef DS2_HATT_VEARLY
+#define DS2_HATT_VEARLY 1
+#endif
 #ifndef DS2_HATT_V8
 #define DS2_HATT_V8 0
 #endif
@@ -318,7 +321,10 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
 #endif
   for (int kt = 0; kt < nkt; ++kt) {
     ATT_T()   // 0: tile start
-    if (kt + 1 < nkt) load_k(kt + 1);
+    if (kt + 1 < nkt) {
+      load_k(kt + 1);
+      if (DS2_HATT_VEARLY) load_v(kt + 1);   // V fetched with K: it is consumed 2 phases later, not right after its issue
+    }
     ATT_T()   // 1: K loads issued
     f32x16 acc;
     bf16x8 pb0[2], pb1[2];
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
     ATT_T()   // 3: softmax + P split done
     if (kt + 1 < nkt) {
       store_k(cur ^ 1);
-      load_v(kt + 1);
+      if (!DS2_HATT_VEARLY) load_v(kt + 1);
     }
     ATT_T()   // 4: K staged, V loads issued
     if (wave_active) {

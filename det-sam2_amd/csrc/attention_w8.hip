@@ -62,16 +62,6 @@ __device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, 
 #ifndef DS2_ATTN_ILV
 #define DS2_ATTN_ILV 1
 #endif
-// DS2_ATTN_DEFER (on top of ILV, frame-token tiles): P.V of tile t is issued at the START of step t+1, from registers (P and the
-// V^T fragments were read before the barrier) - its MFMAs cover the LDS latency of the first K fragments after the barrier and
-// the issue of the step's global loads, which used to be matrix-pipe idle time for both waves of a SIMD at once.
-#ifndef DS2_ATTN_DEFER
-#define DS2_ATTN_DEFER 1
-#endif
-#ifndef DS2_ATTN_DEFER_VALU
-#define DS2_ATTN_DEFER_VALU 3
-#endif
-constexpr int DEFER_VALU = DS2_ATTN_DEFER_VALU;
 #ifndef DS2_ATTN_PRIO
 #define DS2_ATTN_PRIO 0
 #endif
@@ -468,126 +458,6 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }
   };
 
-  // ---- deferred form (DS2_ATTN_DEFER): softmax of tile kt_ only - P and the V^T fragments of the tile are left in pend_pb /
-  // pend_vh; pv_pending() issues the product.  Same arithmetic, same order per accumulator as softmax_pv.
-  constexpr bool DEFER = ILV && DS2_ATTN_DEFER && NT == 4 && QG == 2 && KS == 8;
-  bf16x8 pend_pb[QG], pend_vh[NT <= 4 ? NT : 1];
-#pragma unroll
-  for (int g = 0; g < QG; ++g) pend_pb[g] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int t = 0; t < (NT <= 4 ? NT : 1); ++t) pend_vh[t] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  auto pv_pending = [&]() {
-#pragma unroll
-    for (int t = 0; t < (NT <= 4 ? NT : 1); ++t)
-#pragma unroll
-      for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pend_vh[t], pend_pb[g], o[g][t], 0, 0, 0);
-  };
-  // One deferred step, written as EIGHT pinned segments (one per 32-deep k-step of the scores; sched_barrier(0) between them):
-  //   prefix    : the step's three global loads, the K fragments of k-steps 0 and 1, the 8 pending P.V MFMAs (register operands
-  //               only - they run while the first fragments arrive from LDS)
-  //   segment ks: the fragment reads of k-step ks + 2 (ks >= 6: the tile's V^T fragments for the NEXT step's P.V), the four score
-  //               MFMAs of k-step ks, and one quarter of one query group's softmax (phase ks % 4 of group ks / 4) in their shadow
-  // Inside a segment a four-group sched_group_barrier pipeline alternates MFMA / VALU; across segments nothing moves.  (One
-  // pipeline over the whole step - 40 MFMAs, 90 VALU, 23 reads - is beyond the greedy solver: it clumps dependent MFMAs and
-  // places every read just in time.)
-  const unsigned koff0 = (unsigned)(krow * 512 + kpart * 16);
-  const unsigned voff_lo = (unsigned)tid * 16u, voff_hi = (unsigned)(tid < 256 ? tid : tid - 256) * 16u;
-  float sm_m[QG], sm_a[QG], sm_p[QG][8];
-  bf16x8 sm_pb[QG];
-  auto sm_phase = [&](auto ph_tag, auto g_tag, f32x4 (&s0)[QG], f32x4 (&s1)[QG]) {
-    constexpr int PH = decltype(ph_tag)::value, g = decltype(g_tag)::value;
-    if constexpr (PH == 0) {
-      float tmax = fmaxf(fmaxf(fmaxf(s0[g][0], s0[g][1]), fmaxf(s0[g][2], s0[g][3])),
-                         fmaxf(fmaxf(s1[g][0], s1[g][1]), fmaxf(s1[g][2], s1[g][3])));
-      tmax = xmax16(tmax);
-      tmax = xmax32(tmax);
-      sm_m[g] = fmaxf(m_run[g], tmax);
-      sm_a[g] = __builtin_amdgcn_exp2f(m_run[g] - sm_m[g]);
-      m_run[g] = sm_m[g];
-    } else if constexpr (PH == 1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm_p[g][r] = W8_EXP2(s0[g][r] - sm_m[g]);
-    } else if constexpr (PH == 2) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sm_p[g][4 + r] = W8_EXP2(s1[g][r] - sm_m[g]);
-    } else {
-      l_run[g] = l_run[g] * sm_a[g] + (((sm_p[g][0] + sm_p[g][1]) + (sm_p[g][2] + sm_p[g][3])) + ((sm_p[g][4] + sm_p[g][5]) + (sm_p[g][6] + sm_p[g][7])));
-      sm_pb[g] = pack8(sm_p[g][0], sm_p[g][1], sm_p[g][2], sm_p[g][3], sm_p[g][4], sm_p[g][5], sm_p[g][6], sm_p[g][7]);
-    }
-  };
-  auto step_d = [&](int kt_s, f32x4 (&c0)[QG], f32x4 (&c1)[QG], f32x4 (&n0)[QG], f32x4 (&n1)[QG]) {
-    static_assert(!DEFER || (QG == 2 && KS == 8 && NT == 4), "deferred step: QG = 2, D = 256, DV = 64");
-    if constexpr (DEFER) {
-    pv_pending();
-    {
-      const char* kb_ = kbytes + (size_t)(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1) * (BKEYS * 512);
-      rk0 = *reinterpret_cast<const uint4*>(kb_ + koff0);
-      rk1 = *reinterpret_cast<const uint4*>(kb_ + koff0 + 16 * 512);
-      const int kv_ = kt_s + 1 < nkt ? kt_s + 1 : nkt - 1;
-      rv[0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(vbase + (size_t)kv_ * (8 * DV)) + (kv_ >= n_hi ? voff_lo : voff_hi));
-    }
-    const int kb = (kt_s + 1) & 1, vb = kt_s & 1;
-    const unsigned char* kp0 = &Kp[kb][0][l15 * KROWB + grp * 16];
-    bf16x8 fa[3][2];
-    fa[0][0] = *reinterpret_cast<const bf16x8*>(kp0);
-    fa[0][1] = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB);
-    fa[1][0] = *reinterpret_cast<const bf16x8*>(kp0 + 64);
-    fa[1][1] = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + 64);
-    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto seg = [&](auto ks_tag) {
-      constexpr int ks = decltype(ks_tag)::value;
-      constexpr int PH = ks % 4, sg = ks / 4 < QG ? ks / 4 : QG - 1;
-      // (empty volatile statements fence the phase's VALU work into THIS segment: instruction selection otherwise floats the
-      // register-only arithmetic across the sched_barrier intrinsics, which only order what is chained to them)
-      if constexpr (PH == 0) asm volatile("" : "+v"(m_run[sg]));
-      else asm volatile("" : "+v"(sm_m[sg]));
-      if constexpr (ks + 2 < KS) {
-        fa[(ks + 2) % 3][0] = *reinterpret_cast<const bf16x8*>(kp0 + (ks + 2) * 64);
-        fa[(ks + 2) % 3][1] = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + (ks + 2) * 64);
-      } else {   // the tile's own V^T fragments: consumed by the next step's pv_pending()
-        constexpr int t0 = (ks + 2 - KS) * 2;
-        pend_vh[t0] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t0 * 16 + l15) * VROWB + grp * 16]);
-        pend_vh[t0 + 1] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][((t0 + 1) * 16 + l15) * VROWB + grp * 16]);
-      }
-#pragma unroll
-      for (int g = 0; g < QG; ++g) {
-        n0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks % 3][0], q0[g][ks], ks == 0 ? zero4 : n0[g], 0, 0, 0);
-        n1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks % 3][1], q0[g][ks], ks == 0 ? zero4 : n1[g], 0, 0, 0);
-      }
-      sm_phase(std::integral_constant<int, PH>{}, std::integral_constant<int, sg>{}, c0, c1);
-      if constexpr (PH == 0) asm volatile("" : "+v"(sm_m[sg]), "+v"(sm_a[sg]));
-      else if constexpr (PH == 1) asm volatile("" : "+v"(sm_p[sg][0]), "+v"(sm_p[sg][1]), "+v"(sm_p[sg][2]), "+v"(sm_p[sg][3]));
-      else if constexpr (PH == 2) asm volatile("" : "+v"(sm_p[sg][4]), "+v"(sm_p[sg][5]), "+v"(sm_p[sg][6]), "+v"(sm_p[sg][7]));
-      else asm volatile("" : "+v"(l_run[sg]), "+v"(sm_pb[sg]));
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x402, DEFER_VALU, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    seg(std::integral_constant<int, 0>{}); seg(std::integral_constant<int, 1>{}); seg(std::integral_constant<int, 2>{});
-    seg(std::integral_constant<int, 3>{}); seg(std::integral_constant<int, 4>{}); seg(std::integral_constant<int, 5>{});
-    seg(std::integral_constant<int, 6>{}); seg(std::integral_constant<int, 7>{});
-    bool ch = false;
-#pragma unroll
-    for (int g = 0; g < QG; ++g) ch |= sm_a[g] != 1.f;
-    if (__any(ch)) {
-#pragma unroll
-      for (int g = 0; g < QG; ++g)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) o[g][t] *= sm_a[g];
-    }
-#pragma unroll
-    for (int g = 0; g < QG; ++g) pend_pb[g] = sm_pb[g];
-    }
-  };
-
 #if DS2_ATTN_PRIO
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every VALU arbitration otherwise (MI355X_MICROARCH.md)
 #endif
@@ -616,15 +486,6 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     }                                                                         \
     if constexpr (!(DS2_ABL & 8)) __syncthreads();                            \
   }
-  // deferred step (full tiles only: Lk % 32 == 0): no per-lane address arithmetic - the tile index is scalar
-#define W8_STEP_D(KT, C0, C1, N0, N1)                                         \
-  {                                                                           \
-    const int kt_s = (KT);                                                    \
-    if constexpr (DEFER) step_d(kt_s, C0, C1, N0, N1);                        \
-    W8_STORE_K(kt_s & 1)                                                      \
-    W8_STORE_V((kt_s + 1) & 1, (kt_s + 1 < nkt ? kt_s + 1 : nkt - 1))         \
-    __syncthreads();                                                          \
-  }
   const std::true_type maylo{};
   const std::false_type nolo{};
   // ILV: the tiles below n_hi (frame tokens: no V lo plane) run in a loop of their own without the lo-plane test
@@ -634,17 +495,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     scores(nm, 0, 0, sa0, sa1);
     __syncthreads();   // every wave has read K(0) before iteration 0 overwrites it with K(2)
     int kt = 0;
-    if constexpr (DEFER) {
-      for (; kt < n_fast; kt += 2) {
-        W8_STEP_D(kt, sa0, sa1, sb0, sb1)
-        W8_STEP_D(kt + 1, sb0, sb1, sa0, sa1)
-      }
-      pv_pending();   // the last frame-token tile
-    } else {
-      for (; kt < n_fast; kt += 2) {
-        W8_STEP(nm, nolo, kt, sa0, sa1, sb0, sb1)
-        W8_STEP(nm, nolo, kt + 1, sb0, sb1, sa0, sa1)
-      }
+    for (; kt < n_fast; kt += 2) {
+      W8_STEP(nm, nolo, kt, sa0, sa1, sb0, sb1)
+      W8_STEP(nm, nolo, kt + 1, sb0, sb1, sa0, sa1)
     }
     for (; kt < nkt; kt += 2) {
       W8_STEP(nm, maylo, kt, sa0, sa1, sb0, sb1)
