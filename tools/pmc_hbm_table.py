@@ -41,7 +41,8 @@ named = {
     "k_ingest_u8": ("A3 frame ingest (per frame: 3 MiB uint8 in, 6 MiB fp16 out)", None),
     "k_mask_output": ("A15 256^2 -> video res + threshold + bit-pack (4 MiB logits in, 2 MiB packed out)", 16 * 256 * 256 * 4 + 16 * 1024 * 128),
     "k_bank_mem": ("A11 bank gather (bf16 entries in, fp32 memory + memory_pos out)", 16 * 7 * 4096 * 64 * (2 + 4 + 4)),
-    "k_mask_upsample_transform": ("A13 256^2 -> 1024^2 sigmoid*20-10 (4 MiB in, 64 MiB out)", 16 * 256 * 256 * 4 + 16 * 1024 * 1024 * 4),
+    "k_mask_upsample_transform": ("A13 256^2 -> 1024^2 sigmoid*20-10 (4 MiB in, 64 MiB out; only the mask-prompt path since round 3)", 16 * 256 * 256 * 4 + 16 * 1024 * 1024 * 4),
+    "k_mask_up_conv1": ("A13 256^2 logits -> upsample + sigmoid + conv3x3/s2 + LN2d + GELU (4 MiB in, 64 MiB out; the 1024^2 mask stays on chip)", 16 * 256 * 256 * 4 + 16 * 512 * 512 * 4 * 4),
 }
 print("# named HBM-bound kernels: measured GB/s (counters) and algorithmic GB/s (bytes a launch must move / mean duration)")
 for t_ns, name, n, byt, gbs in rows:
