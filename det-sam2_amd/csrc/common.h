@@ -168,4 +168,9 @@ bool attention_fewq_supported(const AttnArgs& a);                // Lq <= 16 aga
 int launch_attention_fewq(const AttnArgs& a, hipStream_t st);    // split-key exact fp32 path (attention_fewq.hip)
 bool attention_smallwin_supported(const AttnArgs& a);            // 16- / 64-key Hiera windows, bf16x3 (attention_smallwin.hip)
 int launch_attention_smallwin(const AttnArgs& a, hipStream_t st);
+// Hiera global attention over operands pre-split per (image, head) (attention_hg.hip): the caller provides the plane buffers
+bool attention_hg_supported(const AttnArgs& a);
+size_t attention_hg_k_bytes(const AttnArgs& a);                  // K tile images (hi + lo planes)
+size_t attention_hg_vt_bytes(const AttnArgs& a);                 // V^T tile images
+int launch_attention_hg(const AttnArgs& a, void* k_img, void* vt_img, hipStream_t st);
 int launch_attention_bf16x3(const AttnArgs& a, hipStream_t st);  // DS2_ERR_UNSUPPORTED if no kernel for (D,DV)

@@ -755,7 +755,8 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
       const size_t hw = (size_t)n * side * side, hwq = b.q_stride ? hw / 4 : hw;
       outs += hwq * b.dim_out * 4 + 256;
       // fp32 temporaries + (bf16x3 mode) their operand planes, which take the same number of bytes
-      const size_t tmp = 2 * (hw * (b.dim + 32) + hw * b.dim_out * 2 + hw * 3 * b.dim_out + hwq * (b.dim_out + 32) * 3 + hwq * 4 * b.dim_out) * 4 + 65536;
+      size_t tmp = 2 * (hw * (b.dim + 32) + hw * b.dim_out * 2 + hw * 3 * b.dim_out + hwq * (b.dim_out + 32) * 3 + hwq * 4 * b.dim_out) * 4 + 65536;
+      if (b.window == 0) tmp += hw * b.heads * (size_t)(((b.dim_out / b.heads + 31) / 32 * 32) * 4 + 64 + ((b.dim_out / b.heads + 15) / 16 * 16) * 6) + 4096;   // attention_hg tile images
       if (tmp > tmp_max) tmp_max = tmp;
       if (b.q_stride) side /= 2;
     }
@@ -839,7 +840,16 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
     }
     {
       ProfScope _pa("kernel.hiera_attention", st);
-      TRY(launch_attention(aa, st));
+      // global attention in the split modes: K / V pre-split once per (image, head), attention_hg.hip (DS2_ATTN_HG=0: general kernel)
+      static const bool hg_on = [] { const char* e = getenv("DS2_ATTN_HG"); return !e || atoi(e) != 0; }();
+      if (hg_on && ds2_split_mode() && attention_hg_supported(aa)) {
+        void* kimg = m->alloc_bytes(attention_hg_k_bytes(aa));
+        void* vimg = m->alloc_bytes(attention_hg_vt_bytes(aa));
+        if (!kimg || !vimg) { ds2_set_error("image encoder: workspace exhausted (global attention planes)"); return DS2_ERR_STATE; }
+        TRY(launch_attention_hg(aa, kimg, vimg, st));
+      } else {
+        TRY(launch_attention(aa, st));
+      }
     }
     TRY(linear(m, st, p + ".attn.proj", hwq, b.dim_out, b.dim_out, a, b.dim_out, xn, b.dim_out, DS2_ACT_NONE, sc, b.dim_out));
     ALLOC(t2, (size_t)hwq * b.dim_out);
@@ -1445,5 +1455,12 @@ extern "C" int ds2_op_attention(const float* q, const float* k, const float* v, 
   a.batch = batch; a.heads = heads; a.D = D; a.DV = DV; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.win_q = win_q; a.win_k = win_k; a.Hq = Hq; a.Wq = Wq; a.Hk = Hk; a.Wk = Wk; a.nwx = nwx;
   a.k_pad = k_pad; a.v_pad = v_pad;
+  static const bool hg_on = [] { const char* e = getenv("DS2_ATTN_HG"); return !e || atoi(e) != 0; }();
+  if (hg_on && ds2_split_mode() && attention_hg_supported(a)) {   // as the image encoder does for its global-attention blocks
+    hipStream_t st = (hipStream_t)stream;
+    const size_t kb = (attention_hg_k_bytes(a) + 255) & ~(size_t)255, vb = attention_hg_vt_bytes(a);
+    TRY(g_gemm_ctx.require(kb + vb, st));
+    return launch_attention_hg(a, g_gemm_ctx.scratch, g_gemm_ctx.scratch + kb, st);
+  }
   return launch_attention(a, (hipStream_t)stream);
 }

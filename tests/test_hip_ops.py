@@ -151,6 +151,9 @@ def test_layernorm(ops, rows, C, act):
     (1, 2, 72, 72, 256, 256),
     (1, 2, 96, 96, 64, 64),
     (2, 4, 56, 56, 100, 196),
+    (2, 8, 72, 72, 512, 1024),  # Hiera global attention: pre-split operands, attention_hg.hip (split modes)
+    (1, 2, 96, 96, 256, 320),   # ... head dim 96 (tiny / small), odd tile count
+    (1, 4, 56, 56, 256, 64),    # ... head dim 56 (base_plus), two key tiles
 ])
 def test_attention_plain(ops, B, H, D, DV, Lq, Lk):
     g = torch.Generator().manual_seed(D * 31 + Lq)
