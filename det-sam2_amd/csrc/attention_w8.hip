@@ -24,7 +24,7 @@ constexpr int D = 256, BKEYS = 32;
 // pitch of 16*a bytes (mod 256) puts lane (row, chunk) on 4-bank slot (a*row + chunk) mod 16.  Over the hardware's
 // 16-lane service groups a = 1 or 5 (pitch 528 / 80) collide 2-way (PMC: SQ_LDS_BANK_CONFLICT = 44 % of LDS cycles),
 // a = 2 or 6 (pitch 544 / 96) are conflict-free.
-constexpr int KROWB = D * 2 + 32, KPLANE = BKEYS * KROWB;
+constexpr int KROWB_PAD = D * 2 + 32;   // padded K row pitch (conflict-free); the ILV instantiation swizzles 512-byte rows instead
 constexpr int VROWB_WIDE = 96, VROWB_NARROW = 80;   // DV = 256 does not fit LDS with the wide pitch
 constexpr int KS = D / 32;   // 8 k-steps of 32
 
@@ -61,6 +61,10 @@ __device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, 
 // instructions in a row with the matrix pipe idle; both waves of a SIMD do that in step because of the per-tile barrier.
 #ifndef DS2_ATTN_ILV
 #define DS2_ATTN_ILV 1
+#endif
+// DS2_ATTN_DMA (ILV instantiation): tiles staged by LDS-DMA into swizzled LDS images instead of through registers
+#ifndef DS2_ATTN_DMA
+#define DS2_ATTN_DMA 1
 #endif
 #ifndef DS2_ATTN_PRIO
 #define DS2_ATTN_PRIO 0
@@ -168,7 +172,13 @@ struct W8Args {
 template <int DV, int QG, bool KLO>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int BQ = 128 * QG;
-  constexpr int VROWB = DV >= 256 ? VROWB_NARROW : VROWB_WIDE;
+  // ILV instantiation (bf16x3k cross-attention): LDS images WITHOUT row padding - K rows of 512 bytes, V^T rows of 64 - with the
+  // 16-byte chunks of a row XOR-swizzled by the row index instead, so that a tile is a linear 1-KiB-per-wave copy (LDS-DMA,
+  // W8_DMA_*) of the planes as their producers write them.  K: physical chunk = logical chunk ^ (row & 15); V^T: ^ f((row >> 2) & 3),
+  // f = [0, 3, 2, 1] - both conflict-free over the 16-lane service groups of ds_read_b128 (MI355X_MICROARCH.md).
+  constexpr bool SWZ = DS2_ATTN_ILV && DS2_ATTN_DMA && !KLO && DV == 64;
+  constexpr int KROWB = SWZ ? D * 2 : KROWB_PAD, KPLANE = BKEYS * KROWB;
+  constexpr int VROWB = SWZ ? 64 : (DV >= 256 ? VROWB_NARROW : VROWB_WIDE);
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
   // Software pipeline: the scores of tile t+1 are issued BEFORE the softmax of tile t, in one basic block - their MFMAs are
   // independent of that VALU work, so the matrix pipe runs under the exponentials instead of idling (K is staged one tile
@@ -178,8 +188,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   // (DV = 256, the self-attention, keeps the compiler's own order: with 64 accumulator registers on top the interleaved
   // schedule spills the staged K rows to scratch inside the loop - measured 1.39 -> 1.89 ms/frame)
   constexpr bool ILV = DS2_ATTN_ILV && !KLO && DV == 64;
-  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][KLO ? 2 : 1][KPLANE];
-  __shared__ __attribute__((aligned(16))) unsigned char Vp[NVB][VPL][VPLANE];
+  // ONE LDS array addressed by byte offsets (with separate typed arrays hipcc waits for every pending LDS-DMA before a ds_read
+  // that might alias it): K buffer b, plane p at KP(b, p, 0); V^T buffers behind them
+  constexpr int KNP = KLO ? 2 : 1, VOFF = 2 * KNP * KPLANE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * KNP * KPLANE + NVB * VPL * VPLANE];
+#define KP(b_, p_, off_) (lds + ((b_) * KNP + (p_)) * KPLANE + (off_))
+#define VP(b_, p_, off_) (lds + VOFF + ((b_) * VPL + (p_)) * VPLANE + (off_))
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, grp = lane >> 4;
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   // ---- Q: rounds of 32 rows through LDS (fp32, scaled); each wave picks up its 16*QG rows
   bf16x8 q0[QG][KS], q1[QG][KS];
   {
-    float* Qs = reinterpret_cast<float*>(&Kp[0][0][0]);   // [32][D+1]
+    float* Qs = reinterpret_cast<float*>(lds);   // [32][D+1]
     for (int r4 = 0; r4 < BQ / 32; ++r4) {
       for (int idx = tid; idx < 32 * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
@@ -247,7 +261,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   const size_t kbase = (size_t)b * a.Lk;
   const uint4* vbase = a.vt + (size_t)b * nkt * (8 * DV);
   const char* kbytes = reinterpret_cast<const char*>(a.k_hi + kbase * 32);
-  const int kso0 = krow * KROWB + kpart * 16, kso1 = (krow + 16) * KROWB + kpart * 16;
+  const int kso0 = krow * KROWB + (SWZ ? ((kpart ^ (krow & 15)) << 4) : kpart * 16), kso1 = kso0 + 16 * KROWB;
+  // lane constants of the fragment reads: byte offset of this lane's chunk inside a V^T row / of k-step ks inside a K row
+  const int vsw = SWZ ? ((grp ^ ((4 - ((l15 >> 2) & 3)) & 3)) << 4) : grp * 16;
+  auto kfo = [&](int ks) { return SWZ ? (((ks * 4 + grp) ^ l15) << 4) : grp * 16 + ks * 64; };
 
   uint4 rk0, rk1, rk2, rk3, rv[NVLD];
   // ILV: block-uniform base + 32-bit lane offset (one v_min and one shift-add per row instead of 64-bit index arithmetic),
@@ -285,11 +302,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   }
 #define W8_STORE_K(BUF)                                                       \
   {                                                                           \
-    *reinterpret_cast<uint4*>(&Kp[BUF][0][kso0]) = rk0;                       \
-    *reinterpret_cast<uint4*>(&Kp[BUF][0][kso1]) = rk1;                       \
+    *reinterpret_cast<uint4*>(KP(BUF, 0, kso0)) = rk0;                       \
+    *reinterpret_cast<uint4*>(KP(BUF, 0, kso1)) = rk1;                       \
     if (KLO) {                                                                \
-      *reinterpret_cast<uint4*>(&Kp[BUF][KLO ? 1 : 0][kso0]) = rk2;           \
-      *reinterpret_cast<uint4*>(&Kp[BUF][KLO ? 1 : 0][kso1]) = rk3;           \
+      *reinterpret_cast<uint4*>(KP(BUF, KLO ? 1 : 0, kso0)) = rk2;           \
+      *reinterpret_cast<uint4*>(KP(BUF, KLO ? 1 : 0, kso1)) = rk3;           \
     }                                                                         \
   }
 #define W8_STORE_V(VBUF, STKT)                                                \
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       const int u_ = tid + 512 * j;             /* uint4 index inside the tile */ \
       const int pl_ = u_ / (4 * DV), rw_ = (u_ % (4 * DV)) >> 2, pt_ = u_ & 3; \
       if (((ILV && DV == 64) || DV != 64 || st_kt_ >= n_hi || tid < 256) && (DV != 256 || KLO || j < NVLD / 2)) \
-        *reinterpret_cast<uint4*>(&Vp[VBUF][pl_ < VPL ? pl_ : 0][rw_ * VROWB + pt_ * 16]) = rv[j]; \
+        *reinterpret_cast<uint4*>(VP(VBUF, pl_ < VPL ? pl_ : 0, rw_ * VROWB + (SWZ ? ((pt_ ^ ((4 - ((rw_ >> 2) & 3)) & 3)) << 4) : pt_ * 16))) = rv[j]; \
     }                                                                         \
   }
 
@@ -309,15 +326,15 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     constexpr bool MASK = decltype(mask_tag)::value;   // only a key count that is not a multiple of 32 needs the tail mask
 #pragma unroll
     for (int g = 0; g < QG; ++g) { s0[g] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const unsigned char* kp0 = &Kp[kb][0][l15 * KROWB + grp * 16];
-    const unsigned char* kp1 = &Kp[kb][KLO ? 1 : 0][l15 * KROWB + grp * 16];
+    const unsigned char* kp0 = KP(kb, 0, l15 * KROWB);
+    const unsigned char* kp1 = KP(kb, KLO ? 1 : 0, l15 * KROWB);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + ((DS2_ABL & 2) ? 0 : ks * 64));
-      const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + ((DS2_ABL & 2) ? 0 : ks * 64));
+      const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(kp0 + kfo((DS2_ABL & 2) ? 0 : ks));
+      const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(kp0 + 16 * KROWB + kfo((DS2_ABL & 2) ? 0 : ks));
       if constexpr (KLO) {
-        const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + ks * 64);
-        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + ks * 64);
+        const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(kp1 + kfo(ks));
+        const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(kp1 + 16 * KROWB + kfo(ks));
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
           s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, q0[g][ks], s0[g], 0, 0, 0);
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     [[maybe_unused]] bf16x8 vh[NT <= 4 ? NT : 1];
     if constexpr (ILV && NT <= 4) {   // the V^T fragments of this tile are in LDS since the last barrier: read them under the scores
 #pragma unroll
-      for (int t = 0; t < NT; ++t) vh[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
+      for (int t = 0; t < NT; ++t) vh[t] = *reinterpret_cast<const bf16x8*>(VP(vb, 0, (t * 16 + l15) * VROWB + vsw));
     }
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -421,11 +438,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         if constexpr (ILV) v0[t] = vh[t];
-        else v0[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
+        else v0[t] = *reinterpret_cast<const bf16x8*>(VP(vb, 0, (t * 16 + l15) * VROWB + vsw));
       }
       if (MAYLO && kt_ >= n_hi) {   // V lo plane present: third product term
 #pragma unroll
-        for (int t = 0; t < NT; ++t) v1[t] = *reinterpret_cast<const bf16x8*>(&Vp[vb][VPL - 1][(t * 16 + l15) * VROWB + grp * 16]);
+        for (int t = 0; t < NT; ++t) v1[t] = *reinterpret_cast<const bf16x8*>(VP(vb, VPL - 1, (t * 16 + l15) * VROWB + vsw));
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -444,11 +461,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(&Vp[vb][0][(t * 16 + l15) * VROWB + grp * 16]);
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(VP(vb, 0, (t * 16 + l15) * VROWB + vsw));
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
           if constexpr (KLO) {   // (self-attention in bf16x3k: V as one plane too)
-            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(&Vp[vb][VPL - 1][(t * 16 + l15) * VROWB + grp * 16]);
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(VP(vb, VPL - 1, (t * 16 + l15) * VROWB + vsw));
             o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
             o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
           }
@@ -470,17 +487,45 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   __syncthreads();
   // one iteration: [global loads of K(kt+2), V(kt+1)] [scores of tile kt+1 -> nxt] [softmax + P.V of tile kt <- cur] [stage] [barrier]
   // (the scores of a tile past the end are computed on the clamped K buffer and ignored: no branch inside the block)
+  // LDS-DMA staging (SWZ, full tiles): wave w copies K pieces 2w, 2w+1 (1 KiB = two 512-byte rows: lane -> row 2 pc + lane / 32,
+  // physical chunk lane % 32, i.e. the global chunk (lane % 32) ^ (row & 15)) and V^T piece w & 3 of plane w / 4 (16 rows of 64
+  // bytes: lane -> row lane / 4, global chunk (lane & 3) ^ f((lane >> 4) & 3)); tiles without a lo plane: waves 4-7 copy nothing
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int krow_d0 = 4 * wv + (lane >> 5), krow_d1 = krow_d0 + 2;
+  const unsigned kdo0 = (unsigned)(krow_d0 * 512 + (((lane & 31) ^ (krow_d0 & 15)) << 4));
+  const unsigned kdo1 = (unsigned)(krow_d1 * 512 + (((lane & 31) ^ (krow_d1 & 15)) << 4));
+  const unsigned vdo = (unsigned)((wv >> 2) * (64 * DV) + ((wv & 3) * 16 + (lane >> 2)) * 64 + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 4));
+#define W8_DMA_K(KT, BUF)                                                     \
+  {                                                                           \
+    const char* kt_p_ = kbytes + (size_t)(KT) * (BKEYS * 512);                \
+    __builtin_amdgcn_global_load_lds(kt_p_ + kdo0, (lds_ptr)KP(BUF, 0, (2 * wv) * 1024), 16, 0, 0);     \
+    __builtin_amdgcn_global_load_lds(kt_p_ + kdo1, (lds_ptr)KP(BUF, 0, (2 * wv + 1) * 1024), 16, 0, 0); \
+  }
+#define W8_DMA_V(KT, VBUF)                                                    \
+  {                                                                           \
+    const int kt_v_ = (KT);                                                   \
+    if (wv < 4 || kt_v_ >= n_hi)                                              \
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(vbase + (size_t)kt_v_ * (8 * DV)) + vdo, \
+                                       (lds_ptr)VP(VBUF, wv >> 2, (wv & 3) * 1024), 16, 0, 0); \
+  }
 #define W8_STEP(MT, LT, KT, C0, C1, N0, N1)                                   \
   {                                                                           \
     const int kt_s = (KT);                                                    \
-    if constexpr (!(DS2_ABL & 4)) {                                           \
+    constexpr bool dma_ = SWZ && !std::remove_reference_t<decltype(MT)>::value && !(DS2_ABL & 4); \
+    if constexpr (dma_) {                                                     \
+      W8_DMA_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1, kt_s & 1)                 \
+      W8_DMA_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, (kt_s + 1) & 1)           \
+    } else if constexpr (!(DS2_ABL & 4)) {                                    \
     W8_LOAD_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1)                            \
     W8_LOAD_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1)                            \
     }                                                                         \
     if constexpr (ILV) __builtin_amdgcn_sched_barrier(0);   /* the global loads leave first, not at the end of the pipeline */ \
     scores(MT, (kt_s + 1) & 1, kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, N0, N1);  \
     softmax_pv(LT, kt_s & 1, kt_s, C0, C1);                                   \
-    if constexpr (!(DS2_ABL & 4)) {                                           \
+    if constexpr (dma_) {                                                     \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    } else if constexpr (!(DS2_ABL & 4)) {                                    \
     W8_STORE_K(kt_s & 1)                                                      \
     W8_STORE_V((kt_s + 1) & 1, (kt_s + 1 < nkt ? kt_s + 1 : nkt - 1))         \
     }                                                                         \
