@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   // 16-byte chunks of a row XOR-swizzled by the row index instead, so that a tile is a linear 1-KiB-per-wave copy (LDS-DMA,
   // W8_DMA_*) of the planes as their producers write them.  K: physical chunk = logical chunk ^ (row & 15); V^T: ^ f((row >> 2) & 3),
   // f = [0, 3, 2, 1] - both conflict-free over the 16-lane service groups of ds_read_b128 (MI355X_MICROARCH.md).
-  constexpr bool SWZ = DS2_ATTN_ILV && DS2_ATTN_DMA && !KLO && DV == 64;
+  constexpr bool SWZ = DS2_ATTN_DMA && !KLO && (DV == 64 || DV == 256);   // (DV = 256: the self-attention; hi planes only)
   constexpr int KROWB = SWZ ? D * 2 : KROWB_PAD, KPLANE = BKEYS * KROWB;
   constexpr int VROWB = SWZ ? 64 : (DV >= 256 ? VROWB_NARROW : VROWB_WIDE);
   constexpr int VPLANE = DV * VROWB, NT = DV / 16, NVLD = DV / 64;   // V^T plane rows; dv blocks; uint4 loads per thread
@@ -502,12 +502,18 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     __builtin_amdgcn_global_load_lds(kt_p_ + kdo0, (lds_ptr)KP(BUF, 0, (2 * wv) * 1024), 16, 0, 0);     \
     __builtin_amdgcn_global_load_lds(kt_p_ + kdo1, (lds_ptr)KP(BUF, 0, (2 * wv + 1) * 1024), 16, 0, 0); \
   }
+  // (DV = 256: one plane of 256 rows = 16 pieces, wave w copies pieces 2w and 2w+1)
+  const unsigned vdo256 = (unsigned)((32 * wv + (lane >> 2)) * 64 + (((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) << 4));
 #define W8_DMA_V(KT, VBUF)                                                    \
   {                                                                           \
     const int kt_v_ = (KT);                                                   \
-    if (wv < 4 || kt_v_ >= n_hi)                                              \
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(vbase + (size_t)kt_v_ * (8 * DV)) + vdo, \
-                                       (lds_ptr)VP(VBUF, wv >> 2, (wv & 3) * 1024), 16, 0, 0); \
+    const char* vt_p_ = reinterpret_cast<const char*>(vbase + (size_t)kt_v_ * (8 * DV)); \
+    if constexpr (DV == 256) {                                                \
+      __builtin_amdgcn_global_load_lds(vt_p_ + vdo256, (lds_ptr)VP(VBUF, 0, (2 * wv) * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds(vt_p_ + vdo256 + 1024, (lds_ptr)VP(VBUF, 0, (2 * wv + 1) * 1024), 16, 0, 0); \
+    } else if (wv < 4 || kt_v_ >= n_hi) {                                     \
+      __builtin_amdgcn_global_load_lds(vt_p_ + vdo, (lds_ptr)VP(VBUF, wv >> 2, (wv & 3) * 1024), 16, 0, 0); \
+    }                                                                         \
   }
 #define W8_STEP(MT, LT, KT, C0, C1, N0, N1)                                   \
   {                                                                           \
