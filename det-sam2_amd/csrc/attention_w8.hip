@@ -63,6 +63,9 @@ __device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, 
 #define DS2_ATTN_ILV 1
 #endif
 // DS2_ATTN_DMA (ILV instantiation): tiles staged by LDS-DMA into swizzled LDS images instead of through registers
+#ifndef DS2_ATTN_ILV256
+#define DS2_ATTN_ILV256 0
+#endif
 #ifndef DS2_ATTN_DMA
 #define DS2_ATTN_DMA 1
 #endif
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int NVB = 2, VPL = (DV == 256 && !KLO) ? 1 : 2;
   // (DV = 256, the self-attention, keeps the compiler's own order: with 64 accumulator registers on top the interleaved
   // schedule spills the staged K rows to scratch inside the loop - measured 1.39 -> 1.89 ms/frame)
-  constexpr bool ILV = DS2_ATTN_ILV && !KLO && DV == 64;
+  constexpr bool ILV = DS2_ATTN_ILV && !KLO && (DV == 64 || (DS2_ATTN_ILV256 && DV == 256));
   // ONE LDS array addressed by byte offsets (with separate typed arrays hipcc waits for every pending LDS-DMA before a ds_read
   // that might alias it): K buffer b, plane p at KP(b, p, 0); V^T buffers behind them
   constexpr int KNP = KLO ? 2 : 1, VOFF = 2 * KNP * KPLANE;
