@@ -63,6 +63,9 @@ __device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, 
 #define DS2_ATTN_ILV 1
 #endif
 // DS2_ATTN_DMA (ILV instantiation): tiles staged by LDS-DMA into swizzled LDS images instead of through registers
+#ifndef DS2_ATTN_RING4
+#define DS2_ATTN_RING4 1
+#endif
 #ifndef DS2_ATTN_ILV256
 #define DS2_ATTN_ILV256 0
 #endif
@@ -187,14 +190,17 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   // independent of that VALU work, so the matrix pipe runs under the exponentials instead of idling (K is staged one tile
   // ahead of V for this; two score register sets).  (Tried before and left out: running waves 4-7 half a tile behind waves
   // 0-3 with three V buffers - bit-identical but 4 % slower, profiles/r02an_ab_stag.txt.)
-  constexpr int NVB = 2, VPL = (DV == 256 && !KLO) ? 1 : 2;
+  constexpr int VPL = (DV == 256 && !KLO) ? 1 : 2;
   // (DV = 256, the self-attention, keeps the compiler's own order: with 64 accumulator registers on top the interleaved
   // schedule spills the staged K rows to scratch inside the loop - measured 1.39 -> 1.89 ms/frame)
   constexpr bool ILV = DS2_ATTN_ILV && !KLO && (DV == 64 || (DS2_ATTN_ILV256 && DV == 256));
   // ONE LDS array addressed by byte offsets (with separate typed arrays hipcc waits for every pending LDS-DMA before a ds_read
   // that might alias it): K buffer b, plane p at KP(b, p, 0); V^T buffers behind them
-  constexpr int KNP = KLO ? 2 : 1, VOFF = 2 * KNP * KPLANE;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * KNP * KPLANE + NVB * VPL * VPLANE];
+  // RING = tile slots per operand: tile j lives in slot j % RING.  2 = double buffer, one barrier per tile.  4 (DMA-staged
+  // cross-attention): the frame-token loop runs TWO tiles per barrier - its copies target the two slots the pair does not read.
+  constexpr int RING = (SWZ && ILV && DV == 64 && QG == 2 && DS2_ATTN_RING4) ? 4 : 2, NVB = RING;
+  constexpr int KNP = KLO ? 2 : 1, VOFF = RING * KNP * KPLANE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[RING * KNP * KPLANE + NVB * VPL * VPLANE];
 #define KP(b_, p_, off_) (lds + ((b_) * KNP + (p_)) * KPLANE + (off_))
 #define VP(b_, p_, off_) (lds + VOFF + ((b_) * VPL + (p_)) * VPLANE + (off_))
 
@@ -487,6 +493,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   W8_STORE_V(0, 0)
   W8_LOAD_K(nkt > 1 ? 1 : 0)
   W8_STORE_K(1)
+  if constexpr (RING == 4) {   // the first pair also reads K(2) and V^T(1)
+    W8_LOAD_K(nkt > 2 ? 2 : nkt - 1)
+    W8_LOAD_V(nkt > 1 ? 1 : 0)
+    W8_STORE_K(2)
+    W8_STORE_V(1, (nkt > 1 ? 1 : 0))
+  }
   __syncthreads();
   // one iteration: [global loads of K(kt+2), V(kt+1)] [scores of tile kt+1 -> nxt] [softmax + P.V of tile kt <- cur] [stage] [barrier]
   // (the scores of a tile past the end are computed on the clamped K buffer and ignored: no branch inside the block)
@@ -523,22 +535,40 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     const int kt_s = (KT);                                                    \
     constexpr bool dma_ = SWZ && !std::remove_reference_t<decltype(MT)>::value && !(DS2_ABL & 4); \
     if constexpr (dma_) {                                                     \
-      W8_DMA_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1, kt_s & 1)                 \
-      W8_DMA_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, (kt_s + 1) & 1)           \
+      W8_DMA_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1, (kt_s + 2) & (RING - 1))  \
+      W8_DMA_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, (kt_s + 1) & (RING - 1))  \
     } else if constexpr (!(DS2_ABL & 4)) {                                    \
     W8_LOAD_K(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1)                            \
     W8_LOAD_V(kt_s + 1 < nkt ? kt_s + 1 : nkt - 1)                            \
     }                                                                         \
     if constexpr (ILV) __builtin_amdgcn_sched_barrier(0);   /* the global loads leave first, not at the end of the pipeline */ \
-    scores(MT, (kt_s + 1) & 1, kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, N0, N1);  \
-    softmax_pv(LT, kt_s & 1, kt_s, C0, C1);                                   \
+    scores(MT, (kt_s + 1) & (RING - 1), kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, N0, N1); \
+    softmax_pv(LT, kt_s & (RING - 1), kt_s, C0, C1);                          \
     if constexpr (dma_) {                                                     \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
     } else if constexpr (!(DS2_ABL & 4)) {                                    \
-    W8_STORE_K(kt_s & 1)                                                      \
-    W8_STORE_V((kt_s + 1) & 1, (kt_s + 1 < nkt ? kt_s + 1 : nkt - 1))         \
+    W8_STORE_K((kt_s + 2) & (RING - 1))                                       \
+    W8_STORE_V((kt_s + 1) & (RING - 1), (kt_s + 1 < nkt ? kt_s + 1 : nkt - 1)) \
     }                                                                         \
     if constexpr (!(DS2_ABL & 8)) __syncthreads();                            \
+  }
+  // two tiles per barrier (RING == 4, full tiles, DMA staging): the pair (kt, kt + 1) reads K slots kt+1, kt+2 and V^T slots kt,
+  // kt+1 (mod 4); its copies - K(kt+3), K(kt+4), V^T(kt+2), V^T(kt+3) - land in the other two slots of each ring
+#define W8_STEP2(MT, LT, KT, A0, A1, B0, B1)                                  \
+  {                                                                           \
+    const int kt_s = (KT);                                                    \
+    W8_DMA_K(kt_s + 3 < nkt ? kt_s + 3 : nkt - 1, (kt_s + 3) & 3)             \
+    W8_DMA_K(kt_s + 4 < nkt ? kt_s + 4 : nkt - 1, kt_s & 3)                   \
+    W8_DMA_V(kt_s + 2 < nkt ? kt_s + 2 : nkt - 1, (kt_s + 2) & 3)             \
+    W8_DMA_V(kt_s + 3 < nkt ? kt_s + 3 : nkt - 1, (kt_s + 3) & 3)             \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    scores(MT, (kt_s + 1) & 3, kt_s + 1 < nkt ? kt_s + 1 : nkt - 1, B0, B1);  \
+    softmax_pv(LT, kt_s & 3, kt_s, A0, A1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    scores(MT, (kt_s + 2) & 3, kt_s + 2 < nkt ? kt_s + 2 : nkt - 1, A0, A1);  \
+    softmax_pv(LT, (kt_s + 1) & 3, kt_s + 1, B0, B1);                         \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+    __syncthreads();                                                          \
   }
   const std::true_type maylo{};
   const std::false_type nolo{};
@@ -549,9 +579,13 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     scores(nm, 0, 0, sa0, sa1);
     __syncthreads();   // every wave has read K(0) before iteration 0 overwrites it with K(2)
     int kt = 0;
-    for (; kt < n_fast; kt += 2) {
-      W8_STEP(nm, nolo, kt, sa0, sa1, sb0, sb1)
-      W8_STEP(nm, nolo, kt + 1, sb0, sb1, sa0, sa1)
+    if constexpr (RING == 4) {
+      for (; kt < n_fast; kt += 2) W8_STEP2(nm, nolo, kt, sa0, sa1, sb0, sb1)
+    } else {
+      for (; kt < n_fast; kt += 2) {
+        W8_STEP(nm, nolo, kt, sa0, sa1, sb0, sb1)
+        W8_STEP(nm, nolo, kt + 1, sb0, sb1, sa0, sa1)
+      }
     }
     for (; kt < nkt; kt += 2) {
       W8_STEP(nm, maylo, kt, sa0, sa1, sb0, sb1)
