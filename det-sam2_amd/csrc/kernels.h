@@ -126,6 +126,7 @@ struct SkinnyArgs {
 int launch_skinny_linear(const SkinnyArgs& g, hipStream_t st);
 int launch_mask_up_conv1(const float* low, int hin, int Hin, int mode, float scale, float mbias, const float* w, const float* bias,
                          const float* lnw, const float* lnb, float* out, int B, hipStream_t st);
+int launch_im2col3x3s2_split(const float* in, void* hi, void* lo, int ldp, int B, int Hin, int Cin, hipStream_t st);
 int launch_bcast_rows(const float* x, float* out, int n, int B, hipStream_t st);
 int launch_transpose_w(const float* W, int ldw, int N, int K, float* Wt, hipStream_t st);
 

@@ -527,6 +527,34 @@ __global__ void k_im2col3x3s2(const float* in, float* out, int B, int Hin, int C
   *reinterpret_cast<float4*>(out + (((size_t)b * Ho + oy) * Ho + ox) * 9 * Cin + tap * Cin + c4 * 4) = v;
 }
 
+// The same im2col emitted directly as the consumer GEMM's bf16 operand planes [rows, ldp] (the split of k_split_rows, element for
+// element): the GEMM then needs no operand-split pre-pass over the 151 MB column matrix.  Columns 9 Cin .. ldp (the K padding to a
+// multiple of 32) are written as zeros by the threads of a tenth "tap".
+__global__ void k_im2col3x3s2_split(const float* __restrict__ in, uint2* __restrict__ hi, uint2* __restrict__ lo, int ldp, int B, int Hin,
+                                    int Cin) {
+  const int Ho = Hin / 2, c4n = Cin / 4, ntap = ldp > 9 * Cin ? 10 : 9;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Ho * Ho * ntap * c4n) return;
+  const int c4 = (int)(i % c4n);
+  size_t r = i / c4n;
+  const int tap = (int)(r % ntap); r /= ntap;
+  const int col = tap * Cin + c4 * 4;
+  if (col >= ldp) return;
+  const int ox = (int)(r % Ho), oy = (int)((r / Ho) % Ho), b = (int)(r / ((size_t)Ho * Ho));
+  const int iy = 2 * oy - 1 + tap / 3, ix = 2 * ox - 1 + tap % 3;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tap < 9 && iy >= 0 && iy < Hin && ix >= 0 && ix < Hin)
+    v = *reinterpret_cast<const float4*>(in + (((size_t)b * Hin + iy) * Hin + ix) * Cin + c4 * 4);
+  uint2 h, l;
+  h.x = ln_cvt_pk_bf16(v.x, v.y);
+  h.y = ln_cvt_pk_bf16(v.z, v.w);
+  l.x = ln_cvt_pk_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+  l.y = ln_cvt_pk_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+  const size_t o = ((((size_t)b * Ho + oy) * Ho + ox) * ldp + col) / 4;
+  hi[o] = h;
+  lo[o] = l;
+}
+
 // CXBlock depth-wise 7x7 / pad 3 (memory_encoder.py:86-92), NHWC, weights repacked [49][C].
 // One thread = 8 consecutive output pixels of one row for one channel: each input row segment (14 values) is loaded
 // once and feeds all 8 outputs (4x fewer loads than one output per thread); lanes run along C (coalesced).
@@ -1060,6 +1088,14 @@ int launch_conv3x3s2_small(const float* in, const float* w, const float* bias, c
 int launch_im2col3x3s2(const float* in, float* out, int B, int Hin, int Cin, hipStream_t st) {
   DS2_REQUIRE(Cin % 4 == 0, "im2col3x3s2: Cin must be a multiple of 4");
   hipLaunchKernelGGL(k_im2col3x3s2, grid1((size_t)B * (Hin / 2) * (Hin / 2) * 9 * (Cin / 4)), dim3(256), 0, st, in, out, B, Hin, Cin);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_im2col3x3s2_split(const float* in, void* hi, void* lo, int ldp, int B, int Hin, int Cin, hipStream_t st) {
+  DS2_REQUIRE(Cin % 4 == 0 && ldp % 4 == 0 && ldp >= 9 * Cin && ldp - 9 * Cin <= Cin, "im2col3x3s2_split: bad plane pitch");
+  const int ntap = ldp > 9 * Cin ? 10 : 9;
+  hipLaunchKernelGGL(k_im2col3x3s2_split, grid1((size_t)B * (Hin / 2) * (Hin / 2) * ntap * (Cin / 4)), dim3(256), 0, st, in,
+                     reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), ldp, B, Hin, Cin);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

@@ -1346,14 +1346,30 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   ALLOC(c2, (size_t)B * 65536 * 16);
   TRY(launch_conv3x3s2_small(c1, m->P(ds + "3.weight"), m->P(ds + "3.bias"), m->P(ds + "4.weight"), m->P(ds + "4.bias"), c2, B,
                              512, 4, 16, st));
+  // im2col matrices feed one GEMM each: in the split modes they are written as its operand planes directly (no fp32 matrix, no
+  // operand-split pre-pass over 151 MB; DS2_ME_COL_PLANES=0: fp32 + pre-pass, bit-identical)
+  static const bool col_planes = [] { const char* e = getenv("DS2_ME_COL_PLANES"); return !e || atoi(e) != 0; }();
+  auto im2col = [&](const float* in, float* col, int Hin, int Cin) -> int {
+    const int rows_c = B * (Hin / 2) * (Hin / 2), K = 9 * Cin;
+    if (col_planes && ds2_split_mode()) {
+      ds2_model::ActPlanes cp;
+      cp.ld = round32i(K);
+      cp.hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows_c * cp.ld * 2));
+      cp.lo = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows_c * cp.ld * 2));
+      if (!cp.hi || !cp.lo) { ds2_set_error("memory_encoder: workspace exhausted (im2col planes)"); return DS2_ERR_STATE; }
+      m->act_planes[col] = cp;
+      return launch_im2col3x3s2_split(in, cp.hi, cp.lo, cp.ld, B, Hin, Cin, st);
+    }
+    return launch_im2col3x3s2(in, col, B, Hin, Cin, st);
+  };
   ALLOC(col3, (size_t)B * 16384 * 144);
-  TRY(launch_im2col3x3s2(c2, col3, B, 256, 16, st));
+  TRY(im2col(c2, col3, 256, 16));
   ALLOC(g3, (size_t)B * 16384 * 64);
   TRY(gemm(st, B * 16384, 64, 144, col3, 144, m->P("@mds6_w"), 144, m->P(ds + "6.bias"), g3, 64, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(c3, (size_t)B * 16384 * 64);
   TRY(layernorm(m, st, ds + "7", g3, c3, B * 16384, 64, 1e-6f, DS2_ACT_GELU));
   ALLOC(col4, (size_t)rows * 576);
-  TRY(launch_im2col3x3s2(c3, col4, B, 128, 64, st));
+  TRY(im2col(c3, col4, 128, 64));
   ALLOC(g4, (size_t)rows * 256);
   TRY(gemm(st, rows, 256, 576, col4, 576, m->P("@mds9_w"), 576, m->P(ds + "9.bias"), g4, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(c4, (size_t)rows * 256);
