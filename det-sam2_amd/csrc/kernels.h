@@ -32,6 +32,13 @@ int launch_memfeat_finish(const float* feat, const float* obj_logits, const floa
 // keys[b,tok,:] = src[(b,)tok,:] + mask_downscaling(mask[b]) ; prm = {w0,b0,ln1w,ln1b,w3,b3,ln4w,ln4b,w6,b6}
 int launch_mask_downscale_add(const float* mask, const float* const* prm, const float* src, int src_bcast, float* keys, int B,
                               hipStream_t st);
+struct Mlp3Job {
+  const float *A, *w0, *b0, *w1, *b1, *w2, *b2;
+  float* out;
+  int lda, n_out, ldc, last_act;
+};
+struct Mlp3Batch { Mlp3Job job[8]; };
+int launch_mlp3_256_batch(const Mlp3Batch& jb, int n_jobs, int rows, hipStream_t st);   // several 3-layer MLPs, one launch
 int launch_mlp3_256(const float* A, int lda, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
                     const float* b2, int n_out, float* out, int ldc, int last_act, int rows, hipStream_t st);
 int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4, const float* not_a_point,
@@ -161,6 +168,8 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
                                                                                 // V lo plane unless *vlo_flag != 0
 
 // producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)
+int launch_layernorm_add(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, const float* add, float* y2,
+                         int rows, int C, float eps, hipStream_t st);   // y = LN(x), y2 = y + add
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
                            int C, float eps, int act, hipStream_t st);
 int launch_add_bcast_split(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, void* hi, void* lo,

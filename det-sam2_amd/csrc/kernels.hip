@@ -105,7 +105,9 @@ template <int NV, bool SPLIT>
 __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* __restrict__ y, int ldy,
                                                        uint2* __restrict__ hi, uint2* __restrict__ lo, int ldp, int rows, int C,
-                                                       float eps, int act) {
+                                                       float eps, int act, const float* __restrict__ add = nullptr,
+                                                       float* __restrict__ y2 = nullptr) {
+  // (add / y2, fp32 output only: y2 = y + add, same leading dimension as y - the "queries + query_pe" of the two-way transformer)
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ldx;
@@ -150,6 +152,10 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
       }
     } else if (c < C) {
       *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
+      if (y2) {
+        const float4 a4 = *reinterpret_cast<const float4*>(add + (size_t)row * ldy + c);
+        *reinterpret_cast<float4*>(y2 + (size_t)row * ldy + c) = make_float4(o.x + a4.x, o.y + a4.y, o.z + a4.z, o.w + a4.w);
+      }
     }
   }
 }
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
 #endif
 template <bool SPLIT>
 static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, void* hi, void* lo,
-                                 int ldp, int rows, int C, float eps, int act, hipStream_t st) {
+                                 int ldp, int rows, int C, float eps, int act, hipStream_t st, const float* add = nullptr,
+                                 float* y2 = nullptr) {
   const int width = SPLIT ? ldp : C;
   const bool ok = C % 4 == 0 && ldx % 4 == 0 && (SPLIT || ldy % 4 == 0) && width <= 5 * 256 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
@@ -170,7 +177,7 @@ static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const 
   uint2* h2 = reinterpret_cast<uint2*>(hi);
   uint2* l2 = reinterpret_cast<uint2*>(lo);
 #define DS2_LN_CASE(N) \
-  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act); break;
+  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act, add, y2); break;
   switch (nv) {
     DS2_LN_CASE(1) DS2_LN_CASE(2) DS2_LN_CASE(3) DS2_LN_CASE(4) DS2_LN_CASE(5)
     default: return false;
@@ -184,13 +191,12 @@ static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const 
 // tracked frame, i.e. 21 tile GEMMs + 21 operand splits of ~10 us each when done as GEMMs.  One block per row, the
 // activations stay in LDS; a wave owns output features j and its lanes split the 256-long dot product (16-byte
 // coalesced weight reads, butterfly reduction).  Exact fp32 FMA.
-__global__ __launch_bounds__(512) void k_mlp3_256(const float* __restrict__ A, int lda, const float* __restrict__ w0,
-                                                  const float* __restrict__ b0, const float* __restrict__ w1,
-                                                  const float* __restrict__ b1, const float* __restrict__ w2,
-                                                  const float* __restrict__ b2, int n_out, float* __restrict__ out, int ldc,
-                                                  int last_act) {
-  __shared__ __attribute__((aligned(16))) float x[2][256];
-  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+__device__ __forceinline__ void mlp3_256_row(float (&x)[2][256], int row, const float* __restrict__ A, int lda,
+                                             const float* __restrict__ w0, const float* __restrict__ b0,
+                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                             const float* __restrict__ w2, const float* __restrict__ b2, int n_out,
+                                             float* __restrict__ out, int ldc, int last_act) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 256) x[0][t] = A[(size_t)row * lda + t];
   __syncthreads();
 #pragma unroll 1
@@ -224,6 +230,22 @@ __global__ __launch_bounds__(512) void k_mlp3_256(const float* __restrict__ A, i
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(512) void k_mlp3_256(const float* __restrict__ A, int lda, const float* __restrict__ w0,
+                                                  const float* __restrict__ b0, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, int n_out, float* __restrict__ out, int ldc,
+                                                  int last_act) {
+  __shared__ __attribute__((aligned(16))) float x[2][256];
+  mlp3_256_row(x, blockIdx.x, A, lda, w0, b0, w1, b1, w2, b2, n_out, out, ldc, last_act);
+}
+// Several independent MLPs over the same number of rows in ONE launch (blockIdx.y = the MLP): the six heads that read the
+// decoder's output tokens (4 hypernetworks, IoU, object score) - same arithmetic per row as k_mlp3_256.
+__global__ __launch_bounds__(512) void k_mlp3_256_batch(Mlp3Batch jb) {
+  __shared__ __attribute__((aligned(16))) float x[2][256];
+  const Mlp3Job& j = jb.job[blockIdx.y];
+  mlp3_256_row(x, blockIdx.x, j.A, j.lda, j.w0, j.b0, j.w1, j.b1, j.w2, j.b2, j.n_out, j.out, j.ldc, j.last_act);
 }
 
 // ------------------------------------------------------------------ simple elementwise
@@ -964,6 +986,19 @@ int launch_layernorm(const float* x, int ldx, const float* w, const float* b, fl
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
+// y = LayerNorm(x), y2 = y + add (all three with leading dimension ldy): one launch for "norm, then + positional encoding"
+int launch_layernorm_add(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, const float* add, float* y2,
+                         int rows, int C, float eps, hipStream_t st) {
+  DS2_REQUIRE(rows > 0 && C > 0 && add && y2, "layernorm_add: bad argument");
+  const bool aligned = ((reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(y2)) & 15) == 0;
+  if (aligned && launch_layernorm_vec<false>(x, ldx, w, b, y, ldy, nullptr, nullptr, 0, rows, C, eps, DS2_ACT_NONE, st, add, y2)) {
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
+  const int rc = launch_layernorm(x, ldx, w, b, y, ldy, rows, C, eps, DS2_ACT_NONE, st);
+  if (rc != DS2_OK) return rc;
+  return launch_add_bcast(y, ldy, add, ldy, 0, 1.f, y2, ldy, rows, C, st);
+}
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
                            int C, float eps, int act, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && C > 0 && ldp % 32 == 0 && ldp >= C, "layernorm_split: bad dims");
@@ -1196,6 +1231,17 @@ int launch_mask_downscale_add(const float* mask, const float* const* prm, const 
                               hipStream_t st) {
   MaskDownArgs a{prm[0], prm[1], prm[2], prm[3], prm[4], prm[5], prm[6], prm[7], prm[8], prm[9]};
   hipLaunchKernelGGL(k_mask_downscale_add, dim3(4096, B), dim3(256), 0, st, mask, a, src, src_bcast, keys);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
+int launch_mlp3_256_batch(const Mlp3Batch& jb, int n_jobs, int rows, hipStream_t st) {
+  DS2_REQUIRE(rows > 0 && n_jobs > 0 && n_jobs <= 8, "mlp3 batch: bad argument");
+  for (int i = 0; i < n_jobs; ++i) {
+    const Mlp3Job& j = jb.job[i];
+    DS2_REQUIRE(j.A && j.out && j.n_out > 0 && j.n_out <= 256 && j.w0 && j.b0 && j.w1 && j.b1 && j.w2 && j.b2, "mlp3 batch: bad job %d", i);
+  }
+  hipLaunchKernelGGL(k_mlp3_256_batch, dim3(rows, n_jobs), dim3(512), 0, st, jb);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

@@ -1112,6 +1112,15 @@ namespace {
 // keys + key_pe (transformer.py:196-197,211) whose only consumers are projection GEMMs: in bf16x3 mode it is emitted
 // directly as operand planes registered under `kpe` (one pass, re-used by every GEMM that reads it) instead of an fp32
 // tensor that each GEMM would split again.
+#ifndef DS2_MLP3_FUSED
+#define DS2_MLP3_FUSED 1
+#endif
+#ifndef DS2_HEADS_LN_PE
+#define DS2_HEADS_LN_PE 1
+#endif
+#ifndef DS2_HEADS_BATCHED
+#define DS2_HEADS_BATCHED 1
+#endif
 #ifndef DS2_KPE_PLANES
 #define DS2_KPE_PLANES 1
 #endif
@@ -1147,9 +1156,6 @@ int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int
 }
 int mlp3(ds2_model* m, hipStream_t st, const std::string& p, int M, const float* A, int lda, int hidden, int n_out, float* out,
          int ldc, int last_act) {
-#ifndef DS2_MLP3_FUSED
-#define DS2_MLP3_FUSED 1
-#endif
   if (DS2_MLP3_FUSED && hidden == 256 && M <= 64 && n_out <= 256)   // one launch, exact fp32 (kernels.hip k_mlp3_256)
     return launch_mlp3_256(A, lda, m->P(p + ".layers.0.weight"), m->P(p + ".layers.0.bias"), m->P(p + ".layers.1.weight"),
                            m->P(p + ".layers.1.bias"), m->P(p + ".layers.2.weight"), m->P(p + ".layers.2.bias"), n_out, out, ldc,
@@ -1238,6 +1244,17 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   ALLOC(hid, (size_t)B * T * 2048);
   const float* dense_pe = m->P("#dense_pe");
   const int BT = B * T;
+  // queries = LayerNorm(tmpq); qpe = queries + query_pe (transformer.py:199-201,207-208) - one launch
+  auto norm_pe = [&](const std::string& name) -> int {
+    if (!DS2_HEADS_LN_PE) {
+      TRY(layernorm(m, st, name, tmpq, queries, BT, 256, 1e-5f));
+      return launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st);
+    }
+    const float* w = m->P(name + ".weight");
+    const float* b = m->P(name + ".bias");
+    if (!w || !b) { ds2_set_error("missing parameter '%s'", name.c_str()); return DS2_ERR_STATE; }
+    return launch_layernorm_add(tmpq, 256, w, b, queries, 256, tokens, qpe, BT, 256, 1e-5f, st);
+  };
   // TwoWayTransformer (transformer.py:91-131) with TwoWayAttentionBlock (:182-215)
   for (int l = 0; l < 2; ++l) {
     const std::string p = tr + ".layers." + std::to_string(l);
@@ -1245,25 +1262,24 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
     if (l == 0) {   // skip_first_layer_pe: queries = self_attn(q=k=v=queries), no residual
       TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qsrc, qsrc, qsrc, tmpq, nullptr));
     } else {
-      TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+      if (!DS2_HEADS_LN_PE) TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+      // (DS2_HEADS_LN_PE: qpe = queries + query_pe was written with norm3 of the previous layer; queries are unchanged since)
       TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qpe, qpe, queries, tmpq, queries));
     }
-    TRY(layernorm(m, st, p + ".norm1", tmpq, queries, BT, 256, 1e-5f));
     // tokens -> image
-    TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+    TRY(norm_pe(p + ".norm1"));
     TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
     TRY(sam_attention(m, st, p + ".cross_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
     TRY(layernorm(m, st, p + ".norm2", tmpq, queries, BT, 256, 1e-5f));
     // MLP
     TRY(linear(m, st, p + ".mlp.layers.0", BT, 2048, 256, queries, 256, hid, 2048, DS2_ACT_RELU));
     TRY(linear(m, st, p + ".mlp.layers.1", BT, 256, 2048, hid, 2048, tmpq, 256, DS2_ACT_NONE, queries, 256));
-    TRY(layernorm(m, st, p + ".norm3", tmpq, queries, BT, 256, 1e-5f));
     // image -> tokens
-    TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+    TRY(norm_pe(p + ".norm3"));
     TRY(sam_attention(m, st, p + ".cross_attn_image_to_token", B, TOK, T, 128, kpe, qpe, queries, tmpk, keys));
     TRY(layernorm(m, st, p + ".norm4", tmpk, keys, rows, 256, 1e-5f));
   }
-  TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
+  if (!DS2_HEADS_LN_PE) TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
   TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
   TRY(sam_attention(m, st, tr + ".final_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
   float* hs = queries;
@@ -1276,14 +1292,31 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   ALLOC(g2, (size_t)B * 16384 * 128);
   TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(hyper, (size_t)B * 128);
-  for (int i = 0; i < 4; ++i)
-    TRY(mlp3(m, st, md + ".output_hypernetworks_mlps." + std::to_string(i), B, hs + (2 + i) * 256, T * 256, 256, 32,
-             hyper + i * 32, 128, DS2_ACT_NONE));
+  ALLOC(iou4, (size_t)B * 4);
+  const bool heads_batched = DS2_MLP3_FUSED && DS2_HEADS_BATCHED && B <= 64;
+  if (heads_batched) {   // the six MLPs that read the output tokens (4 hypernetworks, IoU, object score) as ONE launch
+    Mlp3Batch jb{};
+    auto job = [&](int i, const std::string& p, const float* A, int n_out, float* out, int ldc, int last_act) {
+      jb.job[i] = Mlp3Job{A, m->P(p + ".layers.0.weight"), m->P(p + ".layers.0.bias"), m->P(p + ".layers.1.weight"),
+                          m->P(p + ".layers.1.bias"), m->P(p + ".layers.2.weight"), m->P(p + ".layers.2.bias"), out,
+                          T * 256, n_out, ldc, last_act};
+    };
+    for (int i = 0; i < 4; ++i)
+      job(i, md + ".output_hypernetworks_mlps." + std::to_string(i), hs + (2 + i) * 256, 32, hyper + i * 32, 128, DS2_ACT_NONE);
+    job(4, md + ".iou_prediction_head", hs + 256, 4, iou4, 4, DS2_ACT_SIGMOID);
+    job(5, md + ".pred_obj_score_head", hs, 1, obj_logits, 1, DS2_ACT_NONE);
+    TRY(launch_mlp3_256_batch(jb, 6, B, st));
+  } else {
+    for (int i = 0; i < 4; ++i)
+      TRY(mlp3(m, st, md + ".output_hypernetworks_mlps." + std::to_string(i), B, hs + (2 + i) * 256, T * 256, 256, 32,
+               hyper + i * 32, 128, DS2_ACT_NONE));
+  }
   ALLOC(masks4, (size_t)B * 4 * 65536);
   TRY(launch_upscale2_masks(g2, fpn0, hyper, masks4, B, st));
-  ALLOC(iou4, (size_t)B * 4);
-  TRY(mlp3(m, st, md + ".iou_prediction_head", B, hs + 256, T * 256, 256, 4, iou4, 4, DS2_ACT_SIGMOID));
-  TRY(mlp3(m, st, md + ".pred_obj_score_head", B, hs, T * 256, 256, 1, obj_logits, 1, DS2_ACT_NONE));
+  if (!heads_batched) {
+    TRY(mlp3(m, st, md + ".iou_prediction_head", B, hs + 256, T * 256, 256, 4, iou4, 4, DS2_ACT_SIGMOID));
+    TRY(mlp3(m, st, md + ".pred_obj_score_head", B, hs, T * 256, 256, 1, obj_logits, 1, DS2_ACT_NONE));
+  }
   ALLOC(sel_tok, (size_t)B * 256);
   TRY(launch_select_masks(masks4, iou4, obj_logits, hs, T * 256, multimask, m->cfg.dynamic_multimask_stability_delta,
                           m->cfg.dynamic_multimask_stability_thresh, low_res, sel_tok, ious, B, st));
