@@ -170,6 +170,11 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
 // producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)
 int launch_layernorm_add(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, const float* add, float* y2,
                          int rows, int C, float eps, hipStream_t st);   // y = LN(x), y2 = y + add
+int launch_layernorm_add_split(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, const float* add,
+                               int add_mod, void* hi, void* lo, int ldp, int rows, int C, float eps, hipStream_t st,
+                               void* hi0 = nullptr, void* lo0 = nullptr);
+int launch_sam_keys_init(const float* src, int src_mod, const float* vec, const float* pe, int pe_mod, float* keys, void* khi,
+                         void* klo, void* phi, void* plo, int rows, hipStream_t st);
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
                            int C, float eps, int act, hipStream_t st);
 int launch_add_bcast_split(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, void* hi, void* lo,

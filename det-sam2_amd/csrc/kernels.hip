@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
                                                        const float* __restrict__ b, float* __restrict__ y, int ldy,
                                                        uint2* __restrict__ hi, uint2* __restrict__ lo, int ldp, int rows, int C,
                                                        float eps, int act, const float* __restrict__ add = nullptr,
-                                                       float* __restrict__ y2 = nullptr) {
-  // (add / y2, fp32 output only: y2 = y + add, same leading dimension as y - the "queries + query_pe" of the two-way transformer)
+                                                       float* __restrict__ y2 = nullptr, int add_mod = 0,
+                                                       uint2* __restrict__ hi0 = nullptr, uint2* __restrict__ lo0 = nullptr) {
+  // add (row stride ldy, row index modulo add_mod when > 0): a second result y + add - as fp32 y2 (!SPLIT: the "queries +
+  // query_pe" of the two-way transformer) or as THE operand planes (SPLIT: "keys + key_pe"; y, when given, still gets LN(x))
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * ldx;
@@ -141,6 +143,20 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
       o.w = ds2_act((v[i].w - mean) * rstd * w4.w + b4.w, act);
     }
     if (SPLIT) {
+      if (y && c < C) *reinterpret_cast<float4*>(y + (size_t)row * ldy + c) = o;
+      if (hi0 && c < ldp) {   // (hi0 / lo0: the planes of LN(x) itself, next to those of LN(x) + add)
+        uint2 h, l;
+        h.x = ln_cvt_pk_bf16(o.x, o.y);
+        h.y = ln_cvt_pk_bf16(o.z, o.w);
+        l.x = ln_cvt_pk_bf16(o.x - __uint_as_float(h.x << 16), o.y - __uint_as_float(h.x & 0xffff0000u));
+        l.y = ln_cvt_pk_bf16(o.z - __uint_as_float(h.y << 16), o.w - __uint_as_float(h.y & 0xffff0000u));
+        hi0[(size_t)row * (ldp / 4) + (c >> 2)] = h;
+        lo0[(size_t)row * (ldp / 4) + (c >> 2)] = l;
+      }
+      if (add && c < C) {
+        const float4 a4 = *reinterpret_cast<const float4*>(add + (size_t)(add_mod > 0 ? row % add_mod : row) * ldy + c);
+        o = make_float4(o.x + a4.x, o.y + a4.y, o.z + a4.z, o.w + a4.w);
+      }
       if (c < ldp) {   // columns C..ldp are zero in both planes
         uint2 h, l;
         h.x = ln_cvt_pk_bf16(o.x, o.y);
@@ -166,18 +182,19 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
 template <bool SPLIT>
 static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, void* hi, void* lo,
                                  int ldp, int rows, int C, float eps, int act, hipStream_t st, const float* add = nullptr,
-                                 float* y2 = nullptr) {
+                                 float* y2 = nullptr, int add_mod = 0, void* hi0 = nullptr, void* lo0 = nullptr) {
   const int width = SPLIT ? ldp : C;
-  const bool ok = C % 4 == 0 && ldx % 4 == 0 && (SPLIT || ldy % 4 == 0) && width <= 5 * 256 &&
+  const bool ok = C % 4 == 0 && ldx % 4 == 0 && ((SPLIT && !y && !add) || ldy % 4 == 0) && width <= 5 * 256 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
-                  (reinterpret_cast<uintptr_t>(b) & 15) == 0 && (SPLIT || (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+                  (reinterpret_cast<uintptr_t>(b) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(add) & 15) == 0 && (reinterpret_cast<uintptr_t>(y2) & 15) == 0;
   if (!ok || !DS2_LN_VEC) return false;
   const int nv = (width + 255) / 256;
   const dim3 grid(cdiv(rows, 4)), blk(256);
   uint2* h2 = reinterpret_cast<uint2*>(hi);
   uint2* l2 = reinterpret_cast<uint2*>(lo);
 #define DS2_LN_CASE(N) \
-  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act, add, y2); break;
+  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act, add, y2, add_mod, reinterpret_cast<uint2*>(hi0), reinterpret_cast<uint2*>(lo0)); break;
   switch (nv) {
     DS2_LN_CASE(1) DS2_LN_CASE(2) DS2_LN_CASE(3) DS2_LN_CASE(4) DS2_LN_CASE(5)
     default: return false;
@@ -998,6 +1015,56 @@ int launch_layernorm_add(const float* x, int ldx, const float* w, const float* b
   const int rc = launch_layernorm(x, ldx, w, b, y, ldy, rows, C, eps, DS2_ACT_NONE, st);
   if (rc != DS2_OK) return rc;
   return launch_add_bcast(y, ldy, add, ldy, 0, 1.f, y2, ldy, rows, C, st);
+}
+// y = LayerNorm(x) (fp32, leading dimension ldy) AND the operand planes of y + add[row % add_mod] (add: row stride ldy)
+// (hi0 / lo0, optional: the planes of y itself as well)
+int launch_layernorm_add_split(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, const float* add,
+                               int add_mod, void* hi, void* lo, int ldp, int rows, int C, float eps, hipStream_t st, void* hi0,
+                               void* lo0) {
+  DS2_REQUIRE(rows > 0 && C > 0 && ldp % 32 == 0 && ldp >= C && y && add && hi && lo && !hi0 == !lo0, "layernorm_add_split: bad argument");
+  if (launch_layernorm_vec<true>(x, ldx, w, b, y, ldy, hi, lo, ldp, rows, C, eps, DS2_ACT_NONE, st, add, nullptr, add_mod, hi0, lo0)) {
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
+  int rc = launch_layernorm(x, ldx, w, b, y, ldy, rows, C, eps, DS2_ACT_NONE, st);
+  if (rc != DS2_OK) return rc;
+  if (hi0 && (rc = launch_split_rows(y, ldy, rows, C, hi0, lo0, ldp, st)) != DS2_OK) return rc;
+  return launch_add_bcast_split(y, ldy, add, ldy, add_mod, 1.f, hi, lo, ldp, rows, C, st);
+}
+// SAM decoder entry: keys = src[(row % src_mod)] + vec (fp32 + operand planes) and the planes of keys + pe[row % pe_mod]
+// (mask_decoder.py:203, transformer.py:196-197) in one pass; C = ldp = 256
+__global__ __launch_bounds__(256) void k_sam_keys_init(const float* __restrict__ src, int src_mod, const float* __restrict__ vec,
+                                                       const float* __restrict__ pe, int pe_mod, float* __restrict__ keys,
+                                                       uint2* __restrict__ khi, uint2* __restrict__ klo, uint2* __restrict__ phi,
+                                                       uint2* __restrict__ plo, int rows) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4
+  if (i >= (size_t)rows * 64) return;
+  const int row = (int)(i >> 6), c = (int)(i & 63) * 4;
+  const float4 s4 = *reinterpret_cast<const float4*>(src + (size_t)(src_mod > 0 ? row % src_mod : row) * 256 + c);
+  const float4 v4 = *reinterpret_cast<const float4*>(vec + c);
+  const float4 p4 = *reinterpret_cast<const float4*>(pe + (size_t)(pe_mod > 0 ? row % pe_mod : row) * 256 + c);
+  const float4 k = make_float4(s4.x + v4.x, s4.y + v4.y, s4.z + v4.z, s4.w + v4.w);
+  *reinterpret_cast<float4*>(keys + (size_t)row * 256 + c) = k;
+  auto split4 = [](const float4& o, uint2& h, uint2& l) {
+    h.x = ln_cvt_pk_bf16(o.x, o.y);
+    h.y = ln_cvt_pk_bf16(o.z, o.w);
+    l.x = ln_cvt_pk_bf16(o.x - __uint_as_float(h.x << 16), o.y - __uint_as_float(h.x & 0xffff0000u));
+    l.y = ln_cvt_pk_bf16(o.z - __uint_as_float(h.y << 16), o.w - __uint_as_float(h.y & 0xffff0000u));
+  };
+  uint2 h, l;
+  split4(k, h, l);
+  khi[i] = h; klo[i] = l;
+  split4(make_float4(k.x + p4.x, k.y + p4.y, k.z + p4.z, k.w + p4.w), h, l);
+  phi[i] = h; plo[i] = l;
+}
+int launch_sam_keys_init(const float* src, int src_mod, const float* vec, const float* pe, int pe_mod, float* keys, void* khi,
+                         void* klo, void* phi, void* plo, int rows, hipStream_t st) {
+  DS2_REQUIRE(rows > 0 && src && vec && pe && keys && khi && klo && phi && plo, "sam_keys_init: bad argument");
+  hipLaunchKernelGGL(k_sam_keys_init, grid1((size_t)rows * 64), dim3(256), 0, st, src, src_mod, vec, pe, pe_mod, keys,
+                     reinterpret_cast<uint2*>(khi), reinterpret_cast<uint2*>(klo), reinterpret_cast<uint2*>(phi),
+                     reinterpret_cast<uint2*>(plo), rows);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
 }
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
                            int C, float eps, int act, hipStream_t st) {

@@ -654,6 +654,51 @@ extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
       DS2_CHECK_HIP(hipMemcpyAsync(b2 + j * 32, m->P("sam_mask_decoder.output_upscaling.3.bias"), 32 * 4, hipMemcpyDeviceToDevice, st));
     }
   }
+  // two-way transformer: within a block keys + key_pe feeds k_proj of the token->image attention AND q_proj of the image->token
+  // attention (transformer.py:196-197,211-212): the two [128,256] weights stacked to one [256,256] GEMM operand
+  for (int l = 0; l < 2; ++l) {
+    const std::string p = "sam_mask_decoder.transformer.layers." + std::to_string(l);
+    const std::string a = p + ".cross_attn_token_to_image.k_proj", b = p + ".cross_attn_image_to_token.q_proj";
+    if (m->Pbytes(a + ".weight") != 128 * 256 * 4 || m->Pbytes(b + ".weight") != 128 * 256 * 4 || m->Pbytes(a + ".bias") != 128 * 4 ||
+        m->Pbytes(b + ".bias") != 128 * 4)
+      continue;   // (not the SAM 2 shapes: sam_attention falls back to the separate projections)
+    float *fw, *fb;
+    TRY(m->add_derived("@sam_kq_w." + std::to_string(l), 256 * 256, &fw));
+    TRY(m->add_derived("@sam_kq_b." + std::to_string(l), 256, &fb));
+    DS2_CHECK_HIP(hipMemcpyAsync(fw, m->P(a + ".weight"), 128 * 256 * 4, hipMemcpyDeviceToDevice, st));
+    DS2_CHECK_HIP(hipMemcpyAsync(fw + 128 * 256, m->P(b + ".weight"), 128 * 256 * 4, hipMemcpyDeviceToDevice, st));
+    DS2_CHECK_HIP(hipMemcpyAsync(fb, m->P(a + ".bias"), 128 * 4, hipMemcpyDeviceToDevice, st));
+    DS2_CHECK_HIP(hipMemcpyAsync(fb + 128, m->P(b + ".bias"), 128 * 4, hipMemcpyDeviceToDevice, st));
+  }
+  // ... and the token side: projections that read the same tokens stacked row-wise into one few-row Linear each
+  // (k_skinny_linear: a row's result depends on K only, so stacking is bit-identical)
+  {
+    const std::string t = "sam_mask_decoder.transformer.";
+    auto stack = [&](const std::string& name, std::initializer_list<std::string> parts) -> int {
+      size_t rows = 0;
+      for (const std::string& q : parts) {
+        const size_t wb = m->Pbytes(q + ".weight"), bb = m->Pbytes(q + ".bias");
+        if (!wb || wb % (256 * 4) || bb != wb / 256) return DS2_OK;   // other shapes: the separate projections are used
+        rows += bb / 4;
+      }
+      float *fw, *fb;
+      TRY(m->add_derived(name + "_w", rows * 256, &fw));
+      TRY(m->add_derived(name + "_b", rows, &fb));
+      size_t r = 0;
+      for (const std::string& q : parts) {
+        const size_t n = m->Pbytes(q + ".bias") / 4;
+        DS2_CHECK_HIP(hipMemcpyAsync(fw + r * 256, m->P(q + ".weight"), n * 256 * 4, hipMemcpyDeviceToDevice, st));
+        DS2_CHECK_HIP(hipMemcpyAsync(fb + r, m->P(q + ".bias"), n * 4, hipMemcpyDeviceToDevice, st));
+        r += n;
+      }
+      return DS2_OK;
+    };
+    const std::string l0 = t + "layers.0.", l1 = t + "layers.1.";
+    TRY(stack("@sam_s0_qkv", {l0 + "self_attn.q_proj", l0 + "self_attn.k_proj", l0 + "self_attn.v_proj"}));
+    TRY(stack("@sam_tq.0", {l0 + "cross_attn_image_to_token.k_proj", l1 + "self_attn.q_proj", l1 + "self_attn.k_proj"}));
+    TRY(stack("@sam_tv.0", {l0 + "cross_attn_image_to_token.v_proj", l1 + "self_attn.v_proj"}));
+    TRY(stack("@sam_tq.1", {l1 + "cross_attn_image_to_token.k_proj", t + "final_attn_token_to_image.q_proj"}));
+  }
   // mask-downsampler 3x3 convs as im2col GEMMs: [Cout,Cin,3,3] -> [Cout,(ky,kx,cin)]
   TRY(m->add_derived("@mds6_w", 64 * 144, &w));
   TRY(launch_permute4(m->P("memory_encoder.mask_downsampler.encoder.6.weight"), w, 64, 16, 3, 3, 0, 2, 3, 1, st));
@@ -1115,6 +1160,15 @@ namespace {
 #ifndef DS2_MLP3_FUSED
 #define DS2_MLP3_FUSED 1
 #endif
+#ifndef DS2_HEADS_TOK_STACK
+#define DS2_HEADS_TOK_STACK 1
+#endif
+#ifndef DS2_HEADS_LN_KPE
+#define DS2_HEADS_LN_KPE 1
+#endif
+#ifndef DS2_HEADS_KQ
+#define DS2_HEADS_KQ 1
+#endif
 #ifndef DS2_HEADS_LN_PE
 #define DS2_HEADS_LN_PE 1
 #endif
@@ -1134,19 +1188,39 @@ int keys_plus_pe(ds2_model* m, hipStream_t st, const float* keys, const float* d
   return launch_add_bcast(keys, 256, dense_pe, 256, TOK, 1.f, kpe, 256, rows, 256, st);
 }
 // q_in [B*Lq,256], k_in/v_in [B*Lk,256]; result (+ optional residual R) -> out [B*Lq,256].
+// pre (optional): projections the caller has already computed (stacked GEMMs over a shared input) - pointer + row stride per
+// operand; a null pointer = project here from q_in / k_in / v_in.
+struct SamPre {
+  const float* q = nullptr; int ldq = 0;
+  const float* k = nullptr; int ldk = 0;
+  const float* v = nullptr; int ldv = 0;
+};
 int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int Lq, int Lk, int internal,
-                  const float* q_in, const float* k_in, const float* v_in, float* out, const float* R) {
+                  const float* q_in, const float* k_in, const float* v_in, float* out, const float* R, const SamPre& pre = SamPre()) {
   const size_t mark = m->ws_top;
-  ALLOC(q, (size_t)B * Lq * internal);
-  ALLOC(k, (size_t)B * Lk * internal);
-  ALLOC(v, (size_t)B * Lk * internal);
+  const float *q = pre.q, *k = pre.k, *v = pre.v;
+  if (!q) {
+    ALLOC(qb, (size_t)B * Lq * internal);
+    TRY(linear(m, st, p + ".q_proj", B * Lq, internal, 256, q_in, 256, qb, internal));
+    q = qb;
+  }
+  if (!k) {
+    ALLOC(kb, (size_t)B * Lk * internal);
+    TRY(linear(m, st, p + ".k_proj", B * Lk, internal, 256, k_in, 256, kb, internal));
+    k = kb;
+  }
+  if (!v) {
+    ALLOC(vb, (size_t)B * Lk * internal);
+    TRY(linear(m, st, p + ".v_proj", B * Lk, internal, 256, v_in, 256, vb, internal));
+    v = vb;
+  }
   ALLOC(o, (size_t)B * Lq * internal);
-  TRY(linear(m, st, p + ".q_proj", B * Lq, internal, 256, q_in, 256, q, internal));
-  TRY(linear(m, st, p + ".k_proj", B * Lk, internal, 256, k_in, 256, k, internal));
-  TRY(linear(m, st, p + ".v_proj", B * Lk, internal, 256, v_in, 256, v, internal));
   AttnArgs a{};
   a.q = q; a.k = k; a.v = v; a.o = o;
-  a.ldq = a.ldk = a.ldv = a.ldo = internal;
+  a.ldq = pre.q ? pre.ldq : internal;
+  a.ldk = pre.k ? pre.ldk : internal;
+  a.ldv = pre.v ? pre.ldv : internal;
+  a.ldo = internal;
   a.batch = B; a.heads = 8; a.D = a.DV = internal / 8; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)a.D);
   TRY(launch_attention(a, st));
@@ -1191,8 +1265,8 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   ProfScope _ps("stage.sam_heads", st);
   const int rows = B * TOK;
   const size_t Tmax = 6 + (size_t)(P > 0 ? P : 1) + 1;      // decoder tokens: 6 output tokens + prompt points + the padding point
-  const size_t need = ((size_t)rows * 256 * 8 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * Tmax * (2048 + 256 * 10) * 2) * 4 +
-                      (size_t)3 * rows * 256 * 4 /* key + pe operand planes, one set per use */ + (8u << 20);
+  const size_t need = ((size_t)rows * 256 * 9 + (size_t)B * 16384 * (64 + 128) + (size_t)B * 4 * 65536 + (size_t)B * Tmax * (2048 + 256 * 10 + 1024) * 2) * 4 +
+                      (size_t)6 * rows * 256 * 4 /* keys / keys + pe operand planes, one set per use */ + (8u << 20);
   TRY(m->require(need, st));
   const std::string md = "sam_mask_decoder", tr = md + ".transformer";
   // no prompt => the reference feeds one dummy point labelled -1 (sam2_base.py:298-301)
@@ -1216,6 +1290,9 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
                            1024.f, tokens, st));
   // src = image_embeddings + dense_prompt (no_mask_embed broadcast)  (mask_decoder.py:203)
   ALLOC(keys, (size_t)rows * 256);
+  ALLOC(kpe, (size_t)rows * 256);      // keys + key_pe
+  const float* const kpe_key = kpe;
+  bool kpe_ready = false;              // the planes of keys + key_pe are already written (keys init / the previous norm4)
   const float* src = pix_feat;
   if (pix_bcast && add_no_mem_embed) {   // directly_add_no_mem_embed (sam2_base.py:651-657)
     ALLOC(pm, (size_t)TOK * 256);
@@ -1230,6 +1307,13 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
                             m->P(pe + "6.weight"), m->P(pe + "6.bias")};
     for (int i = 0; i < 10; ++i) DS2_REQUIRE(prm[i], "ds2_sam_heads: mask_downscaling parameter %d missing", i);
     TRY(launch_mask_downscale_add(mask_inputs, prm, src, pix_bcast ? 1 : 0, keys, B, st));
+  } else if (DS2_HEADS_LN_KPE && DS2_KPE_PLANES && ds2_split_mode()) {
+    // keys (fp32 + operand planes: v_proj / the upscaling GEMM read them without a split pre-pass) and the planes of keys + key_pe
+    ds2_model::ActPlanes kp, pp;
+    TRY(new_act_planes(m, keys, rows, 256, &kp, st));
+    TRY(new_act_planes(m, kpe_key, rows, 256, &pp, st));
+    TRY(launch_sam_keys_init(src, pix_bcast ? TOK : 0, m->P("@dense_vec"), m->P("#dense_pe"), TOK, keys, kp.hi, kp.lo, pp.hi, pp.lo, rows, st));
+    kpe_ready = true;
   } else if (pix_bcast) {
     for (int b = 0; b < B; ++b)
       TRY(launch_add_rowvec(src, 256, m->P("@dense_vec"), keys + (size_t)b * TOK * 256, 256, TOK, 256, st));
@@ -1238,9 +1322,9 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   }
   ALLOC(queries, (size_t)B * T * 256);
   ALLOC(qpe, (size_t)B * T * 256);     // queries + query_pe
-  ALLOC(kpe, (size_t)rows * 256);      // keys + key_pe
   ALLOC(tmpq, (size_t)B * T * 256);
   ALLOC(tmpk, (size_t)rows * 256);
+  ALLOC(kq, (size_t)rows * 256);       // [k_proj of token->image | q_proj of image->token] of the current block
   ALLOC(hid, (size_t)B * T * 2048);
   const float* dense_pe = m->P("#dense_pe");
   const int BT = B * T;
@@ -1255,33 +1339,84 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
     if (!w || !b) { ds2_set_error("missing parameter '%s'", name.c_str()); return DS2_ERR_STATE; }
     return launch_layernorm_add(tmpq, 256, w, b, queries, 256, tokens, qpe, BT, 256, 1e-5f, st);
   };
+  // token-side projections stacked per shared input (DS2_HEADS_TOK_STACK): tq = [i2t.k | next self.q | next self.k] resp.
+  // [i2t.k | final.q] of queries + query_pe, tv = [i2t.v | next self.v] of queries, s0 = layer 0's q | k | v of the prompt tokens
+  ALLOC(tq, (size_t)BT * 640);
+  ALLOC(tv, (size_t)BT * 384);
+  auto stacked = [&](const std::string& name, int N, const float* A, float* out, bool* done) -> int {   // *done = false: not available
+    *done = DS2_HEADS_TOK_STACK && m->Pbytes(name + "_w") == (size_t)N * 256 * 4 && m->Pbytes(name + "_b") == (size_t)N * 4;
+    if (!*done) return DS2_OK;   // (Pbytes first: P() of an absent name would flag a missing parameter)
+    const float* w = m->P(name + "_w");
+    return gemm(st, BT, N, 256, A, 256, w, 256, m->P(name + "_b"), out, N, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m);
+  };
+  bool have_tq = false, have_tv = false;   // tq / tv hold the projections of the current queries
   // TwoWayTransformer (transformer.py:91-131) with TwoWayAttentionBlock (:182-215)
   for (int l = 0; l < 2; ++l) {
     const std::string p = tr + ".layers." + std::to_string(l);
-    const float* qsrc = (l == 0) ? tokens : queries;
     if (l == 0) {   // skip_first_layer_pe: queries = self_attn(q=k=v=queries), no residual
-      TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qsrc, qsrc, qsrc, tmpq, nullptr));
+      SamPre sp;
+      bool s0 = false;
+      TRY(stacked("@sam_s0_qkv", 768, tokens, hid, &s0));   // (hid: free until the MLP)
+      if (s0) sp = SamPre{hid, 768, hid + 256, 768, hid + 512, 768};
+      TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, tokens, tokens, tokens, tmpq, nullptr, sp));
     } else {
       if (!DS2_HEADS_LN_PE) TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
       // (DS2_HEADS_LN_PE: qpe = queries + query_pe was written with norm3 of the previous layer; queries are unchanged since)
-      TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qpe, qpe, queries, tmpq, queries));
+      SamPre sp;
+      if (have_tq) { sp.q = tq + 128; sp.ldq = 640; sp.k = tq + 384; sp.ldk = 640; }
+      if (have_tv) { sp.v = tv + 128; sp.ldv = 384; }
+      TRY(sam_attention(m, st, p + ".self_attn", B, T, T, 256, qpe, qpe, queries, tmpq, queries, sp));
     }
     // tokens -> image
     TRY(norm_pe(p + ".norm1"));
-    TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
-    TRY(sam_attention(m, st, p + ".cross_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
+    if (!kpe_ready) TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
+    const float* kq_w = (DS2_HEADS_KQ && m->Pbytes("@sam_kq_w." + std::to_string(l))) ? m->P("@sam_kq_w." + std::to_string(l)) : nullptr;
+    if (kq_w)   // k_proj of this attention and q_proj of the image->token attention below read the same keys + key_pe: one GEMM
+      TRY(gemm(st, rows, 256, 256, kpe, 256, kq_w, 256, m->P("@sam_kq_b." + std::to_string(l)), kq, 256, DS2_ACT_NONE, nullptr, 0, 0,
+               nullptr, true, m));
+    {
+      SamPre sp;
+      if (kq_w) { sp.k = kq; sp.ldk = 256; }
+      TRY(sam_attention(m, st, p + ".cross_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries, sp));
+    }
     TRY(layernorm(m, st, p + ".norm2", tmpq, queries, BT, 256, 1e-5f));
     // MLP
     TRY(linear(m, st, p + ".mlp.layers.0", BT, 2048, 256, queries, 256, hid, 2048, DS2_ACT_RELU));
     TRY(linear(m, st, p + ".mlp.layers.1", BT, 256, 2048, hid, 2048, tmpq, 256, DS2_ACT_NONE, queries, 256));
     // image -> tokens
     TRY(norm_pe(p + ".norm3"));
-    TRY(sam_attention(m, st, p + ".cross_attn_image_to_token", B, TOK, T, 128, kpe, qpe, queries, tmpk, keys));
-    TRY(layernorm(m, st, p + ".norm4", tmpk, keys, rows, 256, 1e-5f));
+    TRY(stacked("@sam_tq." + std::to_string(l), l == 0 ? 640 : 256, qpe, tq, &have_tq));
+    have_tv = false;
+    if (l == 0) TRY(stacked("@sam_tv.0", 384, queries, tv, &have_tv));
+    {
+      SamPre sp;
+      if (kq_w) { sp.q = kq + 128; sp.ldq = 256; }
+      if (have_tq) { sp.k = tq; sp.ldk = l == 0 ? 640 : 256; }
+      if (have_tv) { sp.v = tv; sp.ldv = 384; }
+      TRY(sam_attention(m, st, p + ".cross_attn_image_to_token", B, TOK, T, 128, kpe, qpe, queries, tmpk, keys, sp));
+    }
+    // keys = norm4(...) and, in the same launch, the operand planes of keys + key_pe for the next block / the final attention
+    kpe_ready = false;
+    if (DS2_HEADS_LN_KPE && DS2_KPE_PLANES && ds2_split_mode()) {
+      const float* w4 = m->P(p + ".norm4.weight");
+      const float* b4 = m->P(p + ".norm4.bias");
+      if (!w4 || !b4) { ds2_set_error("missing parameter '%s.norm4'", p.c_str()); return DS2_ERR_STATE; }
+      ds2_model::ActPlanes kp, k0;
+      TRY(new_act_planes(m, kpe, rows, 256, &kp, st));
+      TRY(new_act_planes(m, keys, rows, 256, &k0, st));   // (replaces the registration of the previous keys)
+      TRY(launch_layernorm_add_split(tmpk, 256, w4, b4, keys, 256, dense_pe, TOK, kp.hi, kp.lo, kp.ld, rows, 256, 1e-5f, st, k0.hi, k0.lo));
+      kpe_ready = true;
+    } else {
+      TRY(layernorm(m, st, p + ".norm4", tmpk, keys, rows, 256, 1e-5f));
+    }
   }
   if (!DS2_HEADS_LN_PE) TRY(launch_add_bcast(queries, 256, tokens, 256, 0, 1.f, qpe, 256, BT, 256, st));
-  TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
-  TRY(sam_attention(m, st, tr + ".final_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries));
+  if (!kpe_ready) TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
+  {
+    SamPre sp;
+    if (have_tq) { sp.q = tq + 128; sp.ldq = 256; }   // (queries + query_pe unchanged since norm3 of the last block)
+    TRY(sam_attention(m, st, tr + ".final_attn_token_to_image", B, T, TOK, 128, qpe, kpe, keys, tmpq, queries, sp));
+  }
   float* hs = queries;
   TRY(layernorm(m, st, tr + ".norm_final_attn", tmpq, hs, BT, 256, 1e-5f));
   // upscaling + hypernetworks (mask_decoder.py:216-235)
