@@ -45,7 +45,7 @@ int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const flo
                          const float* coords, const int* labels, int B, int P, float image_size, float* tokens,
                          hipStream_t st);  // tokens [B, 6+P+1, 256]
 int launch_upscale1(const float* g1, const float* feat_s1, const float* lnw, const float* lnb, float* u1, int B,
-                    hipStream_t st);
+                    hipStream_t st, void* hi = nullptr, void* lo = nullptr);   // hi / lo: operand planes [B*16384, 64] instead of u1
 int launch_upscale2_masks(const float* g2, const float* feat_s0, const float* hyper, float* masks, int B, hipStream_t st);
 int launch_gather_rows(const float* in, int ld_in, int row_stride, int row_off, float* out, int ld_out, int B, int C,
                        hipStream_t st);  // out[b,:] = in[(b*row_stride+row_off), :]

@@ -609,6 +609,7 @@ __global__ void k_dwconv7(const float* in, const float* w, const float* bias, fl
   const float bs = bias[c];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = bs;
+  // (measured and not kept: the row loop fully unrolled with predicated loads instead of the skip - 79 -> 175 us per launch)
   for (int ky = 0; ky < 7; ++ky) {
     const int iy = y + ky - 3;
     if (iy < 0 || iy >= H) continue;
@@ -678,7 +679,7 @@ __global__ void k_prompt_tokens(const float* out_tokens6, const float* gauss, co
 // ConvTranspose2d(2x2,s2) as a GEMM result [B*4096, 4*64] with column (dy*2+dx)*64 + c.
 // One wave per output pixel: the 64 channels are the 64 lanes.
 __global__ __launch_bounds__(256) void k_upscale1(const float* g1, const float* feat_s1, const float* lnw,
-                                                  const float* lnb, float* u1, int B) {
+                                                  const float* lnb, float* u1, int B, unsigned* hi, unsigned* lo) {
   const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int c = threadIdx.x & 63;
   if (pix >= (size_t)B * 128 * 128) return;
@@ -688,7 +689,17 @@ __global__ __launch_bounds__(256) void k_upscale1(const float* g1, const float* 
   const float mean = wave_sum(v) / 64.f;
   const float d = v - mean;
   const float rstd = 1.f / sqrtf(wave_sum(d * d) / 64.f + 1e-6f);
-  u1[pix * 64 + c] = ds2_act(d * rstd * lnw[c] + lnb[c], DS2_ACT_GELU);
+  const float o = ds2_act(d * rstd * lnw[c] + lnb[c], DS2_ACT_GELU);
+  if (hi) {   // operand planes [pixels, 64] instead of fp32: channels (c, c + 1) packed by the even lane
+    const float on = __shfl_down(o, 1);
+    if (!(c & 1)) {
+      const unsigned h = ln_cvt_pk_bf16(o, on);
+      hi[pix * 32 + (c >> 1)] = h;
+      lo[pix * 32 + (c >> 1)] = ln_cvt_pk_bf16(o - __uint_as_float(h << 16), on - __uint_as_float(h & 0xffff0000u));
+    }
+  } else {
+    u1[pix * 64 + c] = o;
+  }
 }
 
 // masks[b,m] = hyper_in[b,m,:] . GELU(ConvT2(u1) + feat_s0)   (mask_decoder.py:224,235) without ever
@@ -1223,8 +1234,10 @@ int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const flo
   return DS2_OK;
 }
 int launch_upscale1(const float* g1, const float* feat_s1, const float* lnw, const float* lnb, float* u1, int B,
-                    hipStream_t st) {
-  hipLaunchKernelGGL(k_upscale1, dim3((unsigned)((size_t)B * 128 * 128 / 4)), dim3(256), 0, st, g1, feat_s1, lnw, lnb, u1, B);
+                    hipStream_t st, void* hi, void* lo) {
+  DS2_REQUIRE(!hi == !lo, "upscale1: both planes or none");
+  hipLaunchKernelGGL(k_upscale1, dim3((unsigned)((size_t)B * 128 * 128 / 4)), dim3(256), 0, st, g1, feat_s1, lnw, lnb, u1, B,
+                     reinterpret_cast<unsigned*>(hi), reinterpret_cast<unsigned*>(lo));
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

@@ -1166,6 +1166,9 @@ namespace {
 #ifndef DS2_HEADS_LN_KPE
 #define DS2_HEADS_LN_KPE 1
 #endif
+#ifndef DS2_HEADS_O_PLANES
+#define DS2_HEADS_O_PLANES 1
+#endif
 #ifndef DS2_HEADS_KQ
 #define DS2_HEADS_KQ 1
 #endif
@@ -1223,6 +1226,13 @@ int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int
   a.ldo = internal;
   a.batch = B; a.heads = 8; a.D = a.DV = internal / 8; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)a.D);
+  // image-side queries (image -> token): the tile kernel writes its result as the operand planes of out_proj (no fp32 `o`,
+  // no split pre-pass); the few-query kernels of the token side have no plane output
+  if (DS2_HEADS_O_PLANES && ds2_split_mode() && Lq >= 1024 && a.D == 16) {
+    ds2_model::ActPlanes op;
+    TRY(new_act_planes(m, o, B * Lq, internal, &op, st));
+    a.o_hi = op.hi; a.o_lo = op.lo; a.ldop = op.ld;
+  }
   TRY(launch_attention(a, st));
   TRY(linear(m, st, p + ".out_proj", B * Lq, 256, internal, o, internal, out, 256, DS2_ACT_NONE, R, 256));
   m->release(mark);
@@ -1423,7 +1433,11 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   float* g1 = tmpk;  // [rows,256]
   TRY(gemm(st, rows, 256, 256, keys, 256, m->P("@up1_w"), 256, m->P("@up1_b"), g1, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(u1, (size_t)B * 16384 * 64);
-  TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st));
+  {   // u1 feeds the second upscaling GEMM only: written as its operand planes in the split modes
+    ds2_model::ActPlanes up{};
+    if (DS2_HEADS_O_PLANES && ds2_split_mode()) TRY(new_act_planes(m, u1, B * 16384, 64, &up, st));
+    TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st, up.hi, up.lo));
+  }
   ALLOC(g2, (size_t)B * 16384 * 128);
   TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(hyper, (size_t)B * 128);
