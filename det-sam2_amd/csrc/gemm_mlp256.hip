@@ -300,6 +300,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
             v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
           }
           *reinterpret_cast<float4*>(a.out + (size_t)tok * a.ldo + n) = v;
+          if (a.out_hi) {   // (same split as k_split_rows: round to nearest even, lo = the rounded remainder)
+            uint2 h, l;
+            h.x = cvt_pk_bf16(v.x, v.y);
+            h.y = cvt_pk_bf16(v.z, v.w);
+            l.x = cvt_pk_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+            l.y = cvt_pk_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+            *reinterpret_cast<uint2*>(a.out_hi + (size_t)tok * a.ldop + n) = h;
+            *reinterpret_cast<uint2*>(a.out_lo + (size_t)tok * a.ldop + n) = l;
+          }
         }
       }
     }

@@ -149,6 +149,7 @@ struct MlpArgs {
   const float* R; int ldr;                         // residual fp32 [rows, ldr] (nullable)
   float* out; int ldo;                             // fp32 [rows, ldo]
   int act;                                         // DS2_ACT_NONE | RELU | GELU
+  unsigned short *out_hi, *out_lo; int ldop;       // optional: the result ALSO as bf16 operand planes [rows, ldop] (next GEMM's A)
 };
 bool mlp256_supported(const MlpArgs& a);
 int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st);

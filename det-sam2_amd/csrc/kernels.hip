@@ -176,6 +176,37 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
   }
 }
 
+// C = 64 (LayerNorm2d of the mask downsampler, 262 144 rows per 16 objects): k_layernorm_vec would keep 16 of a wave's 64 lanes
+// busy - here a 16-lane group owns a row (4 rows per wave).  Same expressions; the 16-lane butterfly (xor 8, 4, 2, 1) adds the
+// same values in the same order as wave_sum does over a wave whose other 48 lanes hold zeros: bit-identical.
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_layernorm_c64(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ y, int ldy, int rows,
+                                                       float eps, int act) {
+  const int lane = threadIdx.x & 63, l = lane & 15;
+  int row = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const bool live = row < rows;
+  row = live ? row : rows - 1;
+  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 4 * l);
+  const float mean = group16_sum((v.x + v.y) + (v.z + v.w)) / 64.f;
+  const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+  const float rstd = 1.f / sqrtf(group16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 64.f + eps);
+  const float4 w4 = *reinterpret_cast<const float4*>(w + 4 * l), b4 = *reinterpret_cast<const float4*>(b + 4 * l);
+  float4 o;
+  o.x = ds2_act((v.x - mean) * rstd * w4.x + b4.x, act);
+  o.y = ds2_act((v.y - mean) * rstd * w4.y + b4.y, act);
+  o.z = ds2_act((v.z - mean) * rstd * w4.z + b4.z, act);
+  o.w = ds2_act((v.w - mean) * rstd * w4.w + b4.w, act);
+  if (live) *reinterpret_cast<float4*>(y + (size_t)row * ldy + 4 * l) = o;
+}
+
+#ifndef DS2_LN_C64
+#define DS2_LN_C64 1
+#endif
 #ifndef DS2_LN_VEC
 #define DS2_LN_VEC 1
 #endif
@@ -1006,6 +1037,12 @@ __global__ __launch_bounds__(256) void k_mask_downscale_add(const float* mask, M
 int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
                      float eps, int act, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && C > 0, "layernorm: bad dims");
+  if (DS2_LN_C64 && C == 64 && ldx % 4 == 0 && ldy % 4 == 0 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
+    hipLaunchKernelGGL(k_layernorm_c64, dim3(cdiv(rows, 16)), dim3(256), 0, st, x, ldx, w, b, y, ldy, rows, eps, act);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
   if (launch_layernorm_vec<false>(x, ldx, w, b, y, ldy, nullptr, nullptr, 0, rows, C, eps, act, st)) {
     DS2_CHECK_LAUNCH();
     return DS2_OK;

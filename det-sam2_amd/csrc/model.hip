@@ -422,7 +422,7 @@ static bool mlp_fused_enabled() {
 // A's operand planes must be registered (its producer emitted them) or are split here.
 static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H, const float* A, int lda, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* gamma, const float* R, int ldr, float* out,
-                     int ldo, int act) {
+                     int ldo, int act, bool planes_too = false) {
   if (!ds2_split_mode() || !mlp_fused_enabled() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
   MlpArgs a{};
   a.rows = rows; a.D = 256; a.H = H; a.ldx = 256; a.ldw1 = 256; a.ldw2 = H;
@@ -460,16 +460,23 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     xh = sh; xl = sl;
   }
   a.X_hi = xh; a.X_lo = xl;
+  if (planes_too && m && ldo == 256) {   // the result also as the next GEMM's operand planes, registered under `out`
+    ds2_model::ActPlanes op;
+    TRY(new_act_planes(m, out, rows, 256, &op, st));
+    a.out_hi = op.hi; a.out_lo = op.lo; a.ldop = op.ld;
+  }
   a.W1_hi = w1p.hi; a.W1_lo = w1p.lo; a.ldw1 = w1p.ld;
   a.W2_hi = w2p.hi; a.W2_lo = w2p.lo; a.ldw2 = w2p.ld;
   ProfScope _gp(ptag, st, g_prof_gemm);
   return launch_mlp256(a, st);
 }
 // two-layer MLP by state_dict prefixes: fused when the shape allows it, else the two GEMMs (hidden planes in `hbuf`)
+// planes_too: `out` feeds a GEMM next - the fused kernel writes its operand planes alongside the fp32 result
 static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::string& p2, int rows, int H, const float* A,
-                float* hbuf, float* out, int act, const float* R, const float* gamma) {
+                float* hbuf, float* out, int act, const float* R, const float* gamma, bool planes_too = false) {
+  m->act_planes.erase(out);   // (`out` is rewritten: planes registered for its previous contents are stale)
   const int rc = mlp_fused(m, m->gctx, st, rows, H, A, 256, m->P(p1 + ".weight"), m->P(p1 + ".bias"), m->P(p2 + ".weight"),
-                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act);
+                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too);
   if (rc != DS2_ERR_UNSUPPORTED) return rc;
   TRY(linear(m, st, p1, rows, H, 256, A, 256, hbuf, H, act, nullptr, 0, 0, nullptr, true));
   return linear(m, st, p2, rows, 256, H, hbuf, H, out, 256, DS2_ACT_NONE, R, 256, 0, gamma);
@@ -1166,6 +1173,9 @@ namespace {
 #ifndef DS2_HEADS_LN_KPE
 #define DS2_HEADS_LN_KPE 1
 #endif
+#ifndef DS2_ME_X_PLANES
+#define DS2_ME_X_PLANES 1
+#endif
 #ifndef DS2_HEADS_O_PLANES
 #define DS2_HEADS_O_PLANES 1
 #endif
@@ -1502,7 +1512,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_encoder", st);
   const int rows = B * TOK;
-  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (size_t)rows * (256 * 3 + 1024 * 2) * 4 + (8u << 20);
+  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (size_t)rows * (256 * 4 + 1024 * 2) * 4 + (8u << 20);
   TRY(m->require(need, st));
   const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
   ALLOC(c1, (size_t)B * 262144 * 4);
@@ -1570,7 +1580,8 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
     const std::string p = me + ".fuser.layers." + std::to_string(l);
     TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
     TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
-    TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma")));
+    TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma"),
+             DS2_ME_X_PLANES && l == 1));   // the last block's result feeds out_proj
   }
   if (out_f32) {      // MemoryEncoder.forward's own output (no no_obj_embed_spatial, no bf16 storage rounding)
     TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, out_f32, 64));

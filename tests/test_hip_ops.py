@@ -125,7 +125,8 @@ def test_linear_small(ops, M, N, K, act, use_r, r_mod):
         assert torch.equal(sub, got[M // 2:])
 
 
-@pytest.mark.parametrize("rows,C,act", [(37, 96, 0), (1000, 256, 2), (5, 1152, 0), (64, 4, 2)])
+@pytest.mark.parametrize("rows,C,act", [(37, 96, 0), (1000, 256, 2), (5, 1152, 0), (64, 4, 2),
+                                        (1003, 64, 2)])     # C = 64: k_layernorm_c64 (16 lanes per row), ragged last block
 def test_layernorm(ops, rows, C, act):
     g = torch.Generator().manual_seed(rows)
     x, w, b = torch.randn(rows, C, generator=g) * 3 + 1, torch.randn(C, generator=g), torch.randn(C, generator=g)
