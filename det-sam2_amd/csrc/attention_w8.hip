@@ -164,6 +164,9 @@ struct W8Args {
   const float* rope_cis; int rope_grid, rope_w;   // rope_w > 0: compact table rows (GemmSplitArgs::rope_w)
   // optional, fp32 output only: o = res + attention (the residual stream; used when out_proj is folded into the values)
   const float* res; int ldres;
+  // rows between the query blocks of consecutive batch items (Lq; 0 = every batch item reads the SAME queries: layer 0 of the
+  // memory attention, where all objects still share the frame's tokens)
+  int q_bstride;
 };
 
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     for (int r4 = 0; r4 < BQ / 32; ++r4) {
       for (int idx = tid; idx < 32 * (D / 4); idx += 512) {
         const int r = idx / (D / 4), c4 = idx - r * (D / 4);
-        float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.Lq + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
+        float4 v = *reinterpret_cast<const float4*>(a.q + ((size_t)b * a.q_bstride + q0i + r4 * 32 + r) * a.ldq + c4 * 4);
         if (a.rope_cis) {   // complex pairs (4 c4, 4 c4 + 1), (4 c4 + 2, 4 c4 + 3): same expression as k_rope
           int t = (q0i + r4 * 32 + r) % a.rope_grid;
           if (a.rope_w > 0) t = c4 * 2 < 64 ? t % a.rope_w : t - t % a.rope_w;   // pairs < 64 depend on x only, the others on y
@@ -688,7 +691,8 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
-                        int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid, const float* res, int ldres) {
+                        int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid, const float* res, int ldres,
+                        bool q_shared) {
   const bool klo = ds2_precision() != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
@@ -696,7 +700,7 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
-           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0, res, ldres};
+           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0, res, ldres, q_shared ? 0 : Lq};
   DS2_REQUIRE(!res || (o && !o_hi && ldres % 4 == 0), "attention_w8: a residual needs the fp32 output");
   for (int w = 1; w * w <= q_rope_grid; ++w)
     if (w * w == q_rope_grid) a.rope_w = w;   // square axial grid (compute_axial_cis with end_x = end_y)

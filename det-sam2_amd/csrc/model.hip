@@ -241,6 +241,9 @@ struct ds2_model {
 
 static int model_precision(const ds2_model* m) { return m->precision; }
 // DS2_MA_FOLD_VO=0: keep out_proj of the memory attention's two attentions as its own GEMM (A/B runs)
+#ifndef DS2_MA_Q_ONCE
+#define DS2_MA_Q_ONCE 1
+#endif
 static bool ma_fold_vo_enabled() {
   static const bool v = [] { const char* e = getenv("DS2_MA_FOLD_VO"); return !(e && atoi(e) == 0); }();
   return v;
@@ -1085,6 +1088,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       float* xs = once ? x1 : x;               // the residual stream this self-attention updates
       if (!m->ma_fold_vo) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
       TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));   // all 256 value columns in one pass
+      // (measured and not kept: norm2 of the written rows emitted as q_proj's operand planes in this kernel's epilogue - the epilogue's
+      // 8-byte plane stores cost the kernel 16 us per launch, what the separate LayerNorm pass costs less its launch: +-0)
       if (m->ma_fold_vo)   // values already carry out_proj: the kernel adds its result to the residual stream in place
         TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, xs, 256, Bs, TOK, TOK, sc, 256, st, nullptr,
                                 nullptr, 0, 0, nullptr, cis, TOK, xs, 256));
@@ -1104,17 +1109,22 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
         TRY(launch_add_bcast(xs, 256, a, 256, 0, 1.0f, xs, 256, Bs * TOK, 256, st));
       }
     }
+    // layer 0, shared input: the residual stream is still the same for every object up to the cross-attention's result, so
+    // norm2 and q_proj run on ONE copy (TOK rows), the attention kernel reads those queries for every object, and the folded
+    // value projection adds its result to x1 broadcast by row (r_mod) - no replication of x1, 15/16 of two passes saved
+    const bool q_once = once && split && m->ma_fold_vo && DS2_MA_Q_ONCE;
     if (once) {
       if (!m->ma_fold_vo) TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
-      TRY(launch_bcast_rows(x1, x, TOK * 256, B, st));   // one launch instead of B device copies
+      if (!q_once) TRY(launch_bcast_rows(x1, x, TOK * 256, B, st));   // one launch instead of B device copies
     } else if (!m->ma_fold_vo) {
       TRY(linear(m, st, p + ".self_attn.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     }
     // -- cross attention to the memory bank.  V = v_proj(memory) is never materialised:
     //    softmax(QK^T) (M Wv^T + bv) = (softmax(QK^T) M) Wv^T + bv, so P.V runs in the 64-d memory space.
     m->act_planes.erase(a);   // self-attention planes are consumed; `a` is re-used below
-    TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
-    TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
+    const int qrows = q_once ? TOK : rows;
+    TRY(layernorm(m, st, p + ".norm2", q_once ? x1 : x, t, qrows, 256, 1e-5f, DS2_ACT_NONE, true));
+    TRY(linear(m, st, p + ".cross_attn_image.q_proj", qrows, 256, 256, t, 256, q, 256));
     if (!split) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     if (split) {
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
@@ -1127,7 +1137,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       ds2_model::ActPlanes cp;
       TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
       TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
-                              Nk - n_ptr_tok, vlo_flag, cis, TOK));
+                              Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once));
     } else {
       TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
@@ -1141,8 +1151,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     // out_proj(v_proj(P M)) folded on the host into ONE 64 -> 256 projection (constants.py fold_out_v: exact in real
     // arithmetic): x += (P M) (Wo Wv)^T + (Wo bv + bo) - one K = 64 GEMM instead of a K = 64 and a K = 256 one
     if (m->ma_fold_vo) {
-      TRY(gemm(st, rows, 256, 64, a64, 64, m->P("#ma_cross_vo_w." + ls), 64, m->P("#ma_cross_vo_b." + ls), x, 256, DS2_ACT_NONE, x, 256,
-               0, nullptr, true, m));
+      TRY(gemm(st, rows, 256, 64, a64, 64, m->P("#ma_cross_vo_w." + ls), 64, m->P("#ma_cross_vo_b." + ls), x, 256, DS2_ACT_NONE,
+               q_once ? x1 : x, 256, q_once ? TOK : 0, nullptr, true, m));
     } else {
       TRY(linear(m, st, p + ".cross_attn_image.v_proj", rows, 256, 64, a64, 64, a, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr,
                  true));   // only consumer: out_proj GEMM
