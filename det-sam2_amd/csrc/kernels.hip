@@ -628,6 +628,57 @@ __global__ void k_im2col3x3s2_split(const float* __restrict__ in, uint2* __restr
 // CXBlock depth-wise 7x7 / pad 3 (memory_encoder.py:86-92), NHWC, weights repacked [49][C].
 // One thread = 8 consecutive output pixels of one row for one channel: each input row segment (14 values) is loaded
 // once and feeds all 8 outputs (4x fewer loads than one output per thread); lanes run along C (coalesced).
+// 4 rows x 8 columns of outputs per thread: an input row is loaded once (14 values) and feeds up to four output rows, 4.4 loads
+// per output instead of 12.25.  The row loop is NOT unrolled (unrolled, hipcc hoists all 140 loads: 218 registers): the weights
+// of the (input row, output row) pair come from L1 inside it.  Per output the products are added in the order of k_dwconv7
+// (input rows ascending = ky ascending, kx ascending, rows outside the map skipped): bit-identical.
+__global__ __launch_bounds__(256) void k_dwconv7_t4(const float* __restrict__ in, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int B, int H, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int XB = H / 8, YB = H / 4;
+  if (i >= (size_t)B * YB * XB * C) return;
+  const int c = (int)(i % C);
+  size_t r_ = i / C;
+  const int xb = (int)(r_ % XB), yb = (int)((r_ / XB) % YB), b = (int)(r_ / ((size_t)XB * YB));
+  const int x0 = xb * 8, y0 = yb * 4;
+  float acc[4][8];
+  const float bs = bias[c];
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[oy][j] = bs;
+#pragma unroll 1
+  for (int r = 0; r < 10; ++r) {
+    const int iy = y0 + r - 3;
+    if (iy < 0 || iy >= H) continue;
+    float v[14];
+    const float* rp = in + (((size_t)b * H + iy) * H) * C + c;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int ix = x0 + j - 3;
+      v[j] = (ix >= 0 && ix < H) ? rp[(size_t)ix * C] : 0.f;
+    }
+#pragma unroll
+    for (int oy = 0; oy < 4; ++oy) {
+      const int ky = r - oy;          // block-uniform
+      if (ky < 0 || ky > 6) continue;
+      const float* wp = w + (size_t)(ky * 7) * C + c;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const float wv = wp[(size_t)kx * C];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[oy][j] += v[j + kx] * wv;
+      }
+    }
+  }
+#pragma unroll
+  for (int oy = 0; oy < 4; ++oy)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[(((size_t)b * H + y0 + oy) * H + x0 + j) * C + c] = acc[oy][j];
+}
+#ifndef DS2_DWCONV_T4
+#define DS2_DWCONV_T4 1
+#endif
 __global__ void k_dwconv7(const float* in, const float* w, const float* bias, float* out, int B, int H, int C) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int XB = H / 8;
@@ -1251,6 +1302,11 @@ int launch_im2col3x3s2_split(const float* in, void* hi, void* lo, int ldp, int B
 }
 int launch_dwconv7(const float* in, const float* w49c, const float* bias, float* out, int B, int H, int C, hipStream_t st) {
   DS2_REQUIRE(H % 8 == 0, "dwconv7: H must be a multiple of 8");
+  if (DS2_DWCONV_T4 && H % 4 == 0) {
+    hipLaunchKernelGGL(k_dwconv7_t4, grid1((size_t)B * (H / 4) * (H / 8) * C), dim3(256), 0, st, in, w49c, bias, out, B, H, C);
+    DS2_CHECK_LAUNCH();
+    return DS2_OK;
+  }
   hipLaunchKernelGGL(k_dwconv7, grid1((size_t)B * H * (H / 8) * C), dim3(256), 0, st, in, w49c, bias, out, B, H, C);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
