@@ -631,7 +631,9 @@ __global__ void k_im2col3x3s2_split(const float* __restrict__ in, uint2* __restr
 // 4 rows x 8 columns of outputs per thread: an input row is loaded once (14 values) and feeds up to four output rows, 4.4 loads
 // per output instead of 12.25.  The row loop is NOT unrolled (unrolled, hipcc hoists all 140 loads: 218 registers): the weights
 // of the (input row, output row) pair come from L1 inside it.  Per output the products are added in the order of k_dwconv7
-// (input rows ascending = ky ascending, kx ascending, rows outside the map skipped): bit-identical.
+// (input rows ascending = ky ascending, kx ascending, rows outside the map skipped), every one as a fused multiply-add (112
+// v_pk_fma_f32); hipcc compiles k_dwconv7's loop with a few products left unfused (v_pk_mul + v_pk_add), so 17 % of the outputs
+// differ from it in the last bit (tools/ubench/dwconv_cmp.hip: max |diff| 7.6e-6 at |x| ~ 5).  79 -> 52 us per launch.
 __global__ __launch_bounds__(256) void k_dwconv7_t4(const float* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ out, int B, int H, int C) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
