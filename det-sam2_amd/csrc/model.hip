@@ -1186,6 +1186,12 @@ namespace {
 #ifndef DS2_ME_X_PLANES
 #define DS2_ME_X_PLANES 1
 #endif
+#ifndef DS2_HEADS_I2T_PLANES
+#define DS2_HEADS_I2T_PLANES 1
+#endif
+#ifndef DS2_HEADS_U1_PLANES
+#define DS2_HEADS_U1_PLANES 1
+#endif
 #ifndef DS2_HEADS_O_PLANES
 #define DS2_HEADS_O_PLANES 1
 #endif
@@ -1248,7 +1254,7 @@ int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int
   a.scale = 1.0f / sqrtf((float)a.D);
   // image-side queries (image -> token): the tile kernel writes its result as the operand planes of out_proj (no fp32 `o`,
   // no split pre-pass); the few-query kernels of the token side have no plane output
-  if (DS2_HEADS_O_PLANES && ds2_split_mode() && Lq >= 1024 && a.D == 16) {
+  if (DS2_HEADS_O_PLANES && DS2_HEADS_I2T_PLANES && ds2_split_mode() && Lq >= 1024 && a.D == 16) {
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, o, B * Lq, internal, &op, st));
     a.o_hi = op.hi; a.o_lo = op.lo; a.ldop = op.ld;
@@ -1455,7 +1461,7 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   ALLOC(u1, (size_t)B * 16384 * 64);
   {   // u1 feeds the second upscaling GEMM only: written as its operand planes in the split modes
     ds2_model::ActPlanes up{};
-    if (DS2_HEADS_O_PLANES && ds2_split_mode()) TRY(new_act_planes(m, u1, B * 16384, 64, &up, st));
+    if (DS2_HEADS_O_PLANES && DS2_HEADS_U1_PLANES && ds2_split_mode()) TRY(new_act_planes(m, u1, B * 16384, 64, &up, st));
     TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st, up.hi, up.lo));
   }
   ALLOC(g2, (size_t)B * 16384 * 128);
