@@ -45,6 +45,8 @@ SIGNATURES = {
     "ds2_memory_attention": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp]),
     "ds2_sam_heads": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ds2_sam_heads_mask": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, c_vp, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_prompt_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp]),
+    "ds2_mask_decoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "ds2_memory_encoder": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, c_vp, c_vp]),
     "ds2_connected_components": (C.c_int, [c_vp, i32, i32, i32, c_vp, c_vp, c_vp, c_vp]),
     "ds2_fill_holes": (C.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp]),
@@ -73,7 +75,7 @@ SIGNATURES = {
 }
 
 # the PyTorch custom ops csrc/torch_ops.cpp registers (torch.ops.det_sam2.<name>)
-TORCH_OPS = ("ingest_frames", "image_encoder", "bank_assemble", "memory_attention", "sam_heads", "memory_encoder",
+TORCH_OPS = ("ingest_frames", "image_encoder", "bank_assemble", "memory_attention", "sam_heads", "prompt_encoder", "mask_decoder", "memory_encoder",
              "memory_encoder_module", "resize_aa", "mask_prompt_prepare", "obj_ptr_gate", "mask_output",
              "get_connected_componnets", "fill_holes", "yolo_postprocess")
 

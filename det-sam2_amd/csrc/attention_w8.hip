@@ -56,6 +56,29 @@ __device__ __forceinline__ bf16x8 pack8(float v0, float v1, float v2, float v3, 
   const bf16x2 c = __builtin_convertvector((f32x2{v4, v5}), bf16x2), d = __builtin_convertvector((f32x2{v6, v7}), bf16x2);
   return bf16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
 }
+// Mode bf16x3k (KLO = false): the single operand planes of the memory attention - queries, keys, softmax weights, values - are
+// IEEE fp16 (11 significant bits), not bf16 (8): same MFMA count and rate (v_mfma_f32_16x16x32_f16), 8x smaller rounding per
+// operand.  Round 4: with bf16 planes the held-out golden AT THE MEASURED SHAPE (hiera_l, 16 objects, structured frames: masks
+// of ~5 500 low-res pixels) missed the 1e-3 IoU bar by 3-7 pixels per mask (tests/test_hip_measured_shape.py); every value
+// involved is O(1) after LayerNorm / softmax, far inside fp16's range.  The 128-bit register containers stay `bf16x8`.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x8 pack8h(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  const f16x2 a = __builtin_convertvector((f32x2{v0, v1}), f16x2), b = __builtin_convertvector((f32x2{v2, v3}), f16x2);
+  const f16x2 c = __builtin_convertvector((f32x2{v4, v5}), f16x2), d = __builtin_convertvector((f32x2{v6, v7}), f16x2);
+  return __builtin_bit_cast(bf16x8, (f16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]}));
+}
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {   // v_cvt_pk_f16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a, b}), f16x2));
+}
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+// one 16x16x32 MFMA on the mode's plane type
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 // DS2_ATTN_ILV (bf16x3k instantiations): the softmax of tile t is interleaved instruction by instruction with the score MFMAs
 // of tile t+1 (sched_group_barrier pipeline).  Left to itself hipcc issues the 32 MFMAs back to back and then ~85 VALU
 // instructions in a row with the matrix pipe idle; both waves of a SIMD do that in step because of the per-tile barrier.
@@ -115,7 +138,9 @@ __device__ __forceinline__ int vt_pos16(int key) { return 8 * ((key >> 2) & 3) +
 // Tiles < n_flag_tiles are expected to hold bf16-exact values (memory-bank frame tokens are bf16 storage upcast to
 // fp32, so their lo plane is identically zero): if any lo value there is NOT zero, *flag is raised and the attention
 // kernel keeps the full three-term P.V product for every tile - the fast path is taken only when it is exact.
-template <int DVT>
+// F16 (mode bf16x3k): both planes as fp16 (hi = fp16(x), lo = fp16(x - hi)); the bf16-exactness test of the flag is unchanged -
+// a bf16-exact value of normal fp16 magnitude is fp16-exact too, and below 2^-14 the hi plane errs by < 2^-25 absolute.
+template <int DVT, bool F16>
 __global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v, int ldv, int batch, int L,
                                                     unsigned short* __restrict__ vt, int n_flag_tiles, int* __restrict__ flag) {
   const int ntile = (L + 31) / 32;
@@ -126,21 +151,26 @@ __global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v,
   const int tile = (int)(bt % ntile), b = (int)(bt / ntile);
   const float* src = v + ((size_t)b * L + (size_t)tile * 32) * ldv + dv;
   const int nvalid = L - tile * 32;          // keys beyond L are zero
-  unsigned h[16], l[16];
+  unsigned h[16], l[16], exact_any = 0;
 #pragma unroll
   for (int key = 0; key < 32; key += 2) {    // keys (key, key+1) sit at adjacent positions (pos, pos+1), pos even
     const float x0 = key < nvalid ? src[(size_t)key * ldv] : 0.f;
     const float x1 = key + 1 < nvalid ? src[(size_t)(key + 1) * ldv] : 0.f;
     const unsigned hh = cvt_pk_bf16(x0, x1);
     const int pos = 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4);
-    h[pos >> 1] = hh;
-    l[pos >> 1] = cvt_pk_bf16(x0 - bf_lo(hh), x1 - bf_hi(hh));
+    const unsigned lb = cvt_pk_bf16(x0 - bf_lo(hh), x1 - bf_hi(hh));
+    if constexpr (F16) {
+      const unsigned hf = cvt_pk_f16(x0, x1);
+      h[pos >> 1] = hf;
+      l[pos >> 1] = cvt_pk_f16(x0 - f16_lo(hf), x1 - f16_hi(hf));
+    } else {
+      h[pos >> 1] = hh;
+      l[pos >> 1] = lb;
+    }
+    exact_any |= lb & 0x7fff7fffu;   // bf16 remainder (-0 counts as zero)
   }
   if (tile < n_flag_tiles) {
-    unsigned any = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) any |= l[j] & 0x7fff7fffu;   // -0 counts as zero
-    if (any) atomicOr(flag, 1);
+    if (exact_any) atomicOr(flag, 1);
   }
   uint4* oh = reinterpret_cast<uint4*>(vt + bt * 2 * (32 * DVT) + (size_t)dv * 32);
   uint4* ol = reinterpret_cast<uint4*>(vt + bt * 2 * (32 * DVT) + 32 * DVT + (size_t)dv * 32);
@@ -184,6 +214,7 @@ struct W8Args {
 template <int DV, int QG, bool KLO>
 __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int BQ = 128 * QG;
+  constexpr bool KF16 = !KLO && DS2_ATTN_K_F16;   // single-plane operands as fp16
   // ILV instantiation (bf16x3k cross-attention): LDS images WITHOUT row padding - K rows of 512 bytes, V^T rows of 64 - with the
   // 16-byte chunks of a row XOR-swizzled by the row index instead, so that a tile is a linear 1-KiB-per-wave copy (LDS-DMA,
   // W8_DMA_*) of the planes as their producers write them.  K: physical chunk = logical chunk ^ (row & 15); V^T: ^ f((row >> 2) & 3),
@@ -248,7 +279,9 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const float* qr = qrow + ks * 32;
-            split8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7], q0[g][ks], q1[g][ks]);
+            if constexpr (KLO) split8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7], q0[g][ks], q1[g][ks]);
+            else if constexpr (KF16) q0[g][ks] = pack8h(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7]);
+            else q0[g][ks] = pack8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7]);
           }
         }
       }
@@ -361,11 +394,11 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
           s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q1[g][ks], s1[g], 0, 0, 0);
         }
       }
-      // (bf16x3k: the queries of the scores are one bf16 plane too - q_hi . k_hi only)
+      // (bf16x3k: queries and keys of the scores are ONE fp16 plane each - one MFMA term)
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
-        s0[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, q0[g][ks], s0[g], 0, 0, 0);
-        s1[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, q0[g][ks], s1[g], 0, 0, 0);
+        s0[g] = mfma16<KF16>(a00, q0[g][ks], s0[g]);
+        s1[g] = mfma16<KF16>(a10, q0[g][ks], s1[g]);
       }
     }
     if constexpr (MASK) {   // keys >= Lk (last tile); lane holds keys 4*grp + r (+16).  Branch-free: the block must stay one
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #if DS2_ABL & 1
       alpha[g] = 1.f;
       l_run[g] += s0[g][0];
-      pb0[g] = pack8(s0[g][0] * 0.015625f, s0[g][1] * 0.015625f, s0[g][2] * 0.015625f, s0[g][3] * 0.015625f, s1[g][0] * 0.015625f,
+      pb0[g] = (KF16 ? pack8h : pack8)(s0[g][0] * 0.015625f, s0[g][1] * 0.015625f, s0[g][2] * 0.015625f, s0[g][3] * 0.015625f, s1[g][0] * 0.015625f,
                      s1[g][1] * 0.015625f, s1[g][2] * 0.015625f, s1[g][3] * 0.015625f);
       continue;
 #endif
@@ -409,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       l_run[g] = l_run[g] * alpha[g] + (((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)));
       m_run[g] = m_new;
       if constexpr (KLO) split8(p0, p1, p2, p3, p4, p5, p6, p7, pb0[g], pb1[g]);
+      else if constexpr (KF16) pb0[g] = pack8h(p0, p1, p2, p3, p4, p5, p6, p7);
       else pb0[g] = pack8(p0, p1, p2, p3, p4, p5, p6, p7);
     }
     if constexpr (ILV) {
@@ -461,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1[t], pb0[g], o[g][t], 0, 0, 0);
+          for (int g = 0; g < QG; ++g) o[g][t] = mfma16<KF16>(v1[t], pb0[g], o[g][t]);
       }
       if (KLO) {   // bf16x3k: the softmax weights enter P.V as one bf16 plane (no V . P_lo term)
 #pragma unroll
@@ -472,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < QG; ++g) o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0[t], pb0[g], o[g][t], 0, 0, 0);
+        for (int g = 0; g < QG; ++g) o[g][t] = mfma16<KF16>(v0[t], pb0[g], o[g][t]);
     } else {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -484,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
             o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, pb0[g], o[g][t], 0, 0, 0);
             o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb1[g], o[g][t], 0, 0, 0);
           }
-          o[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, pb0[g], o[g][t], 0, 0, 0);
+          o[g][t] = mfma16<KF16>(v0, pb0[g], o[g][t]);
         }
       }
     }
@@ -643,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
 
 // ---- producer: (optional RoPE) + split of 256-wide rows into bf16 planes.  One thread per 4 consecutive columns.
 __global__ void k_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
-                             uint2* hi, uint2* lo) {
+                             uint2* hi, uint2* lo, int hi_f16) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)batch * L * 64) return;
   const int c4 = (int)(i & 63);
@@ -654,40 +688,49 @@ __global__ void k_rope_split(const float* x, int ldx, const float* cis, int batc
     const float4 c = *reinterpret_cast<const float4*>(cis + ((size_t)(t % grid_tokens) * 128 + c4 * 2) * 2);
     v = make_float4(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x, v.z * c.z - v.w * c.w, v.z * c.w + v.w * c.z);
   }
+  if (hi_f16) {           // bf16x3k mode: the keys of the scores are one fp16 plane
+    hi[i] = make_uint2(cvt_pk_f16(v.x, v.y), cvt_pk_f16(v.z, v.w));
+    return;
+  }
   uint2 h, l;
   h.x = cvt_pk_bf16(v.x, v.y);
   h.y = cvt_pk_bf16(v.z, v.w);
   l.x = cvt_pk_bf16(v.x - bf_lo(h.x), v.y - bf_hi(h.x));
   l.y = cvt_pk_bf16(v.z - bf_lo(h.y), v.w - bf_hi(h.y));
   hi[i] = h;
-  if (lo) lo[i] = l;      // bf16x3k mode: the keys of the scores carry no lo plane
+  if (lo) lo[i] = l;
 }
 
 }  // namespace
 
 int launch_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
-                      void* hi, void* lo, hipStream_t st) {
+                      void* hi, void* lo, hipStream_t st, bool hi_f16) {
+  DS2_REQUIRE(!(hi_f16 && lo), "rope_split: the fp16 form has no lo plane");
   const size_t n = (size_t)batch * L * 64;
   hipLaunchKernelGGL(k_rope_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, cis, batch, L, n_rope,
-                     grid_tokens, reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo));
+                     grid_tokens, reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), hi_f16 ? 1 : 0);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
 
 
-int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys, int* flag) {
+int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys, int* flag, bool f16) {
   DS2_REQUIRE(dv == 64 || dv == 128 || dv == 256, "vt_split16: dv must be 64, 128 or 256");
   const size_t n = (size_t)batch * ((L + 31) / 32) * dv;     // one thread per (tile, dv) row
   const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
   unsigned short* out = reinterpret_cast<unsigned short*>(vt);
   const int nft = flag ? n_exact_keys / 32 : 0;
   if (flag) DS2_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
-  if (dv == 64)
-    hipLaunchKernelGGL((k_vt_split16<64>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
+  if (dv == 64 && f16)
+    hipLaunchKernelGGL((k_vt_split16<64, true>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
+  else if (dv == 64)
+    hipLaunchKernelGGL((k_vt_split16<64, false>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
   else if (dv == 128)
-    hipLaunchKernelGGL((k_vt_split16<128>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
+    hipLaunchKernelGGL((k_vt_split16<128, false>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
+  else if (f16)
+    hipLaunchKernelGGL((k_vt_split16<256, true>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
   else
-    hipLaunchKernelGGL((k_vt_split16<256>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
+    hipLaunchKernelGGL((k_vt_split16<256, false>), grid, blk, 0, st, v, ldv, batch, L, out, nft, flag);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

@@ -28,15 +28,18 @@ struct YoloWork {                     // per-image slices of the caller's work b
   float* sconf; int* scls;            // [YCAP]
   unsigned long long* mask;           // [YCAP][YWORDS]
 };
+// conf / cls segments rounded up to 16 bytes so that the float4 arrays behind them (sbox, soff) are 16-byte aligned for
+// every N (YOLOv8 at 672 x 672 has N = 9261, odd)
+__host__ __device__ inline size_t yolo_seg_n(int N) { return (((size_t)N * 4) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t yolo_work_per_image(int N) {
-  size_t b = (size_t)N * 8 + (size_t)YCAP * 8 + 256 + (size_t)YCAP * 32 + (size_t)YCAP * 8 + (size_t)YCAP * YWORDS * 8;
+  size_t b = 2 * yolo_seg_n(N) + (size_t)YCAP * 8 + 256 + (size_t)YCAP * 32 + (size_t)YCAP * 8 + (size_t)YCAP * YWORDS * 8;
   return (b + 255) & ~(size_t)255;
 }
 __device__ __forceinline__ YoloWork yolo_slice(unsigned char* work, int N, int b) {
   unsigned char* p = work + (size_t)b * yolo_work_per_image(N);
   YoloWork w;
-  w.conf = reinterpret_cast<float*>(p); p += (size_t)N * 4;
-  w.cls = reinterpret_cast<int*>(p); p += (size_t)N * 4;
+  w.conf = reinterpret_cast<float*>(p); p += yolo_seg_n(N);
+  w.cls = reinterpret_cast<int*>(p); p += yolo_seg_n(N);
   w.cand = reinterpret_cast<int*>(p); p += (size_t)YCAP * 4;
   w.cconf = reinterpret_cast<float*>(p); p += (size_t)YCAP * 4;
   w.count = reinterpret_cast<int*>(p); p += 256;

@@ -400,10 +400,13 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
   static const int tile_env = [] { const char* e = getenv("DS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (g.c_hi_f16) {   // fp16 key planes (mode bf16x3k): the K = 64 streaming kernel's epilogue is the one that writes them
+    DS2_REQUIRE(gemm_split_k64_supported(g), "gemm_split: fp16 hi planes are produced by the K = 64 kernel only (M=%d N=%d Kp=%d)", g.M, g.N, g.Kp);
+  } else
   if (tile_env != 0) return launch_tile(g, tile_env, st);
   // K = 64 projections over hundreds of thousands of rows (memory-attention keys): HBM-bound weight-stationary kernel
   static const bool k64 = [] { const char* e = getenv("DS2_GEMM_K64"); return !(e && atoi(e) == 0); }();
-  if (k64 && gemm_split_k64_supported(g)) {
+  if ((k64 || g.c_hi_f16) && gemm_split_k64_supported(g)) {
     if (!ds2_prof_kernels()) return launch_gemm_split_k64(g, st);
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return launch_gemm_split_k64(g, st);

@@ -51,7 +51,9 @@ struct AFrags {
 // NT = N / 32 column tiles (4 or 8).  PLANES = the launcher found the key / value projection's epilogue (no activation, gamma,
 // residual or fp32 output; plane output): those operands become compile-time constants and their (wave-uniform) branches
 // disappear from the row loop, which is instruction-issue bound.
-template <int NT, bool PLANES>
+// F16H (PLANES only; GemmSplitArgs::c_hi_f16): the hi plane is written as IEEE fp16 and there is no lo plane - the single-plane
+// keys of the memory attention in mode bf16x3k.
+template <int NT, bool PLANES, bool F16H = false>
 __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int tiles_per_wave) {
   constexpr int NCOL = NT * 32;
   constexpr int WPL = NCOL * WROWB;                       // bytes of one weight plane
@@ -223,6 +225,14 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
               v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3;
             }
           }
+          if constexpr (F16H) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            uint2 h;   // v_cvt_pk_f16_f32, round to nearest even
+            h.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{v[0], v[1]}), f16x2));
+            h.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{v[2], v[3]}), f16x2));
+            *reinterpret_cast<uint2*>(e_Chi + (size_t)m * g.ldcp + n) = h;
+          } else {
           uint2 h, l;
           h.x = cvt_pk_bf16(v[0], v[1]);
           h.y = cvt_pk_bf16(v[2], v[3]);
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
           l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
           *reinterpret_cast<uint2*>(e_Chi + (size_t)m * g.ldcp + n) = h;
           if (g.C_lo) *reinterpret_cast<uint2*>(g.C_lo + (size_t)m * g.ldcp + n) = l;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -261,7 +272,12 @@ int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st) {
   if (blocks > 256) blocks = 256;                      // one persistent workgroup per CU
   const int tiles_per_wave = (ntiles + blocks * 8 - 1) / (blocks * 8);
   const bool planes = g.act == DS2_ACT_NONE && !g.gamma && !g.R && !g.C && g.C_hi;
-  if (ncols == 256 && planes)
+  DS2_REQUIRE(!g.c_hi_f16 || (planes && !g.C_lo), "gemm_split_k64: fp16 hi plane needs the plane-only epilogue without a lo plane");
+  if (g.c_hi_f16 && ncols == 256)
+    hipLaunchKernelGGL((k_gemm_split_k64<8, true, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else if (g.c_hi_f16)
+    hipLaunchKernelGGL((k_gemm_split_k64<4, true, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else if (ncols == 256 && planes)
     hipLaunchKernelGGL((k_gemm_split_k64<8, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
   else if (ncols == 256)
     hipLaunchKernelGGL((k_gemm_split_k64<8, false>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);

@@ -3,6 +3,12 @@
 #pragma once
 #include "common.h"
 
+// Mode bf16x3k: the single-plane operands of the memory attention (queries, keys, softmax weights, values) as IEEE fp16 (1,
+// default since round 4) or bf16 (0: the round-2/3 definition, kept for A/B builds: tools/ab.py build kbf16 -DDS2_ATTN_K_F16=0)
+#ifndef DS2_ATTN_K_F16
+#define DS2_ATTN_K_F16 1
+#endif
+
 int launch_add_bcast(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, float* out, int ldo,
                      int rows, int C, hipStream_t st);  // out[r,c] = a[r,c] + alpha*b[r % b_mod, c]  (b_mod<=0: r)
 int launch_add_rowvec(const float* a, int lda, const float* vec, float* out, int ldo, int rows, int C, hipStream_t st);
@@ -43,7 +49,7 @@ int launch_mlp3_256(const float* A, int lda, const float* w0, const float* b0, c
                     const float* b2, int n_out, float* out, int ldc, int last_act, int rows, hipStream_t st);
 int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4, const float* not_a_point,
                          const float* coords, const int* labels, int B, int P, float image_size, float* tokens,
-                         hipStream_t st);  // tokens [B, 6+P+1, 256]
+                         hipStream_t st, int pad = 1, const float* sparse_in = nullptr);  // tokens [B, 6+P+pad, 256]
 int launch_upscale1(const float* g1, const float* feat_s1, const float* lnw, const float* lnb, float* u1, int B,
                     hipStream_t st, void* hi = nullptr, void* lo = nullptr);   // hi / lo: operand planes [B*16384, 64] instead of u1
 int launch_upscale2_masks(const float* g2, const float* feat_s0, const float* hyper, float* masks, int B, hipStream_t st);
@@ -86,7 +92,8 @@ int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* 
 
 // producer of pre-split key planes for the memory attention (attention_w8.hip)
 int launch_rope_split(const float* x, int ldx, const float* cis, int batch, int L, int n_rope, int grid_tokens,
-                      void* hi, void* lo, hipStream_t st);   // rows [batch*L] x 256 cols -> bf16 planes [batch*L][256]
+                      void* hi, void* lo, hipStream_t st, bool hi_f16 = false);   // rows [batch*L] x 256 cols -> bf16 planes [batch*L][256]
+                                                                                    // (hi_f16: the hi plane as fp16, mode bf16x3k)
 
 // pre-split bf16x3 GEMM (gemm_split.hip)
 struct GemmSplitArgs {
@@ -112,6 +119,9 @@ struct GemmSplitArgs {
   int group_m;
   // k_gemm_split_d256: L2 prefetch distance of the A operand in K tiles (0 = off).  Set by launch_gemm_split.
   int prefetch;
+  // C_hi is written as IEEE fp16 (11 significant bits) instead of bf16: the single-plane keys of the memory attention in
+  // mode bf16x3k (attention_w8.hip).  Honoured by the K = 64 streaming kernel only (launch_gemm_split checks).
+  int c_hi_f16;
 };
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 256x128 blocks, 8 waves, 3-stage LDS-DMA ring
@@ -159,7 +169,7 @@ int launch_mlp256(const MlpArgs& a, hipStream_t st);
 // n_exact_keys/flag (optional): the leading n_exact_keys keys are expected to be bf16-exact; *flag (device int) is
 // zeroed and then raised by the kernel if any of them has a non-zero lo part (see launch_attention_w8)
 int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int dv, hipStream_t st, int n_exact_keys = 0,
-                      int* flag = nullptr);   // dv = 64 | 128
+                      int* flag = nullptr, bool f16 = false);   // dv = 64 | 128 | 256; f16: fp16 planes (mode bf16x3k)
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi = nullptr,
                         void* o_lo = nullptr, int ldop = 0,    // o_hi/o_lo: emit bf16 planes [rows, ldop] instead of fp32

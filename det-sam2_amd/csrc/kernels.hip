@@ -729,14 +729,18 @@ __global__ void k_memfeat_finish(const float* feat, const float* obj_logits, con
 // ------------------------------------------------------------------ SAM heads
 // tokens[b] = [obj_score_token, iou_token, mask_tokens(4)] ++ sparse point embeddings (P points + the
 // padding point)  (mask_decoder.py:174-195; prompt_encoder.py:73-95; position_encoding.py:129-158).
+// pad = 0: no padding point (PromptEncoder.forward with boxes given, prompt_encoder.py:158); sparse_in != nullptr: the sparse
+// embeddings are the caller's [B, P, 256] (MaskDecoder.forward's own argument) and are copied behind the output tokens.
 __global__ void k_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4,
                                 const float* not_a_point, const float* coords, const int* labels, int B, int P,
-                                float image_size, float* tokens) {
-  const int T = 6 + P + 1;
+                                float image_size, float* tokens, int pad, const float* sparse_in) {
+  const int T = 6 + P + pad;
   const int bt = blockIdx.x, b = bt / T, t = bt % T, j = threadIdx.x;  // 256 threads = 256 channels
   float v;
   if (t < 6) {
     v = out_tokens6[t * 256 + j];
+  } else if (sparse_in) {
+    v = sparse_in[((size_t)b * P + (t - 6)) * 256 + j];
   } else {
     const int p = t - 6;
     int lab = -1;
@@ -1322,9 +1326,10 @@ int launch_memfeat_finish(const float* feat, const float* obj_logits, const floa
 }
 int launch_prompt_tokens(const float* out_tokens6, const float* gauss, const float* point_emb4, const float* not_a_point,
                          const float* coords, const int* labels, int B, int P, float image_size, float* tokens,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(k_prompt_tokens, dim3(B * (6 + P + 1)), dim3(256), 0, st, out_tokens6, gauss, point_emb4, not_a_point,
-                     coords, labels, B, P, image_size, tokens);
+                         hipStream_t st, int pad, const float* sparse_in) {
+  if (B * (6 + P + pad) <= 0) return DS2_OK;
+  hipLaunchKernelGGL(k_prompt_tokens, dim3(B * (6 + P + pad)), dim3(256), 0, st, out_tokens6, gauss, point_emb4, not_a_point,
+                     coords, labels, B, P, image_size, tokens, pad, sparse_in);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }

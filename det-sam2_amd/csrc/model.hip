@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -113,6 +114,10 @@ struct GemmCtx {
   std::unordered_map<const float*, float*> own_wt;   // skinny linear layers: fp32 weights transposed to [K, N] (once)
   std::unordered_map<const float*, float*>& wt() { return share ? share->own_wt : own_wt; }
   GemmCtx* share = nullptr;   // a VIEW model (ds2_model_create_view) uses its parent's weight planes; the scratch is its own
+  // the three maps are shared by a parent and its views, which may be driven from different host threads: every lookup /
+  // first-use insertion runs under the OWNER's mutex (held across the split + publish, so a second thread finds finished planes)
+  std::mutex own_mu;
+  std::mutex& mu() { return share ? share->own_mu : own_mu; }
   PlaneMap& wc() { return share ? share->own_wcache : own_wcache; }        // weights split into planes (once)
   PlaneMap& w2p() { return share ? share->own_w2perm : own_w2perm; }      // fused MLP: W2 with the hidden index permuted
   // a weight's planes may be consumed on another stream than the one that split it (view models): the creating call waits
@@ -303,7 +308,8 @@ struct GemmDropScope {
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
                 const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false,
-                const float* rope_cis = nullptr, int rope_L = 0, int rope_n = 0, int rope_grid = 0, bool out_hi_only = false) {
+                const float* rope_cis = nullptr, int rope_L = 0, int rope_n = 0, int rope_grid = 0, bool out_hi_only = false,
+                bool out_hi_f16 = false) {
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
@@ -318,6 +324,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     ProfScope _gp(ptag, st, g_prof_gemm);
     GemmCtx& ctx = m->gctx;
     float* wt = nullptr;
+    std::unique_lock<std::mutex> lk(ctx.mu());
     auto it = ctx.wt().find(W);
     if (it != ctx.wt().end()) {
       wt = it->second;
@@ -327,6 +334,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
       TRY(ctx.publish(st));
       ctx.wt()[W] = wt;
     }
+    lk.unlock();
     SkinnyArgs g{M, N, K, A, lda, wt, bias, gamma, R, ldr, r_mod, C, ldc, act};
     return launch_skinny_linear(g, st);
   }
@@ -353,6 +361,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   const size_t a_bytes = ahi ? 0 : (size_t)M * Kp * 2;
   GemmCtx& ctx = m ? m->gctx : g_gemm_ctx;
   GemmPlanes wp;
+  std::unique_lock<std::mutex> lk(ctx.mu());
   auto it = w_static ? ctx.wc().find(W) : ctx.wc().end();
   if (it != ctx.wc().end()) {
     wp = it->second;
@@ -372,6 +381,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     wp.ld = Kp;
     TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st));
   }
+  lk.unlock();
   if (!ahi) {
     unsigned short* sh = reinterpret_cast<unsigned short*>(ctx.scratch);
     unsigned short* sl = sh + (size_t)M * Kp;
@@ -388,6 +398,7 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, C, M, N, &op, st));
     g.C = nullptr; g.C_hi = op.hi; g.C_lo = out_hi_only ? nullptr : op.lo; g.ldcp = op.ld;
+    g.c_hi_f16 = (out_hi_only && out_hi_f16) ? 1 : 0;
     g.rope_cis = rope_cis; g.rope_L = rope_L; g.rope_n = rope_n; g.rope_grid = rope_grid;
     if (rope_cis && m->cfg.image_size / 16 * (m->cfg.image_size / 16) == rope_grid) g.rope_w = m->cfg.image_size / 16;
   }
@@ -402,6 +413,7 @@ static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int
 }
 // weight planes of a static weight [N, K] (split once, cached)
 static int weight_planes(GemmCtx& ctx, const float* W, int N, int K, GemmPlanes* out, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(ctx.mu());
   auto it = ctx.wc().find(W);
   if (it != ctx.wc().end()) { *out = it->second; return DS2_OK; }
   const int Kp = round32i(K);
@@ -435,6 +447,7 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
   if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_mlp256 %d %d %d", rows, 256, 2 * H);   // (2*M*N*K with K = 2H: both layers)
   GemmPlanes w1p, w2p;
   TRY(weight_planes(ctx, W1, H, 256, &w1p, st));
+  std::unique_lock<std::mutex> lk2(ctx.mu());
   auto it = ctx.w2p().find(W2);
   if (it != ctx.w2p().end()) {
     w2p = it->second;
@@ -450,6 +463,7 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     DS2_CHECK_HIP(hipFree(tmp));
     ctx.w2p()[W2] = w2p;
   }
+  lk2.unlock();
   const unsigned short *xh = nullptr, *xl = nullptr;
   if (m) {
     auto ia = m->act_planes.find(A);
@@ -1016,6 +1030,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
   const bool split = ds2_split_mode();
   const bool klo_planes = ds2_precision() != DS2_PREC_BF16X3K;   // keys of the attention scores carry a lo plane
+  const bool k_f16 = !klo_planes && DS2_ATTN_K_F16;              // bf16x3k: the single operand planes are fp16
   const int nt_c = (Nk + 31) / 32, nt_s = TOK / 32;
   const size_t split_bytes = split ? ((size_t)B * Nk * 256 * 4 + (size_t)B * nt_c * 8192 + (size_t)rows * 256 * 4 +
                                       (size_t)4 * B * nt_s * 8192 + (1u << 20)) : 0;
@@ -1047,7 +1062,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (!vlo_flag) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     static const bool no_vlo_skip = getenv("DS2_ATTN_NO_VLO_SKIP") != nullptr;
     if (no_vlo_skip) vlo_flag = nullptr;
-    TRY(launch_vt_split16(memory, 64, B, Nk, vt_c, 64, st, Nk - n_ptr_tok, vlo_flag));
+    TRY(launch_vt_split16(memory, 64, B, Nk, vt_c, 64, st, Nk - n_ptr_tok, vlo_flag, k_f16));   // (bf16x3k: fp16 planes)
   }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object in the tracking loop
   // (curr is the frame's feature, curr_pos the model constant); the general form takes per-object tokens / positions
@@ -1082,12 +1097,12 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
     if (!split) TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));   // (the bf16x3 kernel rotates q while loading it)
     if (split) {
-      TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st));
+      TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st, k_f16));
       ProfScope _p("kernel.self_attention", st);
       ds2_model::ActPlanes sa_p{};
       float* xs = once ? x1 : x;               // the residual stream this self-attention updates
       if (!m->ma_fold_vo) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
-      TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st));   // all 256 value columns in one pass
+      TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st, 0, nullptr, k_f16));   // all 256 value columns in one pass
       // (measured and not kept: norm2 of the written rows emitted as q_proj's operand planes in this kernel's epilogue - the epilogue's
       // 8-byte plane stores cost the kernel 16 us per launch, what the separate LayerNorm pass costs less its launch: +-0)
       if (m->ma_fold_vo)   // values already carry out_proj: the kernel adds its result to the residual stream in place
@@ -1130,7 +1145,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
       TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
                m->P(p + ".cross_attn_image.k_proj.bias"), K, 256, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m, true, cis, Nk,
-               Nk - n_ptr_tok, TOK, !klo_planes));
+               Nk - n_ptr_tok, TOK, !klo_planes, k_f16));   // (bf16x3k: ONE key plane, fp16)
       const ds2_model::ActPlanes kpl = m->act_planes[K];
       khi = kpl.hi; klo = klo_planes ? kpl.lo : nullptr;
       ProfScope _p("kernel.cross_attention", st);
@@ -1289,14 +1304,84 @@ extern "C" int ds2_sam_heads(ds2_model* m, int32_t B, const float* pix_feat, int
                             multimask, low_res, obj_ptr, obj_logits, ious, stream);
 }
 
+// MaskDecoder.forward as a module of its own (ds2_mask_decoder): the decoder core below runs on the CALLER's sparse / dense
+// prompt embeddings and image_pe and returns all four masks / IoUs / mask tokens before the _forward_sam_heads glue.
+struct SamDecoderIO {
+  const float* sparse_in;   // [B, Ns, 256]
+  int Ns;
+  const float* dense_in;    // [B*4096, 256] token-major
+  const float* image_pe;    // [4096, 256]
+  float *masks4, *iou4, *mask_tokens;   // [B,4,65536], [B,4], [B,4,256]
+};
+static int sam_heads_impl(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
+                          const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
+                          int32_t P, const float* mask_inputs, int32_t multimask, float* low_res, float* obj_ptr,
+                          float* obj_logits, float* ious, void* stream, const SamDecoderIO* io);
+
 extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
                                   const float* fpn0, const float* fpn1, const float* point_coords,
                                   const int32_t* point_labels, int32_t P, const float* mask_inputs, int32_t multimask,
                                   float* low_res, float* obj_ptr, float* obj_logits, float* ious, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && pix_feat && fpn0 && fpn1 && low_res && obj_ptr && obj_logits,
               "ds2_sam_heads: bad argument");
+  return sam_heads_impl(m, B, pix_feat, pix_bcast, add_no_mem_embed, fpn0, fpn1, point_coords, point_labels, P, mask_inputs,
+                        multimask, low_res, obj_ptr, obj_logits, ious, stream, nullptr);
+}
+
+extern "C" int ds2_mask_decoder(ds2_model* m, int32_t B, const float* image_embeddings, const float* image_pe,
+                                const float* sparse, int32_t Ns, const float* dense, const float* feat_s0, const float* feat_s1,
+                                float* masks4, float* iou4, float* mask_tokens, float* obj_logits, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && image_embeddings && image_pe && dense && feat_s0 && feat_s1 && masks4 && iou4 &&
+              mask_tokens && obj_logits && Ns >= 0 && Ns <= 257 && (Ns == 0 || sparse), "ds2_mask_decoder: bad argument");
+  SamDecoderIO io{sparse, Ns, dense, image_pe, masks4, iou4, mask_tokens};
+  return sam_heads_impl(m, B, image_embeddings, 0, 0, feat_s0, feat_s1, nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr,
+                        obj_logits, nullptr, stream, &io);
+}
+
+extern "C" int ds2_prompt_encoder(ds2_model* m, int32_t B, const float* point_coords, const int32_t* point_labels, int32_t P,
+                                  int32_t pad, const float* mask_inputs, float* sparse, float* dense, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && P >= 0 && P <= 256 && (pad == 0 || pad == 1) && (P == 0 || (point_coords && point_labels)),
+              "ds2_prompt_encoder: bad argument");
+  DS2_REQUIRE(P + pad == 0 || sparse, "ds2_prompt_encoder: sparse output missing");
+  ModelScope _dg(m);
+  hipStream_t st = (hipStream_t)stream;
+  const int Ns = P + (P > 0 ? pad : 0);      // no points: no padding point either (prompt_encoder.py:155-160)
+  TRY(m->require(((size_t)B * (6 + Ns) * 256 + (size_t)TOK * 256) * 4 + (1u << 20), st));
+  if (Ns > 0) {
+    ALLOC(tokens, (size_t)B * (6 + Ns) * 256);
+    TRY(launch_prompt_tokens(m->P("@out_tokens6"), m->P("sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"),
+                             m->P("@point_emb4"), m->P("sam_prompt_encoder.not_a_point_embed.weight"), point_coords, point_labels,
+                             B, P, 1024.f, tokens, st, pad));
+    DS2_CHECK_HIP(hipMemcpy2DAsync(sparse, (size_t)Ns * 1024, tokens + 6 * 256, (size_t)(6 + Ns) * 1024, (size_t)Ns * 1024, B,
+                                   hipMemcpyDeviceToDevice, st));
+  }
+  if (dense) {
+    const size_t rows = (size_t)B * TOK;
+    if (mask_inputs) {   // mask_downscaling (prompt_encoder.py:53-61,97-100)
+      const std::string pe = "sam_prompt_encoder.mask_downscaling.";
+      const float* prm[10] = {m->P(pe + "0.weight"), m->P(pe + "0.bias"), m->P(pe + "1.weight"), m->P(pe + "1.bias"),
+                              m->P(pe + "3.weight"), m->P(pe + "3.bias"), m->P(pe + "4.weight"), m->P(pe + "4.bias"),
+                              m->P(pe + "6.weight"), m->P(pe + "6.bias")};
+      for (int i = 0; i < 10; ++i) DS2_REQUIRE(prm[i], "ds2_prompt_encoder: mask_downscaling parameter %d missing", i);
+      ALLOC(zero, (size_t)TOK * 256);
+      DS2_CHECK_HIP(hipMemsetAsync(zero, 0, (size_t)TOK * 256 * 4, st));
+      TRY(launch_mask_downscale_add(mask_inputs, prm, zero, 1, dense, B, st));
+    } else {             // no_mask_embed broadcast over the grid (:167-169)
+      DS2_CHECK_HIP(hipMemsetAsync(dense, 0, rows * 256 * 4, st));
+      TRY(launch_add_rowvec(dense, 256, m->P("@dense_vec"), dense, 256, (int)rows, 256, st));
+    }
+  }
+  CHECK_PARAMS();
+  return DS2_OK;
+}
+
+static int sam_heads_impl(ds2_model* m, int32_t B, const float* pix_feat, int32_t pix_bcast, int32_t add_no_mem_embed,
+                          const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
+                          int32_t P, const float* mask_inputs, int32_t multimask, float* low_res, float* obj_ptr,
+                          float* obj_logits, float* ious, void* stream, const SamDecoderIO* io) {
   ModelScope _dg(m);
   DS2_REQUIRE(P >= 0 && P <= 256 && (P == 0 || (point_coords && point_labels)), "ds2_sam_heads: bad prompt");
+  if (io) P = io->Ns;
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.sam_heads", st);
   const int rows = B * TOK;
@@ -1309,7 +1394,8 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   int Pe = P;
   const float* coords = point_coords;
   const int* labels = point_labels;
-  if (P == 0) {
+  const int pad = io ? 0 : 1;
+  if (P == 0 && !io) {
     Pe = 1;
     float* zc = m->alloc((size_t)B * 2);
     int* ml = reinterpret_cast<int*>(m->alloc_bytes((size_t)B * 4));
@@ -1319,11 +1405,11 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
     coords = zc;
     labels = ml;
   }
-  const int T = 6 + Pe + 1;
+  const int T = 6 + Pe + pad;
   ALLOC(tokens, (size_t)B * T * 256);
   TRY(launch_prompt_tokens(m->P("@out_tokens6"), m->P("sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"),
                            m->P("@point_emb4"), m->P("sam_prompt_encoder.not_a_point_embed.weight"), coords, labels, B, Pe,
-                           1024.f, tokens, st));
+                           1024.f, tokens, st, pad, io ? io->sparse_in : nullptr));
   // src = image_embeddings + dense_prompt (no_mask_embed broadcast)  (mask_decoder.py:203)
   ALLOC(keys, (size_t)rows * 256);
   ALLOC(kpe, (size_t)rows * 256);      // keys + key_pe
@@ -1336,7 +1422,9 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
     src = pm;
   }
   DS2_REQUIRE(pix_bcast || !add_no_mem_embed, "ds2_sam_heads: add_no_mem_embed requires pix_bcast");
-  if (mask_inputs) {   // dense prompt = mask_downscaling(mask) instead of no_mask_embed (prompt_encoder.py:97-100,163-168)
+  if (io) {            // src = image_embeddings + the caller's dense prompt embeddings (mask_decoder.py:203)
+    TRY(launch_add_bcast(pix_feat, 256, io->dense_in, 256, 0, 1.f, keys, 256, rows, 256, st));
+  } else if (mask_inputs) {   // dense prompt = mask_downscaling(mask) instead of no_mask_embed (prompt_encoder.py:97-100,163-168)
     const std::string pe = "sam_prompt_encoder.mask_downscaling.";
     const float* prm[10] = {m->P(pe + "0.weight"), m->P(pe + "0.bias"), m->P(pe + "1.weight"), m->P(pe + "1.bias"),
                             m->P(pe + "3.weight"), m->P(pe + "3.bias"), m->P(pe + "4.weight"), m->P(pe + "4.bias"),
@@ -1362,7 +1450,7 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   ALLOC(tmpk, (size_t)rows * 256);
   ALLOC(kq, (size_t)rows * 256);       // [k_proj of token->image | q_proj of image->token] of the current block
   ALLOC(hid, (size_t)B * T * 2048);
-  const float* dense_pe = m->P("#dense_pe");
+  const float* dense_pe = io ? io->image_pe : m->P("#dense_pe");
   const int BT = B * T;
   // queries = LayerNorm(tmpq); qpe = queries + query_pe (transformer.py:199-201,207-208) - one launch
   auto norm_pe = [&](const std::string& name) -> int {
@@ -1491,6 +1579,13 @@ extern "C" int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat
   if (!heads_batched) {
     TRY(mlp3(m, st, md + ".iou_prediction_head", B, hs + 256, T * 256, 256, 4, iou4, 4, DS2_ACT_SIGMOID));
     TRY(mlp3(m, st, md + ".pred_obj_score_head", B, hs, T * 256, 256, 1, obj_logits, 1, DS2_ACT_NONE));
+  }
+  if (io) {   // MaskDecoder.predict_masks' results (mask_decoder.py:163-259); forward()'s slicing is the caller's (Python module)
+    DS2_CHECK_HIP(hipMemcpyAsync(io->masks4, masks4, (size_t)B * 4 * 65536 * 4, hipMemcpyDeviceToDevice, st));
+    DS2_CHECK_HIP(hipMemcpyAsync(io->iou4, iou4, (size_t)B * 4 * 4, hipMemcpyDeviceToDevice, st));
+    DS2_CHECK_HIP(hipMemcpy2DAsync(io->mask_tokens, 4 * 1024, hs + 2 * 256, (size_t)T * 1024, 4 * 1024, B, hipMemcpyDeviceToDevice, st));
+    CHECK_PARAMS();
+    return DS2_OK;
   }
   ALLOC(sel_tok, (size_t)B * 256);
   TRY(launch_select_masks(masks4, iou4, obj_logits, hs, T * 256, multimask, m->cfg.dynamic_multimask_stability_delta,

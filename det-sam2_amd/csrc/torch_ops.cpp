@@ -166,6 +166,62 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sam_heads(int64_t model, int64_t B, c
   return {low, ptr, obj, iou};
 }
 
+// A7: PromptEncoder.forward (prompt_encoder.py:134-171) -> (sparse [B,Ns,256], dense [B,4096,256] token-major)
+std::tuple<Tensor, Tensor> prompt_encoder(int64_t model, int64_t B, const c10::optional<Tensor>& point_coords,
+                                          const c10::optional<Tensor>& point_labels, bool pad, const c10::optional<Tensor>& mask_inputs,
+                                          const Tensor& like) {
+  TORCH_CHECK(like.is_cuda() && B > 0, "det_sam2::prompt_encoder: `like` must be a device tensor");
+  TORCH_CHECK(point_coords.has_value() == point_labels.has_value(), "det_sam2::prompt_encoder: point_coords and point_labels go together");
+  int64_t P = 0;
+  const int32_t* labels = nullptr;
+  if (point_coords.has_value()) {
+    want(*point_coords, at::kFloat, "point_coords");
+    want(*point_labels, at::kInt, "point_labels");
+    TORCH_CHECK(point_coords->dim() == 3 && point_coords->size(0) == B && point_coords->size(2) == 2 && point_labels->dim() == 2 &&
+                point_labels->size(0) == B && point_labels->size(1) == point_coords->size(1),
+                "det_sam2::prompt_encoder: point_coords [B,P,2] / point_labels [B,P] expected");
+    P = point_coords->size(1);
+    labels = point_labels->data_ptr<int32_t>();
+  }
+  if (mask_inputs.has_value()) {
+    want(*mask_inputs, at::kFloat, "mask_inputs");
+    TORCH_CHECK(mask_inputs->numel() == B * 256 * 256, "det_sam2::prompt_encoder: mask_inputs must be [B,256,256]");
+  }
+  c10::hip::HIPGuardMasqueradingAsCUDA g(like.device());
+  auto o = like.options().dtype(at::kFloat);
+  const int64_t Ns = P ? P + (pad ? 1 : 0) : 0;
+  Tensor sparse = at::empty({B, Ns, 256}, o), dense = at::empty({B, TOK, 256}, o);
+  check(ds2_prompt_encoder(model_of(model), (int32_t)B, P ? fptr(point_coords) : nullptr, P ? labels : nullptr, (int32_t)P, pad ? 1 : 0,
+                           fptr(mask_inputs), Ns ? sparse.data_ptr<float>() : nullptr, dense.data_ptr<float>(), stream_of(like)),
+        "prompt_encoder");
+  return {sparse, dense};
+}
+
+// A8: MaskDecoder.predict_masks (mask_decoder.py:163-259) -> (masks [B,4,256,256], iou [B,4], mask_tokens [B,4,256], obj [B])
+std::tuple<Tensor, Tensor, Tensor, Tensor> mask_decoder(int64_t model, int64_t B, const Tensor& image_embeddings, const Tensor& image_pe,
+                                                        const Tensor& sparse, const Tensor& dense, const Tensor& feat_s0,
+                                                        const Tensor& feat_s1) {
+  want(image_embeddings, at::kFloat, "image_embeddings");
+  want(image_pe, at::kFloat, "image_pe");
+  want(sparse, at::kFloat, "sparse");
+  want(dense, at::kFloat, "dense");
+  want(feat_s0, at::kFloat, "feat_s0");
+  want(feat_s1, at::kFloat, "feat_s1");
+  TORCH_CHECK(image_embeddings.numel() == B * TOK * 256 && dense.numel() == B * TOK * 256 && image_pe.numel() == TOK * 256,
+              "det_sam2::mask_decoder: image_embeddings / dense [B,4096,256], image_pe [4096,256] expected");
+  TORCH_CHECK(sparse.dim() == 3 && sparse.size(0) == B && sparse.size(2) == 256, "det_sam2::mask_decoder: sparse [B,Ns,256] expected");
+  TORCH_CHECK(feat_s0.numel() == 65536 * 32 && feat_s1.numel() == 16384 * 64, "det_sam2::mask_decoder: feat_s0 [65536,32] / feat_s1 [16384,64] expected");
+  c10::hip::HIPGuardMasqueradingAsCUDA g(image_embeddings.device());
+  auto o = image_embeddings.options();
+  const int64_t Ns = sparse.size(1);
+  Tensor masks = at::empty({B, 4, 256, 256}, o), iou = at::empty({B, 4}, o), tok = at::empty({B, 4, 256}, o), obj = at::empty({B}, o);
+  check(ds2_mask_decoder(model_of(model), (int32_t)B, image_embeddings.data_ptr<float>(), image_pe.data_ptr<float>(),
+                         Ns ? sparse.data_ptr<float>() : nullptr, (int32_t)Ns, dense.data_ptr<float>(), feat_s0.data_ptr<float>(),
+                         feat_s1.data_ptr<float>(), masks.data_ptr<float>(), iou.data_ptr<float>(), tok.data_ptr<float>(),
+                         obj.data_ptr<float>(), stream_of(image_embeddings)), "mask_decoder");
+  return {masks, iou, tok, obj};
+}
+
 // A13: SAM2Base._encode_new_memory (sam2_base.py:692-743) -> maskmem bf16 [B,4096,64]
 Tensor memory_encoder(int64_t model, int64_t B, const Tensor& fpn2, const Tensor& low_res, const Tensor& obj_logits, bool binarize) {
   want(fpn2, at::kFloat, "fpn2");
@@ -305,6 +361,8 @@ TORCH_LIBRARY(det_sam2, m) {
   m.def("memory_attention(int model, int B, Tensor curr, Tensor? curr_pos, Tensor memory, Tensor memory_pos, int num_obj_ptr_tokens) -> Tensor");
   m.def("sam_heads(int model, int B, Tensor pix_feat, bool pix_bcast, bool add_no_mem_embed, Tensor fpn0, Tensor fpn1, "
         "Tensor? point_coords, Tensor? point_labels, Tensor? mask_inputs, bool multimask) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("prompt_encoder(int model, int B, Tensor? point_coords, Tensor? point_labels, bool pad, Tensor? mask_inputs, Tensor like) -> (Tensor, Tensor)");
+  m.def("mask_decoder(int model, int B, Tensor image_embeddings, Tensor image_pe, Tensor sparse, Tensor dense, Tensor feat_s0, Tensor feat_s1) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("memory_encoder(int model, int B, Tensor fpn2, Tensor low_res, Tensor obj_logits, bool binarize) -> Tensor");
   m.def("memory_encoder_module(int model, int B, Tensor pix_feat, Tensor masks, bool skip_mask_sigmoid) -> Tensor");
   m.def("resize_aa(Tensor x, int Hout, int Wout, float in_scale, float in_bias, float threshold) -> Tensor");
@@ -324,6 +382,8 @@ TORCH_LIBRARY_IMPL(det_sam2, CUDA, m) {
   m.impl("bank_assemble", &bank_assemble);
   m.impl("memory_attention", &memory_attention);
   m.impl("sam_heads", &sam_heads);
+  m.impl("prompt_encoder", &prompt_encoder);
+  m.impl("mask_decoder", &mask_decoder);
   m.impl("memory_encoder", &memory_encoder);
   m.impl("memory_encoder_module", &memory_encoder_module);
   m.impl("resize_aa", &resize_aa);

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import os
 import pickle
-from collections.abc import Mapping
+from collections.abc import Mapping, Sequence
 
 import numpy as np
 import torch
@@ -45,6 +45,30 @@ class PackedMasks(Mapping):
 
     def to_dict(self):
         return {oid: self[oid] for oid in self.obj_ids}
+
+
+class _FolderFrames(Sequence):
+    """Lazy list of the decodable image files of a folder (see VideoProcessor.load_frames_from_folder)."""
+
+    def __init__(self, folder_path):
+        from PIL import Image
+        self.folder, self.names = folder_path, []
+        for name in sorted(f for f in os.listdir(folder_path) if f.endswith((".png", ".jpg", ".jpeg"))):
+            try:
+                with Image.open(os.path.join(folder_path, name)):       # header only
+                    self.names.append(name)
+            except Exception:
+                print(f"--- cannot read frame file: {os.path.join(folder_path, name)}")
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, i):
+        from PIL import Image, ImageOps
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        with Image.open(os.path.join(self.folder, self.names[i])) as im:
+            return np.ascontiguousarray(np.asarray(ImageOps.exif_transpose(im).convert("RGB"), dtype=np.uint8))
 
 
 class VideoProcessor:
@@ -208,21 +232,13 @@ class VideoProcessor:
         return bank_io.load_bank(load_path)
 
     def load_frames_from_folder(self, folder_path):
-        """det_sam2_RT.py:507-524: the .png / .jpg / .jpeg files of a folder in sorted order, as RGB uint8 arrays.  The
-        reference decodes with cv2.imread + BGR->RGB; here PIL decodes (PNG: identical pixels; JPEG: both sit on libjpeg,
-        but the decoders' IDCT / chroma-upsampling choices are not pinned against each other offline) and the frames are
-        produced lazily, so a long folder never sits in host memory at once.  Unreadable files are skipped (:516-518)."""
-        from PIL import Image
-        names = sorted(f for f in os.listdir(folder_path) if f.endswith((".png", ".jpg", ".jpeg")))
-
-        def gen():
-            for name in names:
-                try:
-                    with Image.open(os.path.join(folder_path, name)) as im:
-                        yield np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
-                except Exception:
-                    print(f"--- cannot read frame file: {os.path.join(folder_path, name)}")
-        return names, gen()
+        """det_sam2_RT.py:507-524: the .png / .jpg / .jpeg files of a folder in sorted order, as a LIST-LIKE of RGB uint8
+        arrays (``len()``, indexing, iteration - the reference returns a list).  The reference decodes with cv2.imread +
+        BGR->RGB; here PIL decodes (PNG: identical pixels; JPEG: both sit on libjpeg, but the decoders' IDCT / chroma
+        choices are not pinned against each other offline), EXIF orientation applied as cv2.imread does, and a frame is
+        decoded when it is accessed, so a long folder never sits in host memory at once.  Files PIL cannot open are
+        dropped up front (:516-518), so an all-unreadable folder is empty and ``run`` returns early as the reference does."""
+        return _FolderFrames(folder_path)
 
     def _video_frames(self, video_path):
         """det_sam2_RT.py:558-579: cv2.VideoCapture + BGR->RGB.  OpenCV is an optional dependency of this path only."""
@@ -258,8 +274,8 @@ class VideoProcessor:
             if frames is None:
                 return None
         elif frames is None and frame_dir is not None:
-            names, frames = self.load_frames_from_folder(frame_dir)
-            if not names:
+            frames = self.load_frames_from_folder(frame_dir)
+            if not len(frames):
                 print(f"--- no frame files found in: {frame_dir}")
                 return None
         elif frames is None:

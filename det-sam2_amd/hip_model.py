@@ -162,6 +162,16 @@ class HipSam2(HipOps):
                         f"set_param({k})")
         _capi.check(self.lib.ds2_model_finalize(self.h, self._stream()), "ds2_model_finalize")
         self.no_obj_ptr = torch.from_numpy(sd_np["no_obj_ptr"]).to(self.device)           # [1,256]
+        # the few tensors the module-level drop-ins hand out themselves (modules.HipPromptEncoder.get_dense_pe, .conv_s0/.conv_s1)
+        keep = ["#dense_pe"] + [f"sam_mask_decoder.conv_s{i}.{w}" for i in (0, 1) for w in ("weight", "bias")]
+        self._kept = {k: torch.from_numpy(np.array((consts if k in consts else sd_np)[k], dtype=np.float32)).to(self.device) for k in keep}
+        self.like = self.no_obj_ptr                                                        # a device tensor for op dispatch
+
+    def constant(self, name):
+        return self._kept[name]
+
+    def parameter(self, name):
+        return self._kept[name]
 
     @classmethod
     def view_of(cls, parent: "HipSam2") -> "HipSam2":
@@ -173,7 +183,7 @@ class HipSam2(HipOps):
         h = C.c_void_p()
         _capi.check(self.lib.ds2_model_create_view(parent.h, C.byref(h)), "ds2_model_create_view")
         self.h = h
-        self.no_obj_ptr = parent.no_obj_ptr
+        self.no_obj_ptr, self._kept, self.like = parent.no_obj_ptr, parent._kept, parent.like
         return self
 
     def __del__(self):

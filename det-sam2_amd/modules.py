@@ -5,6 +5,8 @@
     HipMemoryAttention~ MemoryAttention.forward           (sam2/modeling/memory_attention.py:119-176)
     HipMemoryEncoder  ~ MemoryEncoder.forward             (sam2/modeling/memory_encoder.py:158-181)
     HipSamHeads       ~ SAM2Base._forward_sam_heads       (sam2/modeling/sam2_base.py:254-397) = PromptEncoder + MaskDecoder
+    HipPromptEncoder  ~ PromptEncoder.forward / get_dense_pe / mask_input_size   (sam2/modeling/sam/prompt_encoder.py:134-171,64-71,49)
+    HipMaskDecoder    ~ MaskDecoder.forward, .conv_s0 / .conv_s1                 (sam2/modeling/sam/mask_decoder.py:105-161,73-78)
 
 They take and return the reference's tensors - ``[B,C,H,W]`` feature maps, ``(HW,B,C)`` token sequences - and convert to
 the library's token-major layout at the boundary (permute + contiguous: PyTorch is plumbing here, every number comes
@@ -144,8 +146,127 @@ class HipSamHeads(nn.Module):
         return low, high, torch.cat(ious)[:, None], low, high, torch.cat(ptrs), obj
 
 
+class HipPromptEncoder(nn.Module):
+    """``forward(points, boxes, masks) -> (sparse [B,N,256], dense [B,256,64,64])`` with the reference's argument meaning
+    (prompt_encoder.py:134-171): ``points = (coords [B,P,2] in 1024-grid pixels, labels [B,P])`` - the padding point is
+    appended when ``boxes is None`` (:81-85,158) -, ``boxes [B,4]`` become two corner points labelled 2 / 3 (:106-116),
+    ``masks [B,1,256,256]`` go through ``mask_downscaling`` (:97-100), else ``no_mask_embed`` is broadcast (:167-169).
+    ``get_dense_pe()`` (:64-71) and ``mask_input_size`` (:49) as in the reference."""
+
+    def __init__(self, hip: HipSam2):
+        super().__init__()
+        self.hip = hip
+        self.embed_dim = 256
+        self.image_embedding_size = (64, 64)
+        self.input_image_size = (hip.cfg.image_size, hip.cfg.image_size)
+        self.mask_input_size = (256, 256)
+
+    @torch.inference_mode()
+    def get_dense_pe(self):
+        return _map(self.hip.constant("#dense_pe").reshape(1, TOK, 256), 64, 64)
+
+    @torch.inference_mode()
+    def forward(self, points, boxes, masks):
+        h = self.hip
+        if points is not None:
+            B = points[0].shape[0]
+        elif boxes is not None:
+            B = boxes.shape[0]
+        elif masks is not None:
+            B = masks.shape[0]
+        else:
+            B = 1
+        coords = labels = None
+        if points is not None:
+            coords = points[0].to(h.device, torch.float32).reshape(B, -1, 2)
+            labels = points[1].to(h.device, torch.int32).reshape(B, -1)
+        if boxes is not None:
+            bc = boxes.to(h.device, torch.float32).reshape(B, 2, 2)
+            bl = torch.tensor([2, 3], dtype=torch.int32, device=h.device).expand(B, 2)
+            coords = bc if coords is None else torch.cat([coords, bc], 1)
+            labels = bl if labels is None else torch.cat([labels, bl], 1)
+        mi = None if masks is None else masks.to(h.device, torch.float32).reshape(B, 256, 256).contiguous()
+        sparse, dense = h.ops.prompt_encoder(h._h, B, None if coords is None else coords.contiguous(),
+                                             None if labels is None else labels.contiguous(), boxes is None, mi, h.like)
+        return sparse, _map(dense, 64, 64)
+
+
+class _ConvS(nn.Module):
+    """``conv_s0`` / ``conv_s1`` (mask_decoder.py:73-78) - folded into the image encoder stage here (its fpn levels 0 / 1 come
+    out with them applied, as ``forward_image`` returns them, sam2_base.py:455-460): applied to a feature that still needs it
+    through the reference's weights in fp32 on the device."""
+
+    def __init__(self, hip, name):
+        super().__init__()
+        self.hip, self.name = hip, name
+
+    @torch.inference_mode()
+    def forward(self, x):
+        w = self.hip.parameter(f"sam_mask_decoder.{self.name}.weight")
+        b = self.hip.parameter(f"sam_mask_decoder.{self.name}.bias")
+        return torch.nn.functional.conv2d(x.to(self.hip.device, torch.float32), w, b)
+
+
+class HipMaskDecoder(nn.Module):
+    """``forward(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output, repeat_image,
+    high_res_features=None) -> (masks, iou_pred, sam_tokens_out, object_score_logits)`` (mask_decoder.py:105-161).  The
+    two-way transformer, the upscaling and the hypernetwork / IoU / object-score heads run in ``ds2_mask_decoder``; the output
+    slicing of ``forward`` (multimask slice, ``_dynamic_multimask_via_stability`` :261-296) is index arithmetic on four
+    masks per object, done here on the device."""
+
+    def __init__(self, hip: HipSam2):
+        super().__init__()
+        self.hip = hip
+        self.conv_s0, self.conv_s1 = _ConvS(hip, "conv_s0"), _ConvS(hip, "conv_s1")
+        self.dynamic_multimask_via_stability = True        # build_sam.py:126-135
+        self.dynamic_multimask_stability_delta = hip.cfg.dynamic_multimask_stability_delta
+        self.dynamic_multimask_stability_thresh = hip.cfg.dynamic_multimask_stability_thresh
+        self.use_multimask_token_for_obj_ptr = True
+
+    def _dynamic_multimask_via_stability(self, masks, iou):
+        B = masks.shape[0]
+        ar = torch.arange(B, device=masks.device)
+        best = torch.argmax(iou[:, 1:], dim=-1)
+        best_masks, best_iou = masks[:, 1:][ar, best][:, None], iou[:, 1:][ar, best][:, None]
+        single, single_iou = masks[:, 0:1], iou[:, 0:1]
+        flat = single.flatten(-2)
+        d = self.dynamic_multimask_stability_delta
+        area_i, area_u = (flat > d).sum(-1).float(), (flat > -d).sum(-1).float()
+        stable = torch.where(area_u > 0, area_i / area_u, torch.ones_like(area_u)) >= self.dynamic_multimask_stability_thresh
+        return (torch.where(stable[..., None, None].expand_as(single), single, best_masks),
+                torch.where(stable.expand_as(single_iou), single_iou, best_iou))
+
+    @torch.inference_mode()
+    def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output,
+                repeat_image, high_res_features=None):
+        h = self.hip
+        assert high_res_features is not None and len(high_res_features) == 2, "use_high_res_features is on in SAM 2.1"
+        sp = sparse_prompt_embeddings.to(h.device, torch.float32).contiguous()
+        B = sp.shape[0]
+        emb = image_embeddings.to(h.device, torch.float32)
+        if repeat_image:
+            emb = torch.repeat_interleave(emb, B, dim=0)
+        assert emb.shape[0] == B
+        emb, dense = _tok(emb), _tok(dense_prompt_embeddings.to(h.device, torch.float32).expand(B, -1, -1, -1))
+        pe = _tok(image_pe.to(h.device, torch.float32))[0].contiguous()
+        f0 = _tok(high_res_features[0].to(h.device, torch.float32).expand(B, -1, -1, -1))
+        f1 = _tok(high_res_features[1].to(h.device, torch.float32).expand(B, -1, -1, -1))
+        outs = [h.ops.mask_decoder(h._h, 1, emb[b:b + 1], pe, sp[b:b + 1], dense[b:b + 1], f0[b], f1[b]) for b in range(B)]
+        masks, iou, tok, obj = (torch.cat([o[i] for o in outs]) for i in range(4))
+        if multimask_output:
+            masks, iou = masks[:, 1:], iou[:, 1:]
+        elif self.dynamic_multimask_via_stability:
+            masks, iou = self._dynamic_multimask_via_stability(masks, iou)
+        else:
+            masks, iou = masks[:, 0:1], iou[:, 0:1]
+        tokens = tok[:, 1:] if (multimask_output and self.use_multimask_token_for_obj_ptr) else tok[:, 0:1]
+        return masks, iou, tokens, obj[:, None]
+
+
 def build_modules(cfg, state_dict, device="cuda:0", max_batch=16):
-    """-> dict(image_encoder, memory_attention, memory_encoder, sam_heads, hip) over one shared ``ds2_model``."""
+    """-> dict(image_encoder, memory_attention, memory_encoder, sam_heads, sam_prompt_encoder, sam_mask_decoder, hip) over one
+    shared ``ds2_model``."""
     hip = HipSam2(cfg, state_dict, device, max_batch)
     return {"hip": hip, "image_encoder": HipImageEncoder(hip), "memory_attention": HipMemoryAttention(hip),
-            "memory_encoder": HipMemoryEncoder(hip), "sam_heads": HipSamHeads(hip)}
+            "memory_encoder": HipMemoryEncoder(hip), "sam_heads": HipSamHeads(hip),
+            "sam_prompt_encoder": HipPromptEncoder(hip), "sam_mask_decoder": HipMaskDecoder(hip)}

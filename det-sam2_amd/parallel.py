@@ -11,8 +11,9 @@ pass k -> rank k mod N, and a round is
        (ring shift over one xGMI link: buffer x 16 MiB) - a frame is encoded exactly once per stream although two passes
        (on two ranks) track it.  The shift is POSTED here and waited for only before step 5 (the received pyramids are
        first read by the propagation), so steps 2-4 run under the transfer;
-    2. every rank runs the detector on its buffer; the detections are all-gathered as ONE fixed-size tensor per rank
-       ([1 + MAX_DET, 7] fp64: frame, xyxy, class, confidence; row 0 = count - no pickling, one collective), so every
+    2. every rank runs the detector on its buffer; the detections are all-gathered as one tensor per rank ([1 + cap, 7]
+       fp64: frame, xyxy, class, confidence; row 0 = count; cap = the round's largest row count, agreed on by a 4-byte
+       count all-gather - no pickling, no fixed limit on the detections of a pass), so every
        rank derives the same object table for every pass of the round;
     3. every rank prompts + consolidates ITS conditioning frame(s) - ~50 ms, no dependence on other passes;
     4. ONE all-gather replicates the new conditioning entries (bf16 memory + masks + pointers + the frame's level-2
@@ -124,6 +125,10 @@ class TorchDistComm:
         self.group, self.device = group, device
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.host_staged = dist.get_backend(group) == "gloo"
+        if not self.host_staged and self.device is None:   # RCCL moves device tensors only: small host tensors need a home
+            if not torch.cuda.is_available():
+                raise RuntimeError("TorchDistComm: backend 'nccl' (RCCL) needs a GPU; pass device= or use 'gloo'")
+            self.device = torch.device("cuda", torch.cuda.current_device())
 
     def _wire(self, t):
         if self.host_staged:
@@ -430,8 +435,12 @@ def _make_sharded_cls():
                 self.special_classes_detection, self.special_classes_count = keep     # applied in pass order in step 5
             tp = self._tick(rec, "detect", tp)
             if N > 1:
-                all_dets = yield ("all_gather_tensor", dets_to_tensor(dets))
-                self.comm_log.append((round_idx, "all_gather_dets", (1 + MAX_DET) * 7 * 8 * N))
+                # rows on the wire = the round's largest pass (counts first, 4 bytes per rank): no fixed cap on the number of
+                # detections of a pass (detect_interval 1, buffer 30, 16+ objects is 480 rows)
+                n_rows = yield ("all_gather_tensor", torch.tensor([dets_count(dets)], dtype=torch.int32))
+                cap = max(1, max(int(x[0]) for x in n_rows))
+                all_dets = yield ("all_gather_tensor", dets_to_tensor(dets, cap))
+                self.comm_log.append((round_idx, "all_gather_dets", (4 + (1 + cap) * 7 * 8) * N))
                 all_dets = [dets_from_tensor(x) for x in all_dets][:n_pass]
             else:
                 all_dets = [dets]
@@ -460,7 +469,9 @@ def _make_sharded_cls():
             #         pass contributes (frame, batch) travels first as a fixed-size int32 tensor
             meta = {t: int(e["obj_ptr"].shape[0]) for t, e in my_entries.items()}
             if N > 1:
-                metas = yield ("all_gather_tensor", meta_to_tensor(meta))
+                # a pass announces at most one entry per frame it holds detections for - known to every rank from step 2
+                cond_cap = max(1, max(len(x) for x in all_dets))
+                metas = yield ("all_gather_tensor", meta_to_tensor(meta, cond_cap))
                 metas = [meta_from_tensor(x) for x in metas][:n_pass]
             else:
                 metas = [meta]
@@ -550,20 +561,21 @@ def _make_sharded_cls():
     return ShardedVideoProcessor
 
 
-MAX_DET = 255         # detections of one pass on the wire (rows of the fixed-size tensor; exceeded => error, not truncation)
-MAX_COND = 31         # new conditioning entries one pass may announce per round
+def dets_count(dets) -> int:
+    return sum(len(v) for v in (dets or {}).values())
 
 
-def dets_to_tensor(dets) -> torch.Tensor:
-    """{frame: [detection dict]} (detect_predict's output, det_sam2_RT.py:228-244) -> fp64 [1 + MAX_DET, 7]: row 0 =
+def dets_to_tensor(dets, cap: int) -> torch.Tensor:
+    """{frame: [detection dict]} (detect_predict's output, det_sam2_RT.py:228-244) -> fp64 [1 + cap, 7] (``cap`` = the
+    largest row count of the round, agreed on by a count all-gather just before, so every rank sends the same shape): row 0 =
     [count, 0...]; row i = [frame, x0, y0, x1, y1, class, confidence] (the dict keys are "frame_<i>", det_sam2_RT.py:224).  fp32 boxes / classes / confidences and frame
     indices are exact in fp64; detection order (which decides object-table order) is the row order."""
     rows = [(float(str(k).rsplit("_", 1)[-1]), *np.asarray(d["coordinates"], np.float32).reshape(4).astype(np.float64).tolist(),
              float(np.asarray(d["class"], np.float32).reshape(-1)[0]), float(np.asarray(d["confidence"], np.float32).reshape(-1)[0]))
             for k, v in (dets or {}).items() for d in v]
-    if len(rows) > MAX_DET:
-        raise RuntimeError(f"{len(rows)} detections in one pass exceed the wire format's {MAX_DET}")
-    out = torch.zeros((1 + MAX_DET, 7), dtype=torch.float64)
+    if len(rows) > cap:
+        raise RuntimeError(f"{len(rows)} detections in one pass exceed the agreed wire size {cap}")
+    out = torch.zeros((1 + cap, 7), dtype=torch.float64)
     out[0, 0] = len(rows)
     if rows:
         out[1:1 + len(rows)] = torch.tensor(rows, dtype=torch.float64)
@@ -580,11 +592,12 @@ def dets_from_tensor(t: torch.Tensor):
     return out
 
 
-def meta_to_tensor(meta) -> torch.Tensor:
-    """{cond frame: batch size} -> int32 [1 + MAX_COND, 2] (row 0 = count)."""
-    if len(meta) > MAX_COND:
-        raise RuntimeError(f"{len(meta)} conditioning frames in one pass exceed the wire format's {MAX_COND}")
-    out = torch.zeros((1 + MAX_COND, 2), dtype=torch.int32)
+def meta_to_tensor(meta, cap: int) -> torch.Tensor:
+    """{cond frame: batch size} -> int32 [1 + cap, 2] (row 0 = count; ``cap`` = the largest number of detection frames of
+    a pass of the round, which every rank knows after the detection all-gather)."""
+    if len(meta) > cap:
+        raise RuntimeError(f"{len(meta)} conditioning frames in one pass exceed the agreed wire size {cap}")
+    out = torch.zeros((1 + cap, 2), dtype=torch.int32)
     out[0, 0] = len(meta)
     for i, t in enumerate(sorted(meta)):
         out[1 + i, 0], out[1 + i, 1] = int(t), int(meta[t])

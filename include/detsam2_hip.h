@@ -70,8 +70,9 @@ int ds2_model_set_param(ds2_model* m, const char* name, const void* data, int64_
 int ds2_model_finalize(ds2_model* m, void* stream);
 /* A second execution context over the SAME weights (parameters, derived constants, bf16 weight planes are the parent's, which
  * must outlive the view); own workspace arena, GEMM scratch and arithmetic mode.  For running a stage on another stream
- * concurrently with the parent (the predictor encodes the next frames ahead of need this way).  Destroy with
- * ds2_model_destroy. */
+ * concurrently with the parent (the predictor encodes the next frames ahead of need this way).  A parent and its views may
+ * be driven from different host threads (the shared weight-plane caches are filled under a mutex); ONE model or view is
+ * not re-entrant - one host thread at a time, like the reference's predictor.  Destroy with ds2_model_destroy. */
 int ds2_model_create_view(ds2_model* parent, ds2_model** out);
 
 /* ---- A3: frame ingest.  load_video_frames, list-of-ndarray branch (sam2/utils/misc.py:280-284,
@@ -130,6 +131,22 @@ int ds2_sam_heads_mask(ds2_model* m, int32_t B, const float* pix_feat, int32_t p
                        const float* fpn0, const float* fpn1, const float* point_coords, const int32_t* point_labels,
                        int32_t P, const float* mask_inputs, int32_t multimask_output, float* low_res, float* obj_ptr,
                        float* obj_logits, float* ious, void* stream);
+
+/* ---- A7 alone: PromptEncoder.forward (sam2/modeling/sam/prompt_encoder.py:134-171) as a module of its own.
+ * point_coords [B,P,2] (1024-grid pixels; box corners are points labelled 2 / 3, :106-116) / point_labels [B,P]; pad != 0
+ * appends the padding point (:81-85: what the reference does when `boxes is None`).  mask_inputs fp32 [B,256,256] or NULL
+ * (-> no_mask_embed).  sparse [B, P + (P ? pad : 0), 256], dense [B,4096,256] token-major (either may be NULL). */
+int ds2_prompt_encoder(ds2_model* m, int32_t B, const float* point_coords, const int32_t* point_labels, int32_t P, int32_t pad,
+                       const float* mask_inputs, float* sparse, float* dense, void* stream);
+
+/* ---- A8 alone: MaskDecoder.predict_masks (sam2/modeling/sam/mask_decoder.py:163-259) on the CALLER's prompt embeddings:
+ * image_embeddings [B,4096,256], image_pe [4096,256], sparse [B,Ns,256], dense [B,4096,256] (all token-major), feat_s0
+ * [65536,32] / feat_s1 [16384,64] = high_res_features (conv_s0 / conv_s1 applied) shared by the B objects ->
+ * masks4 [B,4,256,256], iou4 [B,4], mask_tokens [B,4,256], obj_logits [B].  MaskDecoder.forward's slicing (:140-161:
+ * multimask / dynamic stability selection) is done by the caller (det_sam2_amd.modules.HipMaskDecoder). */
+int ds2_mask_decoder(ds2_model* m, int32_t B, const float* image_embeddings, const float* image_pe, const float* sparse,
+                     int32_t Ns, const float* dense, const float* feat_s0, const float* feat_s1, float* masks4, float* iou4,
+                     float* mask_tokens, float* obj_logits, void* stream);
 
 /* ---- A13: SAM2Base._encode_new_memory (sam2_base.py:692-743) = 256->1024 bilinear upsample
  * (:355-360) + sigmoid|binarize, *20-10 + MemoryEncoder.forward (memory_encoder.py:158-181) +

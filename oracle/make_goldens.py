@@ -458,6 +458,106 @@ def heldout_large(variant="s1", name="sam2.1_hiera_l"):
           "fg fraction", float((out["low"] > 0).mean()))
 
 
+# ---------------------------------------------------------------------------------------------- round 4: measured shape
+# VERDICT r3 missing #2: an end-to-end reference fixture AT the benchmark's shape (sam2.1_hiera_l x 16 objects with the
+# bank grown to 1 conditioning + 6 non-conditioning frames, Nk = 28 736) and one for BASELINE config 3's model
+# (sam2.1_hiera_base_plus, preloaded bank).
+L16_KW = dict(skip_classes=set(), frame_buffer_size=9, detect_interval=9, max_frame_num_to_track=9,
+              max_inference_state_frames=-1)
+L16_FRAMES = 9
+
+
+def _large_b16(fname, weight_seed=0, logit_scale=1.0, structured=False, name="sam2.1_hiera_l"):
+    vp, yields, passes, final_keys, dt = _run_reference_stream(name, L16_FRAMES, SyntheticDetector(16), weight_seed,
+                                                               logit_scale, structured, **L16_KW)
+    out = {"seconds": np.float64(dt), "frames": np.array([y[1] for y in yields]),
+           "nobj": np.array([len(y[2]) for y in yields]),
+           "logit_absmax": np.float32(max(float(np.abs(y[3]).max()) for y in yields))}
+    for i, y in enumerate(yields):
+        _compact(out, i, y[3], y[4])
+        # the video-resolution masks in FULL (packed; blobs compress well): BASELINE's bar is the IoU of THESE masks, and on
+        # masks of ~5 500 low-res pixels (the structured frames) a 4x decimated copy turns one boundary pixel into 2e-4
+        out[f"bitsfull{i}"] = np.packbits(y[4])
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    print(fname, dt, "s", out["frames"], passes, final_keys, "logit absmax", float(out["logit_absmax"]))
+
+
+def e2e_large_b16():
+    """The BENCHMARK's shape end to end through the reference: sam2.1_hiera_l, 16 objects, ONE reverse pass over 9 frames
+    with the boxes on frame 0 - frame 8 is tracked against the conditioning frame alone, frame 7 against 1 + 1, ...,
+    frames 2 and 1 against 1 conditioning + 6 non-conditioning frames + 4 x (1 + 6 ... 7) pointer tokens
+    (sam2_video_predictor.py:911-1025 driven by det_sam2_RT.py:342-411; bank sam2_base.py:479-690)."""
+    _large_b16("e2e_large_b16.npz")
+
+
+def heldout_large_b16(variant="s1"):
+    ws, ls, st = HELDOUT[variant]
+    _large_b16(f"ho_large_b16_{variant}.npz", ws, ls, st)
+
+
+BPLUS_A = dict(skip_classes=set(), frame_buffer_size=1, detect_interval=1, max_frame_num_to_track=1,
+               max_inference_state_frames=-1)        # bank-building run: ONE conditioning frame (P = 1)
+BPLUS_B = dict(skip_classes=set(), frame_buffer_size=4, detect_interval=-1, max_frame_num_to_track=4,
+               max_inference_state_frames=-1)        # preloaded run: no detector, 4 frames tracked from the bank
+BPLUS_OBJECTS = 4
+
+
+def _bplus(fname, weight_seed=0, logit_scale=1.0, structured=False, name="sam2.1_hiera_b+"):
+    det = SyntheticDetector(BPLUS_OBJECTS)
+    vpa, ya, pa, ka, dta = _run_reference_stream(name, 1, det, weight_seed, logit_scale, structured, **BPLUS_A)
+    scratch = os.path.join(os.path.dirname(GOLD), "_scratch")
+    os.makedirs(scratch, exist_ok=True)
+    tmp = os.path.join(scratch, "bank_bplus.pkl")
+    vpa.save_inference_state(tmp)
+    cfg = resolve_config(name)
+    vp = RS.make_reference_video_processor(f"configs/sam2.1/{name}.yaml", synthetic_state_dict(cfg, weight_seed, logit_scale),
+                                           **BPLUS_B)
+    vp.inference_state = vp.load_inference_state(tmp)
+    od = vp.inference_state["output_dict"]
+    vp.inference_state["preloading_memory_cond_frame_idx"] = list(od["cond_frame_outputs"].keys())
+    vp.inference_state["preloading_memory_non_cond_frames_idx"] = list(od["non_cond_frame_outputs"].keys())
+    vp.pre_frames = vp.inference_state["num_frames"]
+    vp.predictor.init_preloading_state(vp.inference_state)
+    yields = []
+    orig = vp.predictor.propagate_in_video
+
+    def capturing(state, **kw):
+        for t, ids, logits in orig(state, **kw):
+            o = state["output_dict"]
+            key = "cond_frame_outputs" if t in o["cond_frame_outputs"] else "non_cond_frame_outputs"
+            yields.append((t, list(ids), o[key][t]["pred_masks"].clone().numpy(), (logits > 0).numpy()))
+            yield t, ids, logits
+
+    vp.predictor.propagate_in_video = capturing
+    t0 = time.time()
+    for i in range(4):
+        vp.process_frame(vp.pre_frames + i, synthetic_frame(100 + i, structured=structured))
+    dt = time.time() - t0
+    out = {"seconds": np.float64(dt), "frames": np.array([y[0] for y in yields]),
+           "low": np.stack([y[2] for y in yields]).astype(np.float32),            # [4,4,1,256,256] fp32 logits
+           "bits": np.stack([np.packbits(y[3]) for y in yields])}
+    assert not ya          # a reverse pass starting on frame 0 yields nothing: the bank holds the consolidated cond frame only
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    os.remove(tmp)
+    os.rmdir(scratch)
+    print(fname, dta, dt, "s", out["frames"], out["low"].shape, sorted(vp.video_segments),
+          "logit absmax", float(np.abs(out["low"]).max()))
+
+
+def e2e_bplus():
+    """BASELINE config 3's model end to end through the reference: sam2.1_hiera_base_plus, 4 objects; run A prompts one
+    frame and pickles the state with the reference's save_inference_state (det_sam2_RT.py:489-497) - a bank of P = 1
+    conditioning frame; run B preloads it (:539-549, sam2_video_predictor.py:123-156) and tracks 4 new frames with
+    detect_interval = -1 (one reverse pass: 1 preload cond frame + 0..3 non-conditioning frames)."""
+    _bplus("e2e_bplus.npz")
+
+
+def heldout_bplus(variant="s1"):
+    ws, ls, st = HELDOUT[variant]
+    _bplus(f"ho_bplus_{variant}.npz", ws, ls, st)
+
+
+
 if __name__ == "__main__":
     assert RS.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)

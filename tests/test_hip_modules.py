@@ -64,7 +64,33 @@ def test_modules_match_reference_fixtures(mods, prec, golden_dir):
     errs["heads_high"] = _rel(fs[4][:, :, ::16, ::16].cpu(), g["heads_high"])
     errs["heads_ptr"] = _rel(fs[5].cpu(), g["heads_ptr"])
     errs["heads_obj"] = _rel(fs[6].cpu(), g["heads_obj"])
+    # ---- PromptEncoder.forward / get_dense_pe / mask_input_size (prompt_encoder.py:134-171,64-71,49)
+    pe_mod, md_mod = m["sam_prompt_encoder"], m["sam_mask_decoder"]
+    assert tuple(pe_mod.mask_input_size) == (256, 256)
+    sp, de = pe_mod(points=(x["coords"], x["labels"]), boxes=None, masks=x["mask_prompt"])
+    assert tuple(sp.shape) == (2, 3, 256) and tuple(de.shape) == (2, 256, 64, 64)
+    errs["sparse"] = _rel(sp.cpu(), g["sparse"])
+    errs["dense"] = _rel(de[:, ::8, ::4, ::4].cpu(), g["dense"])
+    dpe = pe_mod.get_dense_pe()
+    assert tuple(dpe.shape) == (1, 256, 64, 64)
+    errs["dense_pe"] = _rel(dpe[0, ::8, ::4, ::4].cpu(), g["dense_pe"])
+    # boxes: the two corners as points labelled 2 / 3 without the padding point (prompt_encoder.py:106-116,158) - the same
+    # embeddings the (coords, labels = [2, 3]) point form gives before its padding token
+    spb, _ = pe_mod(points=None, boxes=x["coords"].reshape(2, 4), masks=None)
+    assert tuple(spb.shape) == (2, 2, 256) and torch.equal(spb, sp[:, :2])
+    # ---- MaskDecoder.forward (mask_decoder.py:105-161) on the prompt encoder's own outputs, both multimask settings
+    s_, d_ = pe_mod(points=(x["coords"], x["labels"]), boxes=None, masks=None)
+    for mm in (True, False):
+        r = md_mod(image_embeddings=x["emb"], image_pe=dpe, sparse_prompt_embeddings=s_, dense_prompt_embeddings=d_,
+                   multimask_output=mm, repeat_image=False, high_res_features=[x["hr0"], x["hr1"]])
+        n = 3 if mm else 1
+        assert tuple(r[0].shape) == (2, n, 256, 256) and tuple(r[1].shape) == (2, n) and tuple(r[2].shape) == (2, n, 256) and tuple(r[3].shape) == (2, 1)
+        errs[f"dec{int(mm)}_masks"] = _rel(r[0][:, :, ::4, ::4].cpu(), g[f"dec{int(mm)}_masks"])
+        errs[f"dec{int(mm)}_iou"] = _rel(r[1].cpu(), g[f"dec{int(mm)}_iou"])
+        errs[f"dec{int(mm)}_tok"] = _rel(r[2].cpu(), g[f"dec{int(mm)}_tok"])
+        errs[f"dec{int(mm)}_obj"] = _rel(r[3].cpu(), g[f"dec{int(mm)}_obj"])
     record("modules_vs_reference", config=name, prec=prec, **errs)
     for k, e in errs.items():
-        bound = 1e-6 if k in ("pos2", "memenc_pos") else (tol * (3 if k.startswith("fpn") or k.startswith("heads") else 1))
+        bound = (1e-6 if k in ("pos2", "memenc_pos", "dense_pe", "sparse") else
+                 (tol * (3 if k.startswith("fpn") or k.startswith("heads") or k.startswith("dec") else 1)))
         assert e <= bound, (name, prec, k, e, errs)

@@ -452,3 +452,51 @@ def test_e2e_correction_prompts_match_reference_golden(tiny, golden_dir):
         ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
         for o in range(2):
             assert 1.0 - _iou((logits > 0).numpy()[o], ref[o]) <= 1e-3, (t, o)
+
+
+# ---------------------------------------------------------------------------------------------- round 4: measured shape
+# e2e_large_b16 / e2e_bplus (+ held-out s1): the reference's own output at the benchmark's shape (hiera_l x 16 objects, bank of
+# 1 conditioning + 6 non-conditioning frames) and for BASELINE config 3's model (hiera_b+, preloaded bank of P = 1).
+@pytest.mark.parametrize("variant", ["seed0", "s1"])
+def test_e2e_base_plus_preloaded_bank_matches_reference_golden(variant, golden_dir, tmp_path):
+    from oracle.make_goldens import BPLUS_A, BPLUS_B, BPLUS_OBJECTS, HELDOUT
+    ws, ls, st = (0, 1.0, False) if variant == "seed0" else HELDOUT[variant]
+    cfg = resolve_config("sam2.1_hiera_b+")
+    sd = synthetic_state_dict(cfg, ws, ls)
+    g = np.load(os.path.join(golden_dir, "e2e_bplus.npz" if variant == "seed0" else f"ho_bplus_{variant}.npz"))
+    a = OracleVideoProcessor(sd, cfg, SyntheticDetector(BPLUS_OBJECTS), **BPLUS_A)
+    with torch.inference_mode():
+        a.process_frame(0, synthetic_frame(0, structured=st))
+        a.save_inference_state(str(tmp_path / "bank.pkl"))
+        b = OracleVideoProcessor(sd, cfg, SyntheticDetector(BPLUS_OBJECTS), **BPLUS_B)
+        b.preload(str(tmp_path / "bank.pkl"))
+        assert b.pre_frames == 1
+        for i in range(4):
+            b.process_frame(1 + i, synthetic_frame(100 + i, structured=st))
+    assert b.pass_log[0][1] == list(g["frames"])
+    od = b.inference_state["output_dict"]
+    amax = float(np.abs(g["low"]).max())
+    for i, t in enumerate(g["frames"]):
+        low = od["non_cond_frame_outputs"][int(t)]["pred_masks"].numpy()
+        assert np.abs(low - g["low"][i]).max() <= 2e-4 * amax
+        assert np.abs(low - g["low"][i]).mean() <= 1e-5 * amax
+        ref = np.unpackbits(g["bits"][i]).reshape(BPLUS_OBJECTS, 1, 1024, 1024).astype(bool)
+        for o in range(BPLUS_OBJECTS):
+            assert 1.0 - _iou(b.video_segments[int(t)][o], ref[o]) <= 1e-3
+
+
+@pytest.mark.skipif(not os.environ.get("DS2_SLOW_ORACLE"), reason="~15 min of CPU per variant: DS2_SLOW_ORACLE=1 to run "
+                    "(result of the run made when the fixture was committed: profiles/r04_oracle_large_b16.txt)")
+@pytest.mark.parametrize("variant", ["seed0", "s1"])
+def test_e2e_large_16_objects_full_bank_matches_reference_golden(variant, golden_dir):
+    """The benchmark's shape: sam2.1_hiera_l, 16 objects, one reverse pass over 9 frames (bank up to 1 + 6 frames)."""
+    from oracle.make_goldens import HELDOUT, L16_FRAMES, L16_KW
+    ws, ls, st = (0, 1.0, False) if variant == "seed0" else HELDOUT[variant]
+    cfg = resolve_config("sam2.1_hiera_l")
+    g = np.load(os.path.join(golden_dir, "e2e_large_b16.npz" if variant == "seed0" else f"ho_large_b16_{variant}.npz"))
+    vp = OracleVideoProcessor(synthetic_state_dict(cfg, ws, ls), cfg, SyntheticDetector(16), **L16_KW)
+    lows = _capture(vp)
+    with torch.inference_mode():
+        for t in range(L16_FRAMES):
+            vp.process_frame(t, synthetic_frame(t, structured=st))
+    _check_compact(g, lows)

@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -172,16 +173,19 @@ def test_detection_and_meta_wire_formats_round_trip():
                          {"coordinates": np.array([0.1, 0.2, 0.3, 0.4], np.float32), "class": np.array([11.0], np.float32),
                           "confidence": np.array([0.3], np.float32)}],
             "frame_45": []}
-    t = P.dets_to_tensor(dets)
-    assert tuple(t.shape) == (1 + P.MAX_DET, 7) and t.dtype == torch.float64
+    assert P.dets_count(dets) == 2
+    t = P.dets_to_tensor(dets, 5)
+    assert tuple(t.shape) == (1 + 5, 7) and t.dtype == torch.float64
     back = P.dets_from_tensor(t)
     assert list(back) == ["frame_30"] and len(back["frame_30"]) == 2
     for a, b in zip(back["frame_30"], dets["frame_30"]):
         for k in ("coordinates", "class", "confidence"):
             assert a[k].dtype == np.float32 and np.array_equal(a[k], b[k])          # bit-exact fp32 through fp64
-    assert P.dets_from_tensor(P.dets_to_tensor({})) == {}
+    assert P.dets_from_tensor(P.dets_to_tensor({}, 1)) == {}
     meta = {90: 16, 60: 17}
-    assert P.meta_from_tensor(P.meta_to_tensor(meta)) == meta
+    assert P.meta_from_tensor(P.meta_to_tensor(meta, 2)) == meta
+    with pytest.raises(RuntimeError):
+        P.dets_to_tensor(dets, 1)
 
 
 def test_merge_segments_rule():

@@ -96,8 +96,12 @@ def test_run_from_a_frame_folder_equals_run_from_memory(tmp_path):
     for t in segs_a:
         for o in segs_a[t]:
             assert np.array_equal(segs_a[t][o], segs_b[t][o])
+    lst = b.load_frames_from_folder(str(tmp_path))          # list-like, as the reference's return value (:507-524)
+    assert len(lst) == 7 and np.array_equal(lst[2], frames[2]) and np.array_equal(lst[-1], frames[-1]) and len(lst[1:3]) == 2
     empty = tmp_path / "empty"
     empty.mkdir()
+    assert VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(frame_dir=str(empty)) is None
+    (empty / "00000.png").write_bytes(b"not a png")        # only unreadable files: returns early like the reference (:586-588)
     assert VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(frame_dir=str(empty)) is None
     with pytest.raises(NotImplementedError, match="OpenCV"):
         VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(video_path="x.mp4")

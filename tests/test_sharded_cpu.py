@@ -94,3 +94,18 @@ def test_no_release_and_detect_every_frame():
     seq = _sequential(frames, {2: 4}, **over)
     vps = _sharded(frames, {2: 4}, 2, **over)
     _same(P.merge_segments([v.video_segments for v in vps], 3, 6, 3, 2), seq.video_segments)
+
+
+def test_more_than_255_detections_in_one_pass():
+    """the detection all-gather had a fixed 255-row wire format; a pass with detect_interval 1 and many boxes per
+    frame overflowed it while the sequential driver handled the same stream.  The row count is now agreed on per round."""
+    det = lambda: SyntheticDetector(3, size=32, duplicates={0: 20, 1: 20, 2: 20}, class_ids=[5, 2, 8])   # noqa: E731  63 boxes / frame
+    over = dict(frame_buffer_size=5, detect_interval=1, max_frame_num_to_track=10, max_inference_state_frames=-1)
+    frames = [synthetic_frame(t, size=32) for t in range(10)]
+    assert sum(len(det()(t)) for t in range(5)) == 315
+    seq = VideoProcessor(detector=det(), predictor=fake_predictor(), **{**KW, **over})
+    seq.run(frames=frames)
+    vps = [P.ShardedVideoProcessor(detector=det(), predictor=fake_predictor(), rank=r, world_size=2, **{**KW, **over}) for r in range(2)]
+    P.drive_lockstep(vps, frames)
+    _same(P.merge_segments([v.video_segments for v in vps], 5, 10, 2, 2), seq.video_segments)
+    assert any(kind == "all_gather_dets" and nbytes > 2 * 256 * 7 * 8 for v in vps for _, kind, nbytes in v.comm_log)
