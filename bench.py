@@ -87,10 +87,17 @@ def path_flops(model_name, B, nk):
     return (F_ENC_GFLOP[model_name] + B * (116.0 + 0.017039 * nk + 3.64 + 11.61)) * 1e9
 
 
-def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
-    """Oracle (CPU restatement, oracle/) timed on the host cores on a bounded sample of the same workload:
-    one tracked frame with ONE object (encoder + bank of 7 frames/16 pointers + memory attention + SAM heads +
-    memory encoder), then scaled to 16 objects: t_frame(16) = t_encoder + 16 * t_per_object."""
+def metric_name(model_name, n_obj):
+    """BASELINE.json's metric string for the headline workload; any other --model / --objects is named as what it is."""
+    short = model_name.replace("sam2.1_", "").replace("hiera_large", "hiera_l").replace("hiera_base_plus", "hiera_b+")
+    return f"frames/sec/GPU propagate_in_video, {short}, {n_obj} obj, 1024^2; mask IoU vs ref"
+
+
+def cpu_baseline(model_name, n_obj=16):
+    """Oracle (CPU restatement, oracle/) timed on the host cores on a bounded sample of the same workload: ONE tracked frame
+    at the FULL object count (encoder + bank of 7 frames / 16 pointers + memory attention + SAM heads + memory encoder for
+    `n_obj` objects in one batch, as the reference runs it) - measured, not scaled.  The one-object
+    timing and the value the earlier rounds modelled from it (t_enc + n_obj * t_1) are reported beside it."""
     from det_sam2_amd.config import resolve_config
     from det_sam2_amd.synth import synthetic_frame
     from det_sam2_amd.weights import synthetic_state_dict
@@ -103,22 +110,30 @@ def cpu_baseline(model_name, n_obj_sample=1, nk_frames=7):
     threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
     imgs, _, _ = load_frames([synthetic_frame(0)])
+
+    def bank(B):
+        mk = lambda: {"maskmem_features": torch.randn(B, 64, 64, 64, generator=g).to(torch.bfloat16),  # noqa: E731
+                      "maskmem_pos_enc": [M.sine_pos_2d(64, 64, 64)[None].expand(B, -1, -1, -1)], "obj_ptr": torch.randn(B, 256, generator=g)}
+        return {"cond_frame_outputs": {0: mk()}, "non_cond_frame_outputs": {t: mk() for t in range(1, 16)}}
+
     with torch.inference_mode():
         t0 = time.time()
         fpn, pos = M.forward_image(sd, cfg, imgs[0].float().unsqueeze(0))
         t_enc = time.time() - t0
         feats = [f.flatten(2).permute(2, 0, 1) for f in fpn]
         poss = [p.flatten(2).permute(2, 0, 1) for p in pos]
-        mk = lambda: {"maskmem_features": torch.randn(1, 64, 64, 64, generator=g).to(torch.bfloat16),  # noqa: E731
-                      "maskmem_pos_enc": [M.sine_pos_2d(64, 64, 64)[None]], "obj_ptr": torch.randn(1, 256, generator=g)}
-        od = {"cond_frame_outputs": {0: mk()}, "non_cond_frame_outputs": {t: mk() for t in range(1, 16)}}
         t0 = time.time()
-        op.track_step(16, False, feats, poss, None, None, od, 64, False, True)
-        t_obj = time.time() - t0
-    fps16 = 1.0 / (t_enc + 16.0 * t_obj)
-    return {"value": fps16, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (fp32 PyTorch-CPU restatement) on 1 tracked frame, 1 object, {model_name}, Nk=28736: "
-                      f"encoder {t_enc:.1f}s + per-object {t_obj:.1f}s; value = 1/(t_enc+16*t_obj)"}
+        op.track_step(16, False, feats, poss, None, None, bank(1), 64, False, True)
+        t_one = time.time() - t0
+        featsB = [f.expand(-1, n_obj, -1) for f in feats]
+        possB = [p.expand(-1, n_obj, -1) for p in poss]
+        t0 = time.time()
+        op.track_step(16, False, featsB, possB, None, None, bank(n_obj), 64, False, True)
+        t_all = time.time() - t0
+    return {"value": 1.0 / (t_enc + t_all), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (fp32 PyTorch-CPU restatement) on 1 tracked frame of {model_name} with {n_obj} objects in one batch, "
+                      f"Nk=28736: encoder {t_enc:.1f}s + tracking {t_all:.1f}s (measured); one object alone {t_one:.1f}s",
+            "modelled_from_one_object": 1.0 / (t_enc + n_obj * t_one)}
 
 
 def kernel_probe(pred, gen, st, last_tracked, table_path=None):
@@ -301,7 +316,7 @@ def bench_sharded(a, pred, cfg, world, rank, dev):
             comm[op] = nbytes
         total_tracked = float(tsum[1].item())
         out = {
-            "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
+            "metric": metric_name(cfg.name, B),
             "value": total_tracked / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[a.precision],
@@ -357,10 +372,21 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(backend)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            else:
+                dist.init_process_group(backend)
+            probe = torch.ones(1, device=f"cuda:{local}")      # first collective: RCCL communicator set-up over xGMI
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world
+        except Exception as e:     # the first real multi-GPU run must explain itself: one JSON line per failing rank
+            print(json.dumps({"error": "distributed init failed", "rank": rank, "local_rank": local, "world_size": world,
+                              "backend": backend, "exception": f"{type(e).__name__}: {e}",
+                              "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                              "MASTER_ADDR": os.environ.get("MASTER_ADDR"), "visible_gpus": torch.cuda.device_count()}), flush=True)
+            raise
     dev = f"cuda:{local}"
     if os.environ.get("DS2_BENCH_HIPRIO"):   # experiment: the tracking chain on a high-priority stream (DS2_ASYNC_ENCODE=1 puts the
         torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))   # encoder on a default-priority side stream)
@@ -471,7 +497,7 @@ def main():
                            + ("; a bf16x3 GEMM executes 3 MFMA FLOPs per algorithmic FLOP, so frac <= 1/3" if is_gemm else "")}
         pf = path_flops(cfg.name, B, nk)
         out = {
-            "metric": "frames/sec/GPU propagate_in_video, hiera_l, 16 obj, 1024^2; mask IoU vs ref",
+            "metric": metric_name(cfg.name, B),
             "value": world * K / dt, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[a.precision],
@@ -501,7 +527,7 @@ def main():
             out["stream_fps"] = stream["stream_fps"]
             out["stream"] = stream
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.model)
+            out["cpu_baseline"] = cpu_baseline(a.model, B)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -415,6 +415,9 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
       for (int k = 0; k < 4; ++k) {
         const int dv = t * 32 + 8 * k + 4 * half;
         if (dv < DV) {
+          // (no FMA contraction of `o * inv - hi`: the lo plane must be the remainder of the ROUNDED product, as a separate
+          // k_split_rows pass over the fp32 result would give it - every chain fusion then stays bit-identical to its unfused form)
+#pragma clang fp contract(off)
           const float v0 = o[t][4 * k] * inv, v1 = o[t][4 * k + 1] * inv, v2 = o[t][4 * k + 2] * inv, v3 = o[t][4 * k + 3] * inv;
           uint2 hh, ll;
           hh.x = cvt_pk_bf16(v0, v1);

@@ -650,6 +650,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     if (a.o_hi) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
+#pragma clang fp contract(off)   // (lo plane = remainder of the ROUNDED product, as a separate split pass would give it)
         const float v0 = o[g][t][0] * inv, v1 = o[g][t][1] * inv, v2 = o[g][t][2] * inv, v3 = o[g][t][3] * inv;
         uint2 h, l;
         h.x = cvt_pk_bf16(v0, v1);

@@ -1754,9 +1754,27 @@ extern "C" int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float*
   SkinnyArgs g{M, N, K, A, lda, wt, bias, gamma, R, ldr, r_mod, C, ldc, act};
   return launch_skinny_linear(g, st);
 }
+// The model-less primitive ops share one process-wide plane cache keyed by the weight's device address.  A caller of a
+// primitive owns its weight tensors and may free them between calls - a later allocation at the same address must not find the
+// old planes (tests/test_hip_ops.py::test_fused_mlp read NaNs that way once the allocator's reuse pattern shifted): the
+// primitive forgets the entries of its weights before every call (models keep theirs for life: their parameters never move).
+static int gemm_ctx_forget(GemmCtx& ctx, const float* W) {
+  std::lock_guard<std::mutex> lk(ctx.mu());
+  for (GemmCtx::PlaneMap* mp : {&ctx.wc(), &ctx.w2p()}) {
+    auto it = mp->find(W);
+    if (it == mp->end()) continue;
+    DS2_CHECK_HIP(hipDeviceSynchronize());
+    (void)hipFree(it->second.hi);
+    (void)hipFree(it->second.lo);
+    mp->erase(it);
+  }
+  return DS2_OK;
+}
 extern "C" int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
                           const float* gamma, const float* R, float* out, int32_t act, void* stream) {
   DS2_REQUIRE(rows > 0 && H > 0 && X && W1 && W2 && out, "ds2_op_mlp: bad argument");
+  TRY(gemm_ctx_forget(g_gemm_ctx, W1));
+  TRY(gemm_ctx_forget(g_gemm_ctx, W2));
   const int rc = mlp_fused(nullptr, g_gemm_ctx, (hipStream_t)stream, rows, H, X, 256, W1, b1, W2, b2, gamma, R, 256, out, 256, act);
   DS2_REQUIRE(rc != DS2_ERR_UNSUPPORTED, "ds2_op_mlp: needs a bf16x3 mode, width 256, H a multiple of 64 (<= 4096), act none / relu / gelu");
   return rc;
