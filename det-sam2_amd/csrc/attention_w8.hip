@@ -200,7 +200,53 @@ struct W8Args {
   // rows between the query blocks of consecutive batch items (Lq; 0 = every batch item reads the SAME queries: layer 0 of the
   // memory attention, where all objects still share the frame's tokens)
   int q_bstride;
+  // key split over gridDim.y workgroups (see the kernel): partial results [nsplit][batch * Lq][DV] / (max, sum) [..][2]
+  int nsplit; float* part_o; float* part_ml;
 };
+
+// combine the parts of a key-split attention: out = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m), m = max_s m_s (the maxima are
+// in the log2 domain of the kernel), then the kernel's own epilogue forms: fp32 (+ residual) or bf16 operand planes.
+// One thread per (row, 4 columns).
+template <int DV>
+__global__ __launch_bounds__(256) void k_w8_merge(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit,
+                                                  size_t rows, float* o, int ldo, const float* res, int ldres,
+                                                  unsigned short* o_hi, unsigned short* o_lo, int ldop) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * (DV / 4)) return;
+  const size_t row = i / (DV / 4);
+  const int c4 = (int)(i % (DV / 4)) * 4;
+  float m = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[((size_t)s * rows + row) * 2]);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float l = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float2 ml = *reinterpret_cast<const float2*>(part_ml + ((size_t)s * rows + row) * 2);
+    const float w = __builtin_amdgcn_exp2f(ml.x - m);
+    const float4 p = *reinterpret_cast<const float4*>(part_o + ((size_t)s * rows + row) * DV + c4);
+    acc.x += p.x * w; acc.y += p.y * w; acc.z += p.z * w; acc.w += p.w * w;
+    l += ml.y * w;
+  }
+  const float inv = 1.f / l;
+  {
+#pragma clang fp contract(off)
+    float v0 = acc.x * inv, v1 = acc.y * inv, v2 = acc.z * inv, v3 = acc.w * inv;
+    if (o_hi) {
+      uint2 h, lo;
+      h.x = cvt_pk_bf16(v0, v1);
+      h.y = cvt_pk_bf16(v2, v3);
+      lo.x = cvt_pk_bf16(v0 - bf_lo(h.x), v1 - bf_hi(h.x));
+      lo.y = cvt_pk_bf16(v2 - bf_lo(h.y), v3 - bf_hi(h.y));
+      *reinterpret_cast<uint2*>(o_hi + row * ldop + c4) = h;
+      *reinterpret_cast<uint2*>(o_lo + row * ldop + c4) = lo;
+    } else {
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + row * ldres + c4);
+        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+      }
+      *reinterpret_cast<float4*>(o + row * ldo + c4) = make_float4(v0, v1, v2, v3);
+    }
+  }
+}
 
 // QG = 16-query groups per wave.  QG = 2 re-uses every K / V^T fragment read from LDS for two MFMA B operands
 // (32 queries per wave, 256 per block): LDS traffic per MFMA halves - with QG = 1 the LDS pipe is about as busy as
@@ -299,15 +345,23 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     for (int t = 0; t < NT; ++t) o[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const int nkt = (a.Lk + BKEYS - 1) / BKEYS;
+  // key split (few objects: the grid of batch * Lq / BQ workgroups leaves CUs idle): workgroup (x, y) attends the tiles
+  // [kt0, kt0 + nkt) of its object's keys and writes its UNNORMALISED result + running maximum / sum; k_w8_merge combines the
+  // nsplit parts.  Everything below sees the range as a key sequence of its own (Lk keys from tile 0).
+  const int nkt_all = (a.Lk + BKEYS - 1) / BKEYS;
+  const int kt_per = a.nsplit > 1 ? (((nkt_all + a.nsplit - 1) / a.nsplit + 1) & ~1) : nkt_all;
+  const int kt0 = a.nsplit > 1 ? (int)blockIdx.y * kt_per : 0;
+  const int nkt = (nkt_all - kt0 < kt_per ? nkt_all - kt0 : kt_per);
+  const int Lk = (a.Lk - kt0 * BKEYS < nkt * BKEYS ? a.Lk - kt0 * BKEYS : nkt * BKEYS);
   // tiles below n_hi have a zero V lo plane (block-uniform; read once)
-  const int n_hi = (DV == 64 && a.n_hi_tiles > 0 && a.vlo_flag && __builtin_nontemporal_load(a.vlo_flag) == 0) ? a.n_hi_tiles : 0;
+  const int n_hi_all = (DV == 64 && a.n_hi_tiles > 0 && a.vlo_flag && __builtin_nontemporal_load(a.vlo_flag) == 0) ? a.n_hi_tiles : 0;
+  const int n_hi = n_hi_all - kt0 < 0 ? 0 : (n_hi_all - kt0 < nkt ? n_hi_all - kt0 : nkt);
   // staging: K planes = 2 x (32 rows x 32 uint4); thread handles uint4 #(tid + 512 i), i = 0..3; V^T planes =
   // 2 x (64 rows x 4 uint4), one uint4 per thread
   const int kpart = tid & 31, krow = (tid >> 5) & 15;         // rows krow and krow+16 of each plane
   // V^T tile = 2 planes x DV rows x 4 uint4 = 8*DV uint4; thread loads uint4 #(tid + 512 j), j < DV/64
-  const size_t kbase = (size_t)b * a.Lk;
-  const uint4* vbase = a.vt + (size_t)b * nkt * (8 * DV);
+  const size_t kbase = (size_t)b * a.Lk + (size_t)kt0 * BKEYS;
+  const uint4* vbase = a.vt + ((size_t)b * nkt_all + kt0) * (8 * DV);
   const char* kbytes = reinterpret_cast<const char*>(a.k_hi + kbase * 32);
   const int kso0 = krow * KROWB + (SWZ ? ((kpart ^ (krow & 15)) << 4) : kpart * 16), kso1 = kso0 + 16 * KROWB;
   // lane constants of the fragment reads: byte offset of this lane's chunk inside a V^T row / of k-step ks inside a K row
@@ -322,8 +376,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   {                                                                           \
     const int kt_ = (KT);                                                     \
     int k0_ = kt_ * BKEYS + krow, k1_ = k0_ + 16;                             \
-    k0_ = k0_ < a.Lk ? k0_ : a.Lk - 1;                                        \
-    k1_ = k1_ < a.Lk ? k1_ : a.Lk - 1;                                        \
+    k0_ = k0_ < Lk ? k0_ : Lk - 1;                                            \
+    k1_ = k1_ < Lk ? k1_ : Lk - 1;                                            \
     if constexpr (ILV) {                                                      \
       rk0 = *reinterpret_cast<const uint4*>(kbytes + (unsigned)(k0_ * 512 + kpart * 16)); \
       rk1 = *reinterpret_cast<const uint4*>(kbytes + (unsigned)(k1_ * 512 + kpart * 16)); \
@@ -406,8 +460,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
       for (int g = 0; g < QG; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s0[g][r] = kt_ * BKEYS + 4 * grp + r >= a.Lk ? -INFINITY : s0[g][r];
-          s1[g][r] = kt_ * BKEYS + 16 + 4 * grp + r >= a.Lk ? -INFINITY : s1[g][r];
+          s0[g][r] = kt_ * BKEYS + 4 * grp + r >= Lk ? -INFINITY : s0[g][r];
+          s1[g][r] = kt_ * BKEYS + 16 + 4 * grp + r >= Lk ? -INFINITY : s1[g][r];
         }
     }
   };
@@ -614,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   const std::false_type nolo{};
   // ILV: the tiles below n_hi (frame tokens: no V lo plane) run in a loop of their own without the lo-plane test
   const int n_fast = ILV && DV == 64 ? ((n_hi < nkt ? n_hi : nkt) & ~1) : 0;
-  if (a.Lk % BKEYS == 0) {
+  if (Lk % BKEYS == 0) {
     const std::false_type nm{};
     scores(nm, 0, 0, sa0, sa1);
     __syncthreads();   // every wave has read K(0) before iteration 0 overwrites it with K(2)
@@ -647,6 +701,14 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
     l_tot += __shfl_xor(l_tot, 32);
     const float inv = 1.f / l_tot;
     const size_t orow = (size_t)b * a.Lq + q0i + wave * 16 * QG + g * 16 + l15;
+    if (a.nsplit > 1) {   // part [split][row][DV] unnormalised + (maximum, sum) per row: k_w8_merge finishes
+      const size_t prow = (size_t)blockIdx.y * ((size_t)a.batch * a.Lq) + orow;
+      float* pp = a.part_o + prow * DV + 4 * grp;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) *reinterpret_cast<float4*>(pp + 16 * t) = make_float4(o[g][t][0], o[g][t][1], o[g][t][2], o[g][t][3]);
+      if (grp == 0) *reinterpret_cast<float2*>(a.part_ml + prow * 2) = make_float2(m_run[g], l_tot);
+      continue;
+    }
     if (a.o_hi) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -739,7 +801,7 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
                         int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid, const float* res, int ldres,
-                        bool q_shared) {
+                        bool q_shared, float* split_ws, size_t split_ws_bytes) {
   const bool klo = ds2_precision() != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
@@ -751,25 +813,58 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,
-           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0, res, ldres, q_shared ? 0 : Lq};
+           (vlo_flag && dv == 64) ? n_exact_keys / 32 : 0, vlo_flag, q_rope_cis, q_rope_grid, 0, res, ldres, q_shared ? 0 : Lq,
+           1, nullptr, nullptr};
   DS2_REQUIRE(!res || (o && !o_hi && ldres % 4 == 0), "attention_w8: a residual needs the fp32 output");
   for (int w = 1; w * w <= q_rope_grid; ++w)
     if (w * w == q_rope_grid) a.rope_w = w;   // square axial grid (compute_axial_cis with end_x = end_y)
   DS2_REQUIRE(!q_rope_cis || q_rope_grid > 0, "attention_w8: rope grid");
   DS2_REQUIRE(o || o_hi, "attention_w8: no output");
   DS2_REQUIRE(klo ? (k_lo != nullptr) : true, "attention_w8: the K lo plane is required in bf16x3 mode");
+  // Few workgroups (few objects; layer 0's shared self-attention: 32): split every object's keys over nsplit workgroups and
+  // merge (k_w8_merge).  The caller provides the scratch for the parts; without it, or when the grid already fills the chip,
+  // one workgroup walks all keys.
+  const int nblk = batch * (Lq / ((dv == 64 && !qg1) ? 256 : 128));
+  static const bool split_off = [] { const char* e = getenv("DS2_ATTN_KSPLIT"); return e && atoi(e) == 0; }();
+  int nsplit = 1;
+  if (split_ws && !split_off && (dv == 64 || dv == 256) && nblk <= 128) {
+    const int nkt = (Lk + BKEYS - 1) / BKEYS;
+    nsplit = 256 / nblk;
+    if (nsplit > 8) nsplit = 8;
+    while (nsplit > 1) {   // >= 16 tiles per part, every part non-empty, the scratch large enough
+      const int per = ((nkt + nsplit - 1) / nsplit + 1) & ~1;
+      const size_t need = (size_t)nsplit * batch * Lq * (dv + 2) * sizeof(float);
+      if (per >= 16 && (nsplit - 1) * per < nkt && need <= split_ws_bytes) break;
+      --nsplit;
+    }
+  }
+  if (nsplit > 1) {
+    a.nsplit = nsplit;
+    a.part_o = split_ws;
+    a.part_ml = split_ws + (size_t)nsplit * batch * Lq * dv;
+  }
+  const dim3 grid(nblk, nsplit);
   if (dv == 64 && !qg1) {
-    if (klo) hipLaunchKernelGGL((k_attention_w8<64, 2, true>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_attention_w8<64, 2, false>), dim3(batch * (Lq / 256)), dim3(512), 0, st, a);
+    if (klo) hipLaunchKernelGGL((k_attention_w8<64, 2, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attention_w8<64, 2, false>), grid, dim3(512), 0, st, a);
   } else if (dv == 64) {
-    if (klo) hipLaunchKernelGGL((k_attention_w8<64, 1, true>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_attention_w8<64, 1, false>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+    if (klo) hipLaunchKernelGGL((k_attention_w8<64, 1, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attention_w8<64, 1, false>), grid, dim3(512), 0, st, a);
   } else if (dv == 128) {
-    hipLaunchKernelGGL((k_attention_w8<128, 1, true>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+    hipLaunchKernelGGL((k_attention_w8<128, 1, true>), grid, dim3(512), 0, st, a);
   } else {   // self-attention in one pass: 16 dv blocks (64 accumulator registers), 150 KB of LDS (116 KB without K lo)
-    if (klo) hipLaunchKernelGGL((k_attention_w8<256, 1, true>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_attention_w8<256, 1, false>), dim3(batch * (Lq / 128)), dim3(512), 0, st, a);
+    if (klo) hipLaunchKernelGGL((k_attention_w8<256, 1, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_attention_w8<256, 1, false>), grid, dim3(512), 0, st, a);
   }
   DS2_CHECK_LAUNCH();
+  if (nsplit > 1) {
+    const size_t rows = (size_t)batch * Lq;
+    const dim3 mg((unsigned)((rows * (dv / 4) + 255) / 256));
+    if (dv == 64)
+      hipLaunchKernelGGL((k_w8_merge<64>), mg, dim3(256), 0, st, a.part_o, a.part_ml, nsplit, rows, o, ldo, res, ldres, a.o_hi, a.o_lo, ldop);
+    else
+      hipLaunchKernelGGL((k_w8_merge<256>), mg, dim3(256), 0, st, a.part_o, a.part_ml, nsplit, rows, o, ldo, res, ldres, a.o_hi, a.o_lo, ldop);
+    DS2_CHECK_LAUNCH();
+  }
   return DS2_OK;
 }

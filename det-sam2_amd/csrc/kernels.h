@@ -176,7 +176,8 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
                         int n_exact_keys = 0, const int* vlo_flag = nullptr,    // dv = 64: keys < n_exact_keys have a zero
                         const float* q_rope_cis = nullptr, int q_rope_grid = 0,   // rotate the queries while loading them
                         const float* res = nullptr, int ldres = 0,                // fp32 output: o = res + attention
-                        bool q_shared = false);                                   // every batch item reads q[0 .. Lq)
+                        bool q_shared = false,                                    // every batch item reads q[0 .. Lq)
+                        float* split_ws = nullptr, size_t split_ws_bytes = 0);    // scratch for the key split (few workgroups)
                                                                                 // V lo plane unless *vlo_flag != 0
 
 // producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)

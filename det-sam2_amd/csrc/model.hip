@@ -1035,7 +1035,9 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const size_t split_bytes = split ? ((size_t)B * Nk * 256 * 4 + (size_t)B * nt_c * 8192 + (size_t)rows * 256 * 4 +
                                       (size_t)4 * B * nt_s * 8192 + (1u << 20)) : 0;
   const size_t plane_bytes = split ? ((size_t)rows * (256 * 5 + 64 + F) + (size_t)B * Nk * 64) * 4 + (8u << 20) : 0;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + (4u << 20);
+  // scratch of the key-split attention (few workgroups: attention_w8.hip): nsplit * batch <= 8 query sets of [4096, 256 + 2]
+  const size_t ksplit_bytes = split ? (size_t)8 * TOK * (256 + 2) * sizeof(float) : 0;
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + (4u << 20);
   TRY(m->require(need, st));
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
@@ -1051,6 +1053,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   // bf16x3 mode: attention operands are split into bf16 planes once by their producers (attention_split.hip)
   void *khi = nullptr, *klo = nullptr, *vt_c = nullptr, *khi_s = nullptr, *klo_s = nullptr, *vt_s = nullptr;
   int* vlo_flag = nullptr;
+  float* ksplit_ws = nullptr;
   if (split) {
     vt_c = m->alloc_bytes((size_t)B * nt_c * 8192);
     khi_s = m->alloc_bytes((size_t)rows * 512); klo_s = m->alloc_bytes((size_t)rows * 512);
@@ -1058,6 +1061,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (!vt_c || !khi_s || !klo_s || !vt_s) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     // V = raw memory (64-d), shared by the 4 layers.  Frame tokens of the bank are bf16 storage (lo plane == 0): the
     // split kernel verifies that on the fly (vlo_flag) and the attention kernel then skips the lo term for those tiles.
+    ksplit_ws = reinterpret_cast<float*>(m->alloc_bytes(ksplit_bytes));
+    if (!ksplit_ws) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     vlo_flag = reinterpret_cast<int*>(m->alloc_bytes(256));
     if (!vlo_flag) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     static const bool no_vlo_skip = getenv("DS2_ATTN_NO_VLO_SKIP") != nullptr;
@@ -1107,10 +1112,10 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       // 8-byte plane stores cost the kernel 16 us per launch, what the separate LayerNorm pass costs less its launch: +-0)
       if (m->ma_fold_vo)   // values already carry out_proj: the kernel adds its result to the residual stream in place
         TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, xs, 256, Bs, TOK, TOK, sc, 256, st, nullptr,
-                                nullptr, 0, 0, nullptr, cis, TOK, xs, 256));
+                                nullptr, 0, 0, nullptr, cis, TOK, xs, 256, false, ksplit_ws, ksplit_bytes));
       else
         TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
-                                sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK));
+                                sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK, nullptr, 0, false, ksplit_ws, ksplit_bytes));
     } else {
       TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
       AttnArgs sa{};
@@ -1152,7 +1157,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       ds2_model::ActPlanes cp;
       TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
       TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
-                              Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once));
+                              Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once, ksplit_ws, ksplit_bytes));
     } else {
       TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
