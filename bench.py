@@ -62,7 +62,7 @@ def committed_pmc_traffic(kernel_key, B, nk, precision):
     source file).  None if no committed file matches this workload."""
     if B != 16 or nk != 28736 or precision != "bf16x3k":
         return None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

@@ -33,6 +33,7 @@ def _load_state_dict(cfg, ckpt_path):
 _CFG_KEYS = {
     "model.fill_hole_area": ("fill_hole_area", int),
     "model.binarize_mask_from_pts_for_mem_enc": ("binarize_mask_from_pts_for_mem_enc", "bool"),
+    "model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability": ("dynamic_multimask_via_stability", "bool"),
     "model.sam_mask_decoder_extra_args.dynamic_multimask_stability_delta": ("dynamic_multimask_stability_delta", float),
     "model.sam_mask_decoder_extra_args.dynamic_multimask_stability_thresh": ("dynamic_multimask_stability_thresh", float),
     "model.max_cond_frames_in_attn": ("max_cond_frames_in_attn", int),
@@ -44,7 +45,6 @@ _CFG_KEYS = {
 }
 _FIXED = {   # accepted only with the value the reference's video-predictor build uses
     "model._target_": "sam2.sam2_video_predictor.SAM2VideoPredictor",
-    "model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability": True,
     "model.image_size": 1024, "model.num_maskmem": 7,
 }
 
@@ -84,9 +84,14 @@ def apply_hydra_overrides(cfg, overrides):
 
 def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode="eval", hydra_overrides_extra=[],
                                apply_postprocessing=True, **kwargs):
-    cfg = apply_hydra_overrides(resolve_config(config_file), hydra_overrides_extra)
+    import dataclasses
+    cfg = resolve_config(config_file)
     if not apply_postprocessing:
-        raise NotImplementedError("apply_postprocessing=False (no dynamic multimask / binarised prompt masks) is not built")
+        # without the five overrides of build_sam.py:126-135 the model keeps its constructor defaults: single-mask output is
+        # token 0 (MaskDecoder.dynamic_multimask_via_stability = False, mask_decoder.py:37), prompted masks enter the memory
+        # encoder through the sigmoid (SAM2Base.binarize_mask_from_pts_for_mem_enc = False), no hole filling
+        cfg = dataclasses.replace(cfg, dynamic_multimask_via_stability=False, binarize_mask_from_pts_for_mem_enc=False, fill_hole_area=0)
+    cfg = apply_hydra_overrides(cfg, hydra_overrides_extra)
     if mode != "eval":
         raise NotImplementedError("inference only (mode='eval')")
     dev = "cuda:0" if device in ("cuda", None) else str(device)

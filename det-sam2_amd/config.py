@@ -79,6 +79,7 @@ class ModelCfg:
     multimask_min_pt_num: int = 0
     multimask_max_pt_num: int = 1
     # overrides appended by build_sam2_video_predictor (build_sam.py:126-135)
+    dynamic_multimask_via_stability: bool = True      # build_sam.py:128 (apply_postprocessing); MaskDecoder's own default is False
     dynamic_multimask_stability_delta: float = 0.05
     dynamic_multimask_stability_thresh: float = 0.98
     binarize_mask_from_pts_for_mem_enc: bool = True

@@ -147,7 +147,9 @@ class HipSam2(HipOps):
         c.sigmoid_scale_for_mem_enc, c.sigmoid_bias_for_mem_enc = (self.cfg.sigmoid_scale_for_mem_enc,
                                                                    self.cfg.sigmoid_bias_for_mem_enc)
         c.dynamic_multimask_stability_delta = self.cfg.dynamic_multimask_stability_delta
-        c.dynamic_multimask_stability_thresh = self.cfg.dynamic_multimask_stability_thresh
+        # (via_stability off: the single-mask output is always token 0 = "always stable")
+        c.dynamic_multimask_stability_thresh = (self.cfg.dynamic_multimask_stability_thresh
+                                                if self.cfg.dynamic_multimask_via_stability else float("-inf"))
         h = C.c_void_p()
         _capi.check(self.lib.ds2_model_create(C.byref(c), C.byref(h)), "ds2_model_create")
         self.h = h

@@ -218,7 +218,7 @@ class HipMaskDecoder(nn.Module):
         super().__init__()
         self.hip = hip
         self.conv_s0, self.conv_s1 = _ConvS(hip, "conv_s0"), _ConvS(hip, "conv_s1")
-        self.dynamic_multimask_via_stability = True        # build_sam.py:126-135
+        self.dynamic_multimask_via_stability = hip.cfg.dynamic_multimask_via_stability        # build_sam.py:126-135
         self.dynamic_multimask_stability_delta = hip.cfg.dynamic_multimask_stability_delta
         self.dynamic_multimask_stability_thresh = hip.cfg.dynamic_multimask_stability_thresh
         self.use_multimask_token_for_obj_ptr = True

@@ -149,21 +149,22 @@ def _instantiate(node):
     return _coerce(node)
 
 
-def instantiate_from_yaml(config_file: str, state_dict=None):
-    """Equivalent of ``build_sam2_video_predictor(config_file, device='cpu')``
+def instantiate_from_yaml(config_file: str, state_dict=None, apply_postprocessing: bool = True):
+    """Equivalent of ``build_sam2_video_predictor(config_file, device='cpu', apply_postprocessing=...)``
     (``sam2/build_sam.py:111-146``) without hydra."""
     install_shims()
     path = os.path.join(REFERENCE_ROOT, "sam2", config_file)
     with open(path) as f:
         cfg = yaml.safe_load(f)["model"]
     cfg["_target_"] = "sam2.sam2_video_predictor.SAM2VideoPredictor"
-    cfg["sam_mask_decoder_extra_args"] = {
-        "dynamic_multimask_via_stability": True,
-        "dynamic_multimask_stability_delta": 0.05,
-        "dynamic_multimask_stability_thresh": 0.98,
-    }
-    cfg["binarize_mask_from_pts_for_mem_enc"] = True
-    cfg["fill_hole_area"] = 8
+    if apply_postprocessing:      # the five overrides of build_sam.py:126-135
+        cfg["sam_mask_decoder_extra_args"] = {
+            "dynamic_multimask_via_stability": True,
+            "dynamic_multimask_stability_delta": 0.05,
+            "dynamic_multimask_stability_thresh": 0.98,
+        }
+        cfg["binarize_mask_from_pts_for_mem_enc"] = True
+        cfg["fill_hole_area"] = 8
     torch.manual_seed(0)
     model = _instantiate(cfg)
     if state_dict is not None:

@@ -558,6 +558,35 @@ def heldout_bplus(variant="s1"):
 
 
 
+def e2e_nopost(name="sam2.1_hiera_t"):
+    """build_sam2_video_predictor(..., apply_postprocessing=False) (build_sam.py:111-146 without the overrides of :126-135)
+    through the reference predictor: single-mask decoder output = token 0 (no dynamic multimask fallback; a box prompt is two
+    points > multimask_max_pt_num), prompted masks through the SIGMOID into the memory encoder, no hole filling.  Boxes for 2
+    objects on frame 0, forward propagation over 4 frames."""
+    from det_sam2_amd.synth import synthetic_box
+    cfg = resolve_config(name)
+    sd = synthetic_state_dict(cfg, 0)
+    ref = RS.instantiate_from_yaml(f"configs/sam2.1/{name}.yaml", sd, apply_postprocessing=False)
+    assert not ref.sam_mask_decoder.dynamic_multimask_via_stability and not ref.binarize_mask_from_pts_for_mem_enc
+    frames = [synthetic_frame(t) for t in range(4)]
+    t0 = time.time()
+    with torch.inference_mode():
+        st = ref.init_state(frames, offload_video_to_cpu=True, offload_state_to_cpu=False)
+        for o in range(2):
+            ref.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0))
+        yields = []
+        for t, ids, logits in ref.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=4, reverse=False):
+            od = st["output_dict"]
+            key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+            yields.append((t, od[key][t]["pred_masks"].clone().numpy(), (logits > 0).numpy()))
+    dt = time.time() - t0
+    out = {"seconds": np.float64(dt), "frames": np.array([y[0] for y in yields]), "low": np.stack([y[1] for y in yields]),
+           "bits": np.stack([np.packbits(y[2]) for y in yields])}
+    np.savez_compressed(os.path.join(GOLD, "e2e_nopost.npz"), **out)
+    print("e2e_nopost", dt, "s", out["frames"], out["low"].shape)
+
+
+
 if __name__ == "__main__":
     assert RS.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)

@@ -345,6 +345,9 @@ def mask_decoder(sd, cfg, image_embeddings, image_pe, sparse, dense, multimask_o
     if multimask_output:
         masks, iou = masks[:, 1:], iou[:, 1:]
         sam_tokens = mask_toks[:, 1:]
+    elif not getattr(cfg, "dynamic_multimask_via_stability", True):   # mask_decoder.py:147-148
+        masks, iou = masks[:, 0:1], iou[:, 0:1]
+        sam_tokens = mask_toks[:, 0:1]
     else:
         # _dynamic_multimask_via_stability (mask_decoder.py:261-296)
         mm, mi = masks[:, 1:], iou[:, 1:]

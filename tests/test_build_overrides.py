@@ -31,3 +31,9 @@ def test_unsupported_overrides_fail_loudly():
         apply_hydra_overrides(cfg, ["++model.image_size=512"])
     with pytest.raises(ValueError):
         apply_hydra_overrides(cfg, ["model.fill_hole_area"])
+
+
+def test_decoder_stability_override_maps_onto_cfg():
+    cfg = resolve_config("sam2.1_hiera_t")
+    got = apply_hydra_overrides(cfg, ["++model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability=false"])
+    assert cfg.dynamic_multimask_via_stability and not got.dynamic_multimask_via_stability

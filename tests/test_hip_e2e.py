@@ -331,3 +331,29 @@ def test_three_pass_stream_matches_oracle():
             worst = max(worst, 1.0 - _iou(vp.video_segments[t][o], ovp.video_segments[t][o]))
     record("e2e_three_pass", one_minus_iou=worst)
     assert worst <= 1e-3, worst
+
+
+def test_without_postprocessing_matches_reference(golden_dir):
+    """build_sam2_video_predictor(apply_postprocessing=False): token-0 single-mask output, sigmoid prompt masks into the memory
+    encoder, no hole filling - against the reference built the same way (golden e2e_nopost)."""
+    from det_sam2_amd.build_sam import build_sam2_video_predictor
+    from det_sam2_amd.synth import synthetic_box
+    g = np.load(os.path.join(golden_dir, "e2e_nopost.npz"))
+    pred = build_sam2_video_predictor(TINY, None, device="cuda:0", apply_postprocessing=False, max_batch=2)
+    assert not pred.cfg.dynamic_multimask_via_stability and pred.fill_hole_area == 0
+    st = pred.init_state([synthetic_frame(t) for t in range(4)])
+    for o in range(2):
+        pred.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0))
+    got = [(t, (lg > 0).cpu().numpy()) for t, _, lg in pred.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=4)]
+    assert [t for t, _ in got] == list(g["frames"])
+    od = st["output_dict"]
+    worst, dlogit = 0.0, 0.0
+    for i, (t, m) in enumerate(got):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][t]["pred_masks"].cpu().numpy()
+        dlogit = max(dlogit, float(np.abs(low.reshape(g["low"][i].shape) - g["low"][i]).max()))
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1024, 1024).astype(bool)
+        for o in range(2):
+            worst = max(worst, 1.0 - _iou(m[o].reshape(1024, 1024), ref[o]))
+    record("e2e_nopost", one_minus_iou=worst, max_abs_dlogit=dlogit)
+    assert worst <= 1e-3 and dlogit <= 5e-2, (worst, dlogit)

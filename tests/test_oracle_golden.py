@@ -500,3 +500,28 @@ def test_e2e_large_16_objects_full_bank_matches_reference_golden(variant, golden
         for t in range(L16_FRAMES):
             vp.process_frame(t, synthetic_frame(t, structured=st))
     _check_compact(g, lows)
+
+
+def test_e2e_without_postprocessing_matches_reference_golden(tiny, golden_dir):
+    """build_sam2_video_predictor(apply_postprocessing=False) (sam2/build_sam.py:111-146 without :126-135): single-mask output =
+    token 0, sigmoid (not binarised) prompt masks into the memory encoder, no hole filling - golden e2e_nopost."""
+    import dataclasses
+    from det_sam2_amd.synth import synthetic_box
+    cfg, sd = tiny
+    cfg = dataclasses.replace(cfg, dynamic_multimask_via_stability=False, binarize_mask_from_pts_for_mem_enc=False, fill_hole_area=0)
+    g = np.load(os.path.join(golden_dir, "e2e_nopost.npz"))
+    op = OraclePredictor(sd, cfg)
+    with torch.inference_mode():
+        st = op.init_state([synthetic_frame(t) for t in range(4)])
+        for o in range(2):
+            op.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0))
+        got = [(t, (lg > 0).numpy()) for t, _, lg in op.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=4)]
+    assert [t for t, _ in got] == list(g["frames"])
+    od = st["output_dict"]
+    for i, (t, m) in enumerate(got):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][t]["pred_masks"].numpy()
+        assert np.abs(low - g["low"][i]).max() <= 2e-4
+        ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
+        for o in range(2):
+            assert 1.0 - _iou(m[o], ref[o]) <= 1e-3
