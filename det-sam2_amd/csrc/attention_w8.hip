@@ -798,6 +798,15 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
   return DS2_OK;
 }
 
+// normalise unnormalised attention rows [rows][64] + (max, sum) into bf16 operand planes (attention_x4a.hip: one part)
+int launch_w8_merge64(const float* part_o, const float* part_ml, size_t rows, void* o_hi, void* o_lo, int ldop, hipStream_t st) {
+  const dim3 mg((unsigned)((rows * 16 + 255) / 256));
+  hipLaunchKernelGGL((k_w8_merge<64>), mg, dim3(256), 0, st, part_o, part_ml, 1, rows, nullptr, 0, nullptr, 0,
+                     reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
 int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k_lo, const void* vt, float* o, int ldo,
                         int batch, int Lq, int Lk, float scale, int dv, hipStream_t st, void* o_hi, void* o_lo, int ldop,
                         int n_exact_keys, const int* vlo_flag, const float* q_rope_cis, int q_rope_grid, const float* res, int ldres,

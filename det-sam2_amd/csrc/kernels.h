@@ -180,6 +180,16 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
                         float* split_ws = nullptr, size_t split_ws_bytes = 0);    // scratch for the key split (few workgroups)
                                                                                 // V lo plane unless *vlo_flag != 0
 
+// assembly 4-wave / 64-queries-per-wave cross-attention of mode bf16x3k (attention_x4a.hip): fp16 key plane [batch*Lk][256]
+// (GemmSplitArgs::c_hi_f16), V^T tiles from launch_vt_pack32, result as bf16 operand planes; ws: attention_x4a_ws_bytes()
+bool attention_x4a_enabled();
+bool attention_x4a_supported(int batch, int Lq, int Lk, int dv, bool planes_out);
+size_t attention_x4a_ws_bytes(int batch, int Lq);
+int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st);   // [batch][ceil(L/32)][64][32] fp16
+int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void* vt32, int batch, int Lq, int Lk, float scale,
+                         hipStream_t st, void* o_hi, void* o_lo, int ldop, const float* q_rope_cis, int q_rope_grid, bool q_shared,
+                         void* ws, size_t ws_bytes);
+
 // producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)
 int launch_layernorm_add(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, const float* add, float* y2,
                          int rows, int C, float eps, hipStream_t st);   // y = LN(x), y2 = y + add

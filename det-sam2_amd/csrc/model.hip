@@ -1037,7 +1037,11 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const size_t plane_bytes = split ? ((size_t)rows * (256 * 5 + 64 + F) + (size_t)B * Nk * 64) * 4 + (8u << 20) : 0;
   // scratch of the key-split attention (few workgroups: attention_w8.hip): nsplit * batch <= 8 query sets of [4096, 256 + 2]
   const size_t ksplit_bytes = split ? (size_t)8 * TOK * (256 + 2) * sizeof(float) : 0;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + (4u << 20);
+  // the assembly cross-attention (attention_x4a.hip): its own V^T tile order, Q fragments and unnormalised partial rows
+  const bool x4a = split && k_f16 && attention_x4a_enabled() && attention_x4a_supported(B, TOK, Nk, 64, true);
+  const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK) : 0;
+  const size_t x4a_bytes = x4a ? x4a_ws_bytes + (size_t)B * nt_c * 4096 + 4096 : 0;
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (4u << 20);
   TRY(m->require(need, st));
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
@@ -1054,6 +1058,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   void *khi = nullptr, *klo = nullptr, *vt_c = nullptr, *khi_s = nullptr, *klo_s = nullptr, *vt_s = nullptr;
   int* vlo_flag = nullptr;
   float* ksplit_ws = nullptr;
+  void *vt32 = nullptr, *x4a_ws = nullptr;
   if (split) {
     vt_c = m->alloc_bytes((size_t)B * nt_c * 8192);
     khi_s = m->alloc_bytes((size_t)rows * 512); klo_s = m->alloc_bytes((size_t)rows * 512);
@@ -1067,7 +1072,14 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (!vlo_flag) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     static const bool no_vlo_skip = getenv("DS2_ATTN_NO_VLO_SKIP") != nullptr;
     if (no_vlo_skip) vlo_flag = nullptr;
-    TRY(launch_vt_split16(memory, 64, B, Nk, vt_c, 64, st, Nk - n_ptr_tok, vlo_flag, k_f16));   // (bf16x3k: fp16 planes)
+    if (x4a) {
+      vt32 = m->alloc_bytes((size_t)B * nt_c * 4096);
+      x4a_ws = m->alloc_bytes(x4a_ws_bytes);
+      if (!vt32 || !x4a_ws) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
+      TRY(launch_vt_pack32(memory, 64, B, Nk, vt32, st));
+    } else {
+      TRY(launch_vt_split16(memory, 64, B, Nk, vt_c, 64, st, Nk - n_ptr_tok, vlo_flag, k_f16));   // (bf16x3k: fp16 planes)
+    }
   }
   // output = curr + 0.1 * curr_pos (memory_attention.py:139-141); identical for every object in the tracking loop
   // (curr is the frame's feature, curr_pos the model constant); the general form takes per-object tokens / positions
@@ -1153,11 +1165,18 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
                Nk - n_ptr_tok, TOK, !klo_planes, k_f16));   // (bf16x3k: ONE key plane, fp16)
       const ds2_model::ActPlanes kpl = m->act_planes[K];
       khi = kpl.hi; klo = klo_planes ? kpl.lo : nullptr;
+      if (x4a && Nk % 32) {   // the last key tile of the last object reads past the plane: into the (unused) lo plane - finite values
+        DS2_REQUIRE(reinterpret_cast<char*>(kpl.lo) == reinterpret_cast<char*>(kpl.hi) + (size_t)B * Nk * 512, "memory_attention: key planes not adjacent");
+        DS2_CHECK_HIP(hipMemsetAsync(kpl.lo, 0, 32 * 512, st));
+      }
       ProfScope _p("kernel.cross_attention", st);
       ds2_model::ActPlanes cp;
       TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
-      TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
-                              Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once, ksplit_ws, ksplit_bytes));
+      if (x4a)
+        TRY(launch_attention_x4a(q, 256, khi, vt32, B, TOK, Nk, sc, st, cp.hi, cp.lo, cp.ld, cis, TOK, q_once, x4a_ws, x4a_ws_bytes));
+      else
+        TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
+                                Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once, ksplit_ws, ksplit_bytes));
     } else {
       TRY(linear(m, st, p + ".cross_attn_image.k_proj", B * Nk, 256, 64, kin, 64, K, 256));
       TRY(launch_rope(K, 256, cis, B, Nk, Nk - n_ptr_tok, TOK, st));
