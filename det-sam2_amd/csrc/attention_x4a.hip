@@ -16,7 +16,11 @@
 
 #include "common.h"
 #include "kernels.h"
+#ifdef X4A_BODY_INC      // (tools/experiments/x4a_bench.hip: schedule experiments)
+#include X4A_BODY_INC
+#else
 #include "attention_x4a_body.inc"
+#endif
 
 namespace {
 

@@ -21,14 +21,46 @@ import sys
 
 KT_BYTES, VT_BYTES, V_OFF = 16384, 4096, 65536
 SA, SB, PF, KF, VF, KRO, VRO, KDO, VDO = 64, 96, 128, 144, 156, 172, 188, 192, 196
-MRUN, LRUN, ALPHA, MNEW, T0 = 197, 199, 201, 203, 205      # pairs (qb0, qb1); T0..: temporaries 205..222
+MRUN, LRUN, ALPHA, MNEW, T0 = 197, 199, 201, 203, 205      # (qb0, qb1); T0..: temporaries 205..222
+# (v_pk_add_f32 / v_pk_mul_f32 / v_dot2_f32_f16 were measured at 16 / 16 / 10 issue cycles beside MFMAs, v_exp_f32 at 8, plain
+#  VALU at 4 - tools/experiments/mfma_issue_cost.hip - so the softmax uses scalar-per-lane instructions only)
+import os
+ISSUE, GAP = int(os.environ.get('X4A_ISSUE', 4)), int(os.environ.get('X4A_GAP', 26))      # schedule model: issue cycles per filler instruction, filler cycles in the shadow of one MFMA (32 cycles)
 TMP = 207
 L31, HALF = 223, 224
 MASK, H4, NEGINF = 232, 248, 249    # additive score mask of the LAST key tile (0 / -inf per accumulator register), 4 * half, -inf
 out = []
+FLAGS = set(sys.argv[2:])      # timing experiments only (results are wrong): nosoft noexp nokread novread nodma nos nopv nobarrier
 
 
 def e(s):
+    op = s.split()[0]
+    if "noexp" in FLAGS and op == "v_exp_f32":
+        s = s.replace("v_exp_f32", "v_mov_b32")
+    if (step.n > 0 or op == "L_loop:") and "strip" in FLAGS and not getattr(e, "epi", False):
+        keep = op.startswith("v_mfma") or op.endswith(":") or "s44" in s or op in ("s_branch",) or "L_done" in s
+        if "keepwait" in FLAGS and op == "s_waitcnt":
+            keep = True
+        if "keepsalu" in FLAGS and op.startswith("s_") and "m0" not in s and not op.startswith("s_cbranch") and op not in ("s_barrier", "s_nop", "s_waitcnt"):
+            keep = True
+        if "keepnop" in FLAGS and op == "s_nop":
+            keep = True
+        if "keepbr" in FLAGS and (op.startswith("s_cbranch") or op.startswith("s_cmp") or op.startswith("v_cmp") or op == "s_or_b64"):
+            keep = True
+        if not keep:
+            return
+    if step.n > 0 and not getattr(e, "epi", False):
+        if "loosevm" in FLAGS and s == "s_waitcnt vmcnt(5)":
+            s = "s_waitcnt vmcnt(10)"
+        if "nowaitk" in FLAGS and s.startswith("s_waitcnt lgkmcnt"):
+            return
+    if step.n > 0 or op == "L_loop:":      # (inside the loop only)
+        if ("nokread" in FLAGS and op == "ds_read_b128" and f"v[{KF}" <= s.split()[1] < f"v[{VF}") or \
+           ("novread" in FLAGS and op == "ds_read_b128" and s.split()[1] >= f"v[{VF}") or \
+           ("nobarrier" in FLAGS and op == "s_barrier") or ("nodma" in FLAGS and op == "global_load_lds_dwordx4") or \
+           ("nos" in FLAGS and op.startswith("v_mfma") and s.split()[1].startswith("v[")) or \
+           ("nopv" in FLAGS and op.startswith("v_mfma") and s.split()[1].startswith("a[")):
+            return
     out.append(s)
 
 
@@ -137,9 +169,8 @@ def prologue():
             e("s_addc_u32 s51, s51, 0")
     # first tiles: K(0) V(0) K(1) V(1) K(2)
     for kt, slot, with_v in ((0, 0, True), (1, 1, True), (2, 2, False)):
-        dma_k(kt_imm=kt, slot=slot)
-        if with_v:
-            dma_v(kt_imm=kt, slot=slot)
+        for ins in dma_k(kt_imm=kt, slot=slot) + (dma_v(kt_imm=kt, slot=slot) if with_v else []):
+            e(ins)
     e("s_waitcnt vmcnt(0)")
     e("s_barrier")
     # scores of tile 0 -> set A
@@ -157,102 +188,136 @@ def prologue():
 
 
 def dma_k(slot, kt_imm=None, t_plus=None):
-    """copy K tile min(t + t_plus, nkt - 1) (or the constant tile kt_imm, clamped) into ring slot `slot`"""
+    """copy K tile min(t + t_plus, nkt - 1) (or the constant tile kt_imm, clamped) into ring slot `slot` -> instruction list"""
+    L = []
     if kt_imm is not None:
-        e(f"s_min_u32 s45, {kt_imm}, s46")
+        L.append(f"s_min_u32 s45, {kt_imm}, s46")
     else:
-        e(f"s_add_u32 s45, s44, {t_plus}")
-        e("s_min_u32 s45, s45, s46")
-    e("s_lshl_b32 s45, s45, 14")
-    e("s_add_u32 s40, %[klo], s45")
-    e("s_addc_u32 s41, %[khi], 0")
+        L.append(f"s_add_u32 s45, s44, {t_plus}")
+        L.append("s_min_u32 s45, s45, s46")
+    L.append("s_lshl_b32 s45, s45, 14")
+    L.append("s_add_u32 s40, %[klo], s45")
+    L.append("s_addc_u32 s41, %[khi], 0")
     for j in range(4):
-        e(f"s_add_u32 m0, s48, {slot * KT_BYTES + j * 1024}")
-        e("s_nop 0")
-        e(f"global_load_lds_dwordx4 {vr(KDO + j)}, s[40:41]")
+        L.append(f"s_add_u32 m0, s48, {slot * KT_BYTES + j * 1024}")
+        L.append("s_nop 0")
+        L.append(f"global_load_lds_dwordx4 {vr(KDO + j)}, s[40:41]")
+    return L
 
 
 def dma_v(slot, kt_imm=None, t_plus=None):
+    L = []
     if kt_imm is not None:
-        e(f"s_min_u32 s45, {kt_imm}, s46")
+        L.append(f"s_min_u32 s45, {kt_imm}, s46")
     else:
-        e(f"s_add_u32 s45, s44, {t_plus}")
-        e("s_min_u32 s45, s45, s46")
-    e("s_lshl_b32 s45, s45, 12")
-    e("s_add_u32 s42, %[vlo], s45")
-    e("s_addc_u32 s43, %[vhi], 0")
-    e(f"s_add_u32 m0, s49, {slot * VT_BYTES}")
-    e("s_nop 0")
-    e(f"global_load_lds_dwordx4 {vr(VDO)}, s[42:43]")
+        L.append(f"s_add_u32 s45, s44, {t_plus}")
+        L.append("s_min_u32 s45, s45, s46")
+    L.append("s_lshl_b32 s45, s45, 12")
+    L.append("s_add_u32 s42, %[vlo], s45")
+    L.append("s_addc_u32 s43, %[vhi], 0")
+    L.append(f"s_add_u32 m0, s49, {slot * VT_BYTES}")
+    L.append("s_nop 0")
+    L.append(f"global_load_lds_dwordx4 {vr(VDO)}, s[42:43]")
+    return L
 
 
-def softmax_fillers(cur):
-    """-> list (one entry per k-step slot) of instruction lists: the softmax of the scores in set `cur`, in place"""
+def cost(ins):
+    """issue cycles a filler takes from the one wave of its SIMD (model: one instruction per ISSUE cycles, transcendentals 16)"""
+    op = ins.split()[0]
+    if op.startswith("v_exp"):
+        return 8
+    if op == "s_nop":
+        return int(ins.split()[1]) + 1
+    return ISSUE
+
+
+def softmax_stream(cur, n):
+    """the online softmax of the scores in set `cur` (in place) as an ordered filler list of (instruction | block, tag)"""
     S = lambda qb, i: vr(cur + qb * 16 + i)   # noqa: E731
-    slots = [[] for _ in range(16)]
-    # slots 0 / 1: maximum of the 16 scores of q block 0 / 1 -> T0 + qb
+    F = []
+    add = lambda ins, tag=None: F.append((ins, tag))   # noqa: E731
+    # maxima of the 16 scores of each query block -> T0 + qb
     for qb in range(2):
-        L = slots[qb]
-        L.append(f"v_max3_f32 {vr(T0 + qb)}, {S(qb, 0)}, {S(qb, 1)}, {S(qb, 2)}")
+        add(f"v_max3_f32 {vr(T0 + qb)}, {S(qb, 0)}, {S(qb, 1)}, {S(qb, 2)}")
         for i in range(3, 15, 2):
-            L.append(f"v_max3_f32 {vr(T0 + qb)}, {vr(T0 + qb)}, {S(qb, i)}, {S(qb, i + 1)}")
-        L.append(f"v_max_f32 {vr(T0 + qb)}, {vr(T0 + qb)}, {S(qb, 15)}")
-    # slot 2: across the lane halves, new maximum, rescale factor
-    L = slots[2]
+            add(f"v_max3_f32 {vr(T0 + qb)}, {vr(T0 + qb)}, {S(qb, i)}, {S(qb, i + 1)}")
+        add(f"v_max_f32 {vr(T0 + qb)}, {vr(T0 + qb)}, {S(qb, 15)}")
+    # across the lane halves, new maximum (pair MP: both words), rescale factor
     for qb in range(2):
-        L.append(f"v_mov_b32 {vr(TMP + qb)}, {vr(T0 + qb)}")
-    L.append("s_nop 1")
+        add(f"v_mov_b32 {vr(TMP + qb)}, {vr(T0 + qb)}")
+    add("s_nop 1")
     for qb in range(2):
-        L.append(f"v_permlane32_swap_b32 {vr(T0 + qb)}, {vr(TMP + qb)}")
-    L.append("s_nop 1")
+        add(f"v_permlane32_swap_b32 {vr(T0 + qb)}, {vr(TMP + qb)}")
+    add("s_nop 1")
     for qb in range(2):
-        L.append(f"v_max3_f32 {vr(MNEW + qb)}, {vr(T0 + qb)}, {vr(TMP + qb)}, {vr(MRUN + qb)}")
+        add(f"v_max3_f32 {vr(MNEW + qb)}, {vr(T0 + qb)}, {vr(TMP + qb)}, {vr(MRUN + qb)}")
     for qb in range(2):
-        L.append(f"v_sub_f32 {vr(TMP + 2 + qb)}, {vr(MRUN + qb)}, {vr(MNEW + qb)}")
+        add(f"v_sub_f32 {vr(TMP + 2 + qb)}, {vr(MRUN + qb)}, {vr(MNEW + qb)}")
     for qb in range(2):
-        L.append(f"v_exp_f32 {vr(ALPHA + qb)}, {vr(TMP + 2 + qb)}")
+        add(f"v_exp_f32 {vr(ALPHA + qb)}, {vr(TMP + 2 + qb)}")
     for qb in range(2):
-        L.append(f"v_mov_b32 {vr(MRUN + qb)}, {vr(MNEW + qb)}")
-    # slots 3..15: p = exp2(s - m) in place; order (qb0, 0..7), (qb1, 0..7), (qb0, 8..15), (qb1, 8..15); conversions behind
-    order = [(qb, i) for half in range(2) for qb in range(2) for i in range(half * 8, half * 8 + 8)]
-    per = [3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2]    # 32 elements over slots 3..15
-    assert sum(per) == 32
-    k = 0
-    done_at = {}
-    for si, n in enumerate(per):
-        L = slots[3 + si]
-        grp = order[k:k + n]
-        for qb, i in grp:
-            L.append(f"v_sub_f32 {S(qb, i)}, {S(qb, i)}, {vr(MNEW + qb)}")
-        for qb, i in grp:
-            L.append(f"v_exp_f32 {S(qb, i)}, {S(qb, i)}")
-            done_at[(qb, i)] = 3 + si
-        k += n
-    # fp16 packing: pf[qb][st] word w = elements (8 st + 2 w, 8 st + 2 w + 1); placed one slot after both are exponentiated
-    tail = []
-    for st in range(2):
+        add(f"v_mov_b32 {vr(MRUN + qb)}, {vr(MNEW + qb)}")
+    # exact running-maximum rescale of O (rare after the first tiles): one block
+    lab = f"L_norescale_{n}"
+    blk = [f"v_cmp_neq_f32 vcc, 1.0, {vr(ALPHA)}", f"v_cmp_neq_f32 s[52:53], 1.0, {vr(ALPHA + 1)}", "s_or_b64 vcc, vcc, s[52:53]",
+           "s_nop 1", f"s_cbranch_vccz {lab}"]
+    for dvb in range(2):
         for qb in range(2):
-            for w in range(4):
-                a, b = 8 * st + 2 * w, 8 * st + 2 * w + 1
-                ins = f"v_cvt_pk_f16_f32 {vr(PF + (qb * 2 + st) * 4 + w)}, {S(qb, a)}, {S(qb, b)}"
-                at = max(done_at[(qb, a)], done_at[(qb, b)]) + 1
-                if at <= 15:
-                    slots[at].append(ins)
-                else:
-                    tail.append(ins)
-    return slots, tail
+            base = 128 + (dvb * 2 + qb) * 16
+            for r in range(0, 16, 4):
+                for i in range(4):
+                    blk.append(f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, a{base + r + i}")
+                for i in range(4):
+                    blk.append(f"v_mul_f32 {vr(TMP + 4 + i)}, {vr(TMP + 4 + i)}, {vr(ALPHA + qb)}")
+                for i in range(4):
+                    blk.append(f"v_accvgpr_write_b32 a{base + r + i}, {vr(TMP + 4 + i)}")
+    blk += ["s_nop 7", f"{lab}:"]
+    F.append((blk, None))
+    # p = exp2(s - m) in place, pair by pair; one pair behind: the fp16 packing
+    pairs = [(qb, 4 * st + w) for st in range(2) for qb in range(2) for w in range(4)]
+    prev = None
+
+    def finish(pr):
+        qb, j = pr
+        st, w = j // 4, j % 4
+        add(f"v_cvt_pk_f16_f32 {vr(PF + (qb * 2 + st) * 4 + w)}, {S(qb, 2 * j)}, {S(qb, 2 * j + 1)}", ("pf", qb, st) if w == 3 else None)
+
+    for qb, j in pairs:
+        add(f"v_sub_f32 {S(qb, 2 * j)}, {S(qb, 2 * j)}, {vr(MNEW + qb)}")
+        add(f"v_sub_f32 {S(qb, 2 * j + 1)}, {S(qb, 2 * j + 1)}, {vr(MNEW + qb)}")
+        add(f"v_exp_f32 {S(qb, 2 * j)}, {S(qb, 2 * j)}")
+        add(f"v_exp_f32 {S(qb, 2 * j + 1)}, {S(qb, 2 * j + 1)}")
+        if prev is not None:
+            finish(prev)
+        prev = (qb, j)
+    add("s_nop 0")
+    finish(prev)
+    # row sums: l = l * alpha + sum(p)
+    for qb in range(2):
+        t = TMP + 8 + qb * 4
+        P = lambda i, qb=qb: S(qb, i)   # noqa: E731
+        for ins in [f"v_add_f32 {vr(t)}, {P(0)}, {P(1)}", f"v_add_f32 {vr(t + 1)}, {P(2)}, {P(3)}",
+                    f"v_add_f32 {vr(t + 2)}, {P(4)}, {P(5)}", f"v_add_f32 {vr(t + 3)}, {P(6)}, {P(7)}",
+                    f"v_add_f32 {vr(t)}, {vr(t)}, {P(8)}", f"v_add_f32 {vr(t + 1)}, {vr(t + 1)}, {P(9)}",
+                    f"v_add_f32 {vr(t + 2)}, {vr(t + 2)}, {P(10)}", f"v_add_f32 {vr(t + 3)}, {vr(t + 3)}, {P(11)}",
+                    f"v_add_f32 {vr(t)}, {vr(t)}, {P(12)}", f"v_add_f32 {vr(t + 1)}, {vr(t + 1)}, {P(13)}",
+                    f"v_add_f32 {vr(t + 2)}, {vr(t + 2)}, {P(14)}", f"v_add_f32 {vr(t + 3)}, {vr(t + 3)}, {P(15)}",
+                    f"v_add_f32 {vr(t)}, {vr(t)}, {vr(t + 1)}", f"v_add_f32 {vr(t + 2)}, {vr(t + 2)}, {vr(t + 3)}",
+                    f"v_add_f32 {vr(t)}, {vr(t)}, {vr(t + 2)}",
+                    f"v_fma_f32 {vr(LRUN + qb)}, {vr(LRUN + qb)}, {vr(ALPHA + qb)}, {vr(t)}"]:
+            add(ins)
+    if "nosoft" in FLAGS:
+        F = [("s_nop 0", tag) for _, tag in F if tag]
+    return F
 
 
 def step(sl, cur, nxt):
     kslot, vslot = (sl + 1) & 3, sl & 3
-    dma_k(slot=(sl + 3) & 3, t_plus=3)
-    dma_v(slot=(sl + 2) & 3, t_plus=2)
-    e(f"ds_read_b128 {kf(0)}, {vr(KRO + 0)} offset:{kslot * KT_BYTES}")
-    e(f"ds_read_b128 {kf(1)}, {vr(KRO + 1)} offset:{kslot * KT_BYTES}")
-    fill, tail = softmax_fillers(cur)
+    n = step.n
+    step.n += 1
     # the scores started in this step are those of tile t + 1: when it is the last one, keys >= nval (of its 32) get -inf through
     # the first MFMA's C operand.  Register r of a lane in half h holds key (r & 3) + 8 (r >> 2) + 4 h.
-    lab = f"L_nomask_{step.n}"
+    lab = f"L_nomask_{n}"
     e("s_add_u32 s45, s44, 2")
     e("s_cmp_eq_u32 s45, %[nkt]")
     e(f"s_cbranch_scc0 {lab}")
@@ -262,73 +327,62 @@ def step(sl, cur, nxt):
         e(f"v_cndmask_b32 {vr(MASK + r)}, 0, {vr(NEGINF)}, vcc")
     e("s_nop 4")
     e(f"{lab}:")
-    VF_SLOT = 12
+    # LDS reads first issued: the four V^T fragments of tile t, K fragments 0 and 1 of tile t + 1
+    for st in range(2):
+        for dvb in range(2):
+            e(f"ds_read_b128 {vf(st, dvb)}, {vr(VRO + st * 2 + dvb)} offset:{vslot * VT_BYTES}")
+    e(f"ds_read_b128 {kf(0)}, {vr(KRO + 0)} offset:{kslot * KT_BYTES}")
+    e(f"ds_read_b128 {kf(1)}, {vr(KRO + 1)} offset:{kslot * KT_BYTES}")
+    # fillers, in order: copies of the tiles three / two steps ahead, then the softmax of the current scores
+    F = [(i, None) for i in dma_k(slot=(sl + 3) & 3, t_plus=3) + dma_v(slot=(sl + 2) & 3, t_plus=2)] + softmax_stream(cur, n)
+    pos = [0]
+    done = set()
+    debt = [0.0]
+
+    def emit_one():
+        ins, tag = F[pos[0]]
+        pos[0] += 1
+        c = 0
+        for line in (ins if isinstance(ins, list) else [ins]):
+            e(line)
+            c += cost(line) if isinstance(ins, str) else 0
+        if isinstance(ins, list):
+            c = 5 * ISSUE            # the block's usual path: the branch over it
+        if tag:
+            done.add(tag)
+        return c
+
+    def fill(budget):
+        """fillers worth `budget` issue cycles in the shadow of the MFMA just issued (over / undershoot carried)"""
+        debt[0] += budget
+        while pos[0] < len(F) and debt[0] > 0:
+            debt[0] -= emit_one()
+
+    def flush_until(tag):
+        any_ = False
+        while tag not in done:
+            debt[0] -= emit_one()
+            any_ = True
+        if any_:
+            e("s_nop 1")           # VALU write of a P fragment -> MFMA read
+
     for ks in range(16):
         if ks + 2 < 16:
             e(f"ds_read_b128 {kf(ks + 2)}, {vr(KRO + ks + 2)} offset:{kslot * KT_BYTES}")
-        # outstanding LDS reads behind kf(ks): the later K fragments and, from slot 13 on, the four V^T fragments
-        if ks <= VF_SLOT:
-            n = min(2, 15 - ks)
-        elif ks == 13:
-            n = 6
-        elif ks == 14:
-            n = 5
-        else:
-            n = 0
-        e(f"s_waitcnt lgkmcnt({n})")
+        e(f"s_waitcnt lgkmcnt({min(2, 15 - ks)})")
         for qb in range(2):
             c = vr(MASK, 16) if ks == 0 else vr(nxt + qb * 16, 16)
             e(f"v_mfma_f32_32x32x16_f16 {vr(nxt + qb * 16, 16)}, {kf(ks)}, {qf(qb, ks)}, {c}")
-        for ins in fill[ks]:
-            e(ins)
-        if ks == VF_SLOT:
-            for st in range(2):
-                for dvb in range(2):
-                    e(f"ds_read_b128 {vf(st, dvb)}, {vr(VRO + st * 2 + dvb)} offset:{vslot * VT_BYTES}")
-    for ins in tail:
-        e(ins)
-    # exact running-maximum rescale of O (rare after the first tiles)
-    lab = f"L_norescale_{step.n}"
-    step.n += 1
-    e(f"v_cmp_neq_f32 vcc, 1.0, {vr(ALPHA)}")
-    e(f"v_cmp_neq_f32 s[52:53], 1.0, {vr(ALPHA + 1)}")
-    e("s_or_b64 vcc, vcc, s[52:53]")
-    e("s_nop 1")
-    e(f"s_cbranch_vccz {lab}")
-    for dvb in range(2):
-        for qb in range(2):
-            base = 128 + (dvb * 2 + qb) * 16
-            for r in range(0, 16, 4):
-                for i in range(4):
-                    e(f"v_accvgpr_read_b32 {vr(TMP + 4 + i)}, a{base + r + i}")
-                for i in range(4):
-                    e(f"v_mul_f32 {vr(TMP + 4 + i)}, {vr(TMP + 4 + i)}, {vr(ALPHA + qb)}")
-                for i in range(4):
-                    e(f"v_accvgpr_write_b32 a{base + r + i}, {vr(TMP + 4 + i)}")
-    e("s_nop 7")
-    e(f"{lab}:")
-    # P.V with the row sums in the MFMAs' shadow: l = l * alpha + sum(p)
-    adds = []
-    for qb in range(2):
-        S = lambda i, qb=qb: vr(cur + qb * 16 + i)   # noqa: E731
-        t = TMP + 8 + qb * 4
-        adds += [f"v_add_f32 {vr(t)}, {S(0)}, {S(1)}", f"v_add_f32 {vr(t + 1)}, {S(2)}, {S(3)}",
-                 f"v_add_f32 {vr(t + 2)}, {S(4)}, {S(5)}", f"v_add_f32 {vr(t + 3)}, {S(6)}, {S(7)}"]
-        adds += [f"v_add_f32 {vr(t)}, {vr(t)}, {S(8)}", f"v_add_f32 {vr(t + 1)}, {vr(t + 1)}, {S(9)}",
-                 f"v_add_f32 {vr(t + 2)}, {vr(t + 2)}, {S(10)}", f"v_add_f32 {vr(t + 3)}, {vr(t + 3)}, {S(11)}"]
-        adds += [f"v_add_f32 {vr(t)}, {vr(t)}, {S(12)}", f"v_add_f32 {vr(t + 1)}, {vr(t + 1)}, {S(13)}",
-                 f"v_add_f32 {vr(t + 2)}, {vr(t + 2)}, {S(14)}", f"v_add_f32 {vr(t + 3)}, {vr(t + 3)}, {S(15)}"]
-        adds += [f"v_add_f32 {vr(t)}, {vr(t)}, {vr(t + 1)}", f"v_add_f32 {vr(t + 2)}, {vr(t + 2)}, {vr(t + 3)}",
-                 f"v_add_f32 {vr(t)}, {vr(t)}, {vr(t + 2)}", f"v_fma_f32 {vr(LRUN + qb)}, {vr(LRUN + qb)}, {vr(ALPHA + qb)}, {vr(t)}"]
-    i = 0
+            fill(GAP - (2 * ISSUE if qb == 1 and ks + 1 < 16 else 0))     # (the next slot's read + wait are issued in this gap)
+    # P.V
     for st in range(2):
         for dvb in range(2):
             for qb in range(2):
+                flush_until(("pf", qb, st))
                 e(f"v_mfma_f32_32x32x16_f16 {oacc(dvb, qb)}, {vf(st, dvb)}, {pf(qb, st)}, {oacc(dvb, qb)}")
-                for ins in adds[i:i + 4]:
-                    e(ins)
-                i += 4
-    assert i >= len(adds)
+                fill(GAP)
+    while pos[0] < len(F):
+        emit_one()
     e("s_waitcnt vmcnt(5)")
     e("s_barrier")
     e("s_add_u32 s44, s44, 1")
@@ -340,6 +394,7 @@ step.n = 0
 
 
 def epilogue():
+    e.epi = True
     e("L_done:")
     e("s_waitcnt vmcnt(0)")
     e("s_nop 15")

@@ -13,6 +13,10 @@ Schemes (cost in bf16-MFMA equivalents per product; MX-fp8 and int8 MFMAs run at
     gemm2a    bf16x3 without the activation's lo plane (calibration: measured 6.1e-3 on cfg1 on the GPU)   2.0
     mx_bf16   bf16 hi.hi + MX-fp8 (e4m3, 32-element block scales) cross terms a_lo8.w_hi8 + a_hi8.w_lo8    2.0
     mx_f16    fp16 hi.hi + the same MX-fp8 cross terms                     2.0
+    f16x3     fp16 planes, three terms                                     3.0
+    f16x2a    fp16 hi.hi + a_lo.w_hi (weights rounded to fp16)             2.0
+    f16x2w    fp16 hi.hi + a_hi.w_lo (activations rounded to fp16)         2.0
+    f16x1     one fp16 plane each                                          1.0
     i8x3      per-row 16-bit fixed point as two int8 planes, hi.hi + both cross terms      1.5
     i8x4      the same with all four terms (exact 16-bit fixed-point product)             2.0
 """
@@ -67,10 +71,33 @@ def _fix16(x):
     return q, hi, lo, s
 
 
+REGION = [None]         # which stage of the oracle is running (DS2_EMU_ONLY=enc|ma|dec|menc: the scheme there, bf16x3 elsewhere)
+ONLY = os.environ.get("DS2_EMU_ONLY")
+
+
+def _scoped(mod, name, tag):
+    f = getattr(mod, name)
+
+    def g(*a, **k):
+        prev, REGION[0] = REGION[0], tag
+        try:
+            return f(*a, **k)
+        finally:
+            REGION[0] = prev
+    setattr(mod, name, g)
+
+
 def emu_linear(x, w, b=None):
+    global SCHEME
     rows = x.numel() // x.shape[-1]
     if SCHEME == "exact" or rows <= 128:          # k_skinny_linear: exact fp32 in every mode
         return _orig_linear(x, w, b)
+    if ONLY and REGION[0] != ONLY and SCHEME != "bf16x3":
+        keep, SCHEME = SCHEME, "bf16x3"
+        try:
+            return emu_linear(x, w, b)
+        finally:
+            SCHEME = keep
     mm = lambda a, ww: _orig_linear(a, ww)        # noqa: E731  fp32 accumulation
     if SCHEME == "bf16x3":
         xh, wh = _bf16(x), _bf16(w)
@@ -87,6 +114,14 @@ def emu_linear(x, w, b=None):
     elif SCHEME in ("mx_f16_a", "mx_f16_w"):      # fp16 hi.hi + ONE MX-fp8 cross term (1.5 equivalents)
         xh, wh = _f16(x), _f16(w)
         y = (mm(_mx8(x - xh), _mx8(w)) if SCHEME == "mx_f16_a" else mm(_mx8(x), _mx8(w - wh))) + mm(xh, wh)
+    elif SCHEME in ("f16x3", "f16x2a", "f16x2w", "f16x1"):   # fp16 planes: 11-bit mantissas (range: |x| < 65504, subnormal below 6e-5)
+        xh, wh = _f16(x), _f16(w)
+        xl, wl = _f16(x - xh), _f16(w - wh)
+        y = mm(xh, wh)
+        if SCHEME in ("f16x3", "f16x2a"):
+            y = y + mm(xl, wh)
+        if SCHEME in ("f16x3", "f16x2w"):
+            y = y + mm(xh, wl)
     elif SCHEME in ("i8x3", "i8x4"):
         qx, xh, xl, sx = _fix16(x)
         qw, wh, wl, sw = _fix16(w)
@@ -178,6 +213,9 @@ def run_large():
 if __name__ == "__main__":
     SCHEME = sys.argv[1]
     F.linear = emu_linear
+    import oracle.modeling as _M
+    for _n, _t in (("forward_image", "enc"), ("memory_attention", "ma"), ("mask_decoder", "dec"), ("memory_encoder", "menc")):
+        _scoped(_M, _n, _t)
     torch.set_num_threads(int(os.environ.get("DS2_EMU_THREADS", "2")))
     for case in (sys.argv[2:] or ["cfg1"]):
         worst, dl = globals()["run_" + case]()
