@@ -22,7 +22,14 @@
 //   lane: X 128 + out 128 + hidden accumulators 32 + their bf16 fragments 32 = 320 of 512, the rest buys fragment prefetch.
 //   Epilogue: a lane holds 4 consecutive output columns of its token: + b2, * gamma, + R, one 16-byte store - no LDS round trip.
 // Product terms and their order as in the GEMM kernels: a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulation.
+// X2 (MlpArgs::f16x2, round 4): TWO terms on IEEE fp16 planes - x_h w_l + x_h w_h with x and the hidden activations rounded to one
+// fp16 plane (11 bits) and the weights kept as two (22 bits).  The matrix pipe of a fully loaded chip is power-limited
+// (profiles/r04_mfma_power_calibration.txt), so a third of the MFMAs is a third of the time; tools/prec_emulate.py f16x2w shows
+// no loss against the reference goldens when it is confined to the memory attention / memory encoder (DS2_EMU_ONLY=ma|menc),
+// and a visible one in the image encoder - which keeps three terms.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -36,6 +43,14 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {   // v_cvt_pk_f16_f32, round to nearest even
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2{a, b}), h2));
+}
 constexpr int MD = 256;            // model width (k of phase A, n of phase B)
 constexpr int MBR = 128;           // token rows per workgroup
 constexpr int MHC = 64;            // hidden units per chunk
@@ -77,8 +92,9 @@ __device__ __forceinline__ void wait_vm_lgkm() {   // s_waitcnt needs an immedia
   else static_assert(N == 8 || N == 12 || N == 16, "unexpected DMA count");
 }
 
-template <int ACT>
+template <int ACT, bool X2>
 __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
+  using FragT = typename std::conditional<X2, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   float* b1s = reinterpret_cast<float*>(lds + MNS * MSLOT);   // [H]
 
@@ -143,9 +159,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   _Pragma("unroll") for (int i_ = 0; i_ < (NP) / 2 - 2; ++i_) {                               \
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                         \
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                         \
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, X2 ? 2 : 4, 0);                                \
   }                                                                                           \
-  __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, X2 ? 8 : 12, 0);
   // end of the step at pair position PP: the next tile must have landed (the two after it may stay in flight), this
   // wave's fragment reads are retired, then everybody meets
 #define MLP_STEP_END(PP)                                                         \
@@ -160,15 +176,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     const int tok = rb * MBR + wave * 32 + l31;
     const int tokc = tok < a.rows ? tok : a.rows - 1;   // clamp: rows beyond the end are computed but never stored
     // ---- X fragments of this wave's 32 tokens: B operand (token = lane & 31, k = 16 s + 8 half .. + 7), both planes
-    bf16x8 xh[MD / 16], xl[MD / 16];
+    FragT xh[MD / 16], xl[X2 ? 1 : MD / 16];
     {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4* ph = reinterpret_cast<const u32x4*>(a.X_hi + (size_t)tokc * a.ldx + half * 8);
       const u32x4* pl = reinterpret_cast<const u32x4*>(a.X_lo + (size_t)tokc * a.ldx + half * 8);
 #pragma unroll
       for (int s = 0; s < MD / 16; ++s) {
-        xh[s] = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(ph + s * 2));   // streamed once: keep the weights in L2
-        xl[s] = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(pl + s * 2));
+        const u32x4 h = __builtin_nontemporal_load(ph + s * 2);   // streamed once: keep the weights in L2
+        const u32x4 l = __builtin_nontemporal_load(pl + s * 2);
+        if constexpr (X2) {   // x = hi + lo of its bf16 planes, rounded to ONE fp16 plane
+          u32x4 r;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) r[w] = cvt_pk_f16(bf_lo(h[w]) + bf_lo(l[w]), bf_hi(h[w]) + bf_hi(l[w]));
+          xh[s] = __builtin_bit_cast(FragT, r);
+        } else {
+          xh[s] = __builtin_bit_cast(FragT, h);
+          xl[s] = __builtin_bit_cast(FragT, l);
+        }
       }
     }
     f32x16 out[MD / 32];
@@ -192,18 +217,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   {                                                                                                                       \
     MLP_PREFETCH(PP)                                                                                                      \
     const unsigned char* base_ = lds + ((PP) % MNS) * MSLOT;                                                              \
-    bf16x8 wh_[4][MHC / 32], wl_[4][MHC / 32];                                                                            \
+    FragT wh_[4][MHC / 32], wl_[4][MHC / 32];                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
       _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
         const unsigned char* r_ = base_ + (ks >> 1) * 4096 + (hb * 32 + l31) * 64 + ((((ks & 1) * 2 + half) ^ sw) << 4);  \
-        wh_[ks][hb] = *reinterpret_cast<const bf16x8*>(r_);                                                               \
-        wl_[ks][hb] = *reinterpret_cast<const bf16x8*>(r_ + MLO);                                                         \
+        wh_[ks][hb] = *reinterpret_cast<const FragT*>(r_);                                                                \
+        wl_[ks][hb] = *reinterpret_cast<const FragT*>(r_ + MLO);                                                          \
       }                                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
       _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
-        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[ks][hb], xh[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb], 0, 0, 0); \
-        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xl[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb], 0, 0, 0); \
-        hid[hb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[ks][hb], xh[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb], 0, 0, 0); \
+        hid[hb] = mfma16(wl_[ks][hb], xh[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb]);                                       \
+        if constexpr (!X2) hid[hb] = mfma16(wh_[ks][hb], xl[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb]);                    \
+        hid[hb] = mfma16(wh_[ks][hb], xh[((PP) % MT_PER_CHUNK) * 4 + ks], hid[hb]);                                       \
       }                                                                                                                   \
     MLP_INTERLEAVE(8)                                                                                                     \
     MLP_STEP_END(PP)                                                                                                      \
@@ -215,16 +240,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     const unsigned char* base_ = lds + ((PP) % MNS) * MSLOT;                                                              \
     constexpr int Q_ = (PP) % MT_PER_CHUNK - MTA;                                                                         \
     _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                       \
-      bf16x8 wh_[MD / 32], wl_[MD / 32];                                                                                  \
+      FragT wh_[MD / 32], wl_[MD / 32];                                                                                   \
       _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
         const unsigned char* r_ = base_ + (nb * 32 + l31) * 64 + (((t * 2 + half) ^ sw) << 4);                            \
-        wh_[nb] = *reinterpret_cast<const bf16x8*>(r_);                                                                   \
-        wl_[nb] = *reinterpret_cast<const bf16x8*>(r_ + MLO);                                                             \
+        wh_[nb] = *reinterpret_cast<const FragT*>(r_);                                                                    \
+        wl_[nb] = *reinterpret_cast<const FragT*>(r_ + MLO);                                                              \
       }                                                                                                                   \
       _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
-        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl_[nb], fh[Q_][t], out[nb], 0, 0, 0);                          \
-        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fl[Q_][t], out[nb], 0, 0, 0);                          \
-        out[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh_[nb], fh[Q_][t], out[nb], 0, 0, 0);                          \
+        out[nb] = mfma16(wl_[nb], fh[Q_][t], out[nb]);                                                                    \
+        if constexpr (!X2) out[nb] = mfma16(wh_[nb], fl[Q_][t], out[nb]);                                                 \
+        out[nb] = mfma16(wh_[nb], fh[Q_][t], out[nb]);                                                                    \
       }                                                                                                                   \
     }                                                                                                                     \
     MLP_INTERLEAVE(16)                                                                                                    \
@@ -249,14 +274,20 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
             v[gg * 4 + e] = DS2_MLP_ABL == 1 ? hid[hb][(2 * t + gg) * 4 + e]                                              \
                                              : ds2_act(hid[hb][(2 * t + gg) * 4 + e] + bb[hb][2 * t + gg][e], ACT);       \
         uint4 h, l;                                                                                                       \
-        h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);                                                     \
-        h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);                                                     \
-        l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));                                                          \
-        l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));                                                          \
-        l.z = cvt_pk_bf16(v[4] - bf_lo(h.z), v[5] - bf_hi(h.z));                                                          \
-        l.w = cvt_pk_bf16(v[6] - bf_lo(h.w), v[7] - bf_hi(h.w));                                                          \
-        fh[hb][t] = __builtin_bit_cast(bf16x8, h);                                                                        \
-        fl[hb][t] = __builtin_bit_cast(bf16x8, l);                                                                        \
+        if constexpr (X2) {                                                                                               \
+          h.x = cvt_pk_f16(v[0], v[1]); h.y = cvt_pk_f16(v[2], v[3]);                                                     \
+          h.z = cvt_pk_f16(v[4], v[5]); h.w = cvt_pk_f16(v[6], v[7]);                                                     \
+          fh[hb][t] = __builtin_bit_cast(FragT, h);                                                                       \
+        } else {                                                                                                          \
+          h.x = cvt_pk_bf16(v[0], v[1]); h.y = cvt_pk_bf16(v[2], v[3]);                                                   \
+          h.z = cvt_pk_bf16(v[4], v[5]); h.w = cvt_pk_bf16(v[6], v[7]);                                                   \
+          l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));                                                        \
+          l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));                                                        \
+          l.z = cvt_pk_bf16(v[4] - bf_lo(h.z), v[5] - bf_hi(h.z));                                                        \
+          l.w = cvt_pk_bf16(v[6] - bf_lo(h.w), v[7] - bf_hi(h.w));                                                        \
+          fh[hb][t] = __builtin_bit_cast(FragT, h);                                                                       \
+          fl[hb][t] = __builtin_bit_cast(FragT, l);                                                                       \
+        }                                                                                                                 \
       }                                                                                                                   \
   }
 #define MLP_ZERO_HID()                                                   \
@@ -264,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     _Pragma("unroll") for (int e = 0; e < 16; ++e) hid[i][e] = 0.f;
       static_assert(MTA == 4 && MTB == 2, "the chunk pair is unrolled by hand");
       f32x16 hid[MHC / 32];
-      bf16x8 fh[MHC / 32][2], fl[MHC / 32][2];
+      FragT fh[MHC / 32][2], fl[X2 ? 1 : MHC / 32][2];
       MLP_ZERO_HID()
       MLP_A(0) MLP_A(1) MLP_A(2) MLP_A(3)
       MLP_ACT(c2)
@@ -353,16 +384,17 @@ int launch_mlp256(const MlpArgs& a, hipStream_t st) {
   const int grid = nrb < ncu ? nrb : ncu;
   const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4;
   void (*kern)(MlpArgs) = nullptr;
+  const bool x2 = a.f16x2 != 0;
   switch (a.act) {
-    case DS2_ACT_NONE: kern = k_mlp256<DS2_ACT_NONE>; break;
-    case DS2_ACT_RELU: kern = k_mlp256<DS2_ACT_RELU>; break;
-    case DS2_ACT_GELU: kern = k_mlp256<DS2_ACT_GELU>; break;
+    case DS2_ACT_NONE: kern = x2 ? k_mlp256<DS2_ACT_NONE, true> : k_mlp256<DS2_ACT_NONE, false>; break;
+    case DS2_ACT_RELU: kern = x2 ? k_mlp256<DS2_ACT_RELU, true> : k_mlp256<DS2_ACT_RELU, false>; break;
+    case DS2_ACT_GELU: kern = x2 ? k_mlp256<DS2_ACT_GELU, true> : k_mlp256<DS2_ACT_GELU, false>; break;
     default: DS2_REQUIRE(false, "mlp256: unsupported activation %d", a.act);
   }
-  static bool attr_done[4] = {false, false, false, false};
-  if (!attr_done[a.act]) {
+  static bool attr_done[2][4] = {};
+  if (!attr_done[x2][a.act]) {
     DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[a.act] = true;
+    attr_done[x2][a.act] = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
   DS2_CHECK_LAUNCH();

@@ -50,6 +50,25 @@ __global__ void k_split_rows(const float* x, int ldx, int rows, int cols, uint2*
   lo[i] = l;
 }
 
+// the same with IEEE fp16 planes (hi = fp16(x), lo = fp16(x - hi): 22 bits together; |x| < 65504).  Weights of the two-term
+// fp16 products (gemm_mlp256.hip, mode bf16x3k)
+__global__ void k_split_rows_f16(const float* x, int ldx, int rows, int cols, uint2* hi, uint2* lo, int ldp) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = ldp / 4;
+  if (i >= (size_t)rows * q) return;
+  const int c4 = (int)(i % q);
+  const size_t r = i / q;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < cols) v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
+  const h2 h0 = __builtin_convertvector((f2{v.x, v.y}), h2), h1 = __builtin_convertvector((f2{v.z, v.w}), h2);
+  const h2 l0 = __builtin_convertvector((f2{v.x - (float)h0[0], v.y - (float)h0[1]}), h2);
+  const h2 l1 = __builtin_convertvector((f2{v.z - (float)h1[0], v.w - (float)h1[1]}), h2);
+  hi[i] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+  lo[i] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
+
 template <int DBG>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, int nt) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][2][PLANE];   // [buf][A/B][hi/lo]
@@ -306,10 +325,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
 
 }  // namespace
 
-int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st) {
+int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st, bool f16) {
   DS2_REQUIRE(ldp % 32 == 0 && ldx % 4 == 0 && cols % 4 == 0, "split_rows: ldp must be a multiple of 32, ldx/cols of 4");
   const size_t n = (size_t)rows * (ldp / 4);
-  hipLaunchKernelGGL(k_split_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, rows, cols,
+  hipLaunchKernelGGL(f16 ? k_split_rows_f16 : k_split_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, rows, cols,
                      reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), ldp);
   DS2_CHECK_LAUNCH();
   return DS2_OK;

@@ -130,7 +130,8 @@ int launch_gemm_split_pp256(const GemmSplitArgs& g, hipStream_t st);        // p
 bool gemm_split_pp256_supported(const GemmSplitArgs& g);
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
-int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st);
+int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st,
+                      bool f16 = false);   // f16: IEEE fp16 planes instead of bf16
 // gemm_skinny.hip: fp32 linear layer for M <= 128 rows over the transposed weight Wt[K,N]
 struct SkinnyArgs {
   int M, N, K;
@@ -160,6 +161,9 @@ struct MlpArgs {
   float* out; int ldo;                             // fp32 [rows, ldo]
   int act;                                         // DS2_ACT_NONE | RELU | GELU
   unsigned short *out_hi, *out_lo; int ldop;       // optional: the result ALSO as bf16 operand planes [rows, ldop] (next GEMM's A)
+  // two-term fp16 products (mode bf16x3k, memory attention / memory encoder): W1 / W2 planes are FP16 (launch_split_rows
+  // f16), X (read from its bf16 planes) and the hidden activations are rounded to ONE fp16 plane: x_h w_h + x_h w_l
+  int f16x2;
 };
 bool mlp256_supported(const MlpArgs& a);
 int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st);

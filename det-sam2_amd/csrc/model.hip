@@ -110,7 +110,7 @@ constexpr int TOK = 4096;  // 64x64 tokens at stride 16
 struct GemmPlanes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
 struct GemmCtx {
   typedef std::unordered_map<const float*, GemmPlanes> PlaneMap;
-  PlaneMap own_wcache, own_w2perm;
+  PlaneMap own_wcache, own_w2perm, own_wcache16, own_w2perm16;   // (..16: IEEE fp16 planes of the two-term products)
   std::unordered_map<const float*, float*> own_wt;   // skinny linear layers: fp32 weights transposed to [K, N] (once)
   std::unordered_map<const float*, float*>& wt() { return share ? share->own_wt : own_wt; }
   GemmCtx* share = nullptr;   // a VIEW model (ds2_model_create_view) uses its parent's weight planes; the scratch is its own
@@ -120,6 +120,8 @@ struct GemmCtx {
   std::mutex& mu() { return share ? share->own_mu : own_mu; }
   PlaneMap& wc() { return share ? share->own_wcache : own_wcache; }        // weights split into planes (once)
   PlaneMap& w2p() { return share ? share->own_w2perm : own_w2perm; }      // fused MLP: W2 with the hidden index permuted
+  PlaneMap& wc16() { return share ? share->own_wcache16 : own_wcache16; }
+  PlaneMap& w2p16() { return share ? share->own_w2perm16 : own_w2perm16; }
   // a weight's planes may be consumed on another stream than the one that split it (view models): the creating call waits
   // for its split kernels once (first use only)
   int publish(hipStream_t st) { DS2_CHECK_HIP(hipStreamSynchronize(st)); return DS2_OK; }
@@ -140,6 +142,10 @@ struct GemmCtx {
     own_wcache.clear();
     for (auto& kv : own_w2perm) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     own_w2perm.clear();
+    for (PlaneMap* mp : {&own_wcache16, &own_w2perm16}) {
+      for (auto& kv : *mp) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
+      mp->clear();
+    }
     for (auto& kv : own_wt) (void)hipFree(kv.second);
     own_wt.clear();
     if (scratch) (void)hipFree(scratch);
@@ -412,20 +418,26 @@ static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int
               planes_out);
 }
 // weight planes of a static weight [N, K] (split once, cached)
-static int weight_planes(GemmCtx& ctx, const float* W, int N, int K, GemmPlanes* out, hipStream_t st) {
+static int weight_planes(GemmCtx& ctx, const float* W, int N, int K, GemmPlanes* out, hipStream_t st, bool f16 = false) {
   std::lock_guard<std::mutex> lk(ctx.mu());
-  auto it = ctx.wc().find(W);
-  if (it != ctx.wc().end()) { *out = it->second; return DS2_OK; }
+  GemmCtx::PlaneMap& map = f16 ? ctx.wc16() : ctx.wc();
+  auto it = map.find(W);
+  if (it != map.end()) { *out = it->second; return DS2_OK; }
   const int Kp = round32i(K);
   GemmPlanes wp;
   DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.hi), (size_t)N * Kp * 2));
   DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), (size_t)N * Kp * 2));
   wp.ld = Kp;
-  TRY(launch_split_rows(W, K, N, K, wp.hi, wp.lo, Kp, st));
+  TRY(launch_split_rows(W, K, N, K, wp.hi, wp.lo, Kp, st, f16));
   TRY(ctx.publish(st));
-  ctx.wc()[W] = wp;
+  map[W] = wp;
   *out = wp;
   return DS2_OK;
+}
+// two-term fp16 products in the memory attention / memory encoder of mode bf16x3k (gemm_mlp256.hip X2; DS2_F16X2=0: three bf16 terms)
+static bool f16x2_enabled() {
+  const char* e = getenv("DS2_F16X2");   // (read per call: the tests compare both in one process)
+  return !(e && atoi(e) == 0) && ds2_precision() == DS2_PREC_BF16X3K;
 }
 // DS2_MLP_FUSED=0 keeps the two-GEMM form (A/B runs)
 static bool mlp_fused_enabled() {
@@ -437,19 +449,21 @@ static bool mlp_fused_enabled() {
 // A's operand planes must be registered (its producer emitted them) or are split here.
 static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H, const float* A, int lda, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* gamma, const float* R, int ldr, float* out,
-                     int ldo, int act, bool planes_too = false) {
+                     int ldo, int act, bool planes_too = false, bool f16x2 = false) {
   if (!ds2_split_mode() || !mlp_fused_enabled() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
   MlpArgs a{};
+  a.f16x2 = f16x2 ? 1 : 0;
   a.rows = rows; a.D = 256; a.H = H; a.ldx = 256; a.ldw1 = 256; a.ldw2 = H;
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.R = R; a.ldr = ldr; a.out = out; a.ldo = ldo; a.act = act;
   if (!mlp256_supported(a) || !(act == DS2_ACT_NONE || act == DS2_ACT_RELU || act == DS2_ACT_GELU)) return DS2_ERR_UNSUPPORTED;
   char ptag[96] = "";
   if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_mlp256 %d %d %d", rows, 256, 2 * H);   // (2*M*N*K with K = 2H: both layers)
   GemmPlanes w1p, w2p;
-  TRY(weight_planes(ctx, W1, H, 256, &w1p, st));
+  TRY(weight_planes(ctx, W1, H, 256, &w1p, st, f16x2));
   std::unique_lock<std::mutex> lk2(ctx.mu());
-  auto it = ctx.w2p().find(W2);
-  if (it != ctx.w2p().end()) {
+  GemmCtx::PlaneMap& map2 = f16x2 ? ctx.w2p16() : ctx.w2p();
+  auto it = map2.find(W2);
+  if (it != map2.end()) {
     w2p = it->second;
   } else {   // once per weight: permute the hidden index inside groups of 16, then split
     float* tmp = nullptr;
@@ -458,10 +472,10 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.hi), (size_t)256 * H * 2));
     DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.lo), (size_t)256 * H * 2));
     w2p.ld = H;
-    TRY(launch_split_rows(tmp, H, 256, H, w2p.hi, w2p.lo, H, st));
+    TRY(launch_split_rows(tmp, H, 256, H, w2p.hi, w2p.lo, H, st, f16x2));
     DS2_CHECK_HIP(hipStreamSynchronize(st));
     DS2_CHECK_HIP(hipFree(tmp));
-    ctx.w2p()[W2] = w2p;
+    map2[W2] = w2p;
   }
   lk2.unlock();
   const unsigned short *xh = nullptr, *xl = nullptr;
@@ -490,10 +504,10 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
 // two-layer MLP by state_dict prefixes: fused when the shape allows it, else the two GEMMs (hidden planes in `hbuf`)
 // planes_too: `out` feeds a GEMM next - the fused kernel writes its operand planes alongside the fp32 result
 static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::string& p2, int rows, int H, const float* A,
-                float* hbuf, float* out, int act, const float* R, const float* gamma, bool planes_too = false) {
+                float* hbuf, float* out, int act, const float* R, const float* gamma, bool planes_too = false, bool f16x2 = false) {
   m->act_planes.erase(out);   // (`out` is rewritten: planes registered for its previous contents are stale)
   const int rc = mlp_fused(m, m->gctx, st, rows, H, A, 256, m->P(p1 + ".weight"), m->P(p1 + ".bias"), m->P(p2 + ".weight"),
-                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too);
+                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too, f16x2);
   if (rc != DS2_ERR_UNSUPPORTED) return rc;
   TRY(linear(m, st, p1, rows, H, 256, A, 256, hbuf, H, act, nullptr, 0, 0, nullptr, true));
   return linear(m, st, p2, rows, 256, H, hbuf, H, out, 256, DS2_ACT_NONE, R, 256, 0, gamma);
@@ -1199,7 +1213,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     }
     // -- FFN
     TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
-    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr));
+    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr, false, f16x2_enabled()));
     m->release(layer_mark);
   }
   TRY(layernorm(m, st, "memory_attention.norm", x, out, rows, 256, 1e-5f));
@@ -1716,7 +1730,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
     TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
     TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
     TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma"),
-             DS2_ME_X_PLANES && l == 1));   // the last block's result feeds out_proj
+             DS2_ME_X_PLANES && l == 1, f16x2_enabled()));   // the last block's result feeds out_proj
   }
   if (out_f32) {      // MemoryEncoder.forward's own output (no no_obj_embed_spatial, no bf16 storage rounding)
     TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, out_f32, 64));
@@ -1784,7 +1798,7 @@ extern "C" int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float*
 // primitive forgets the entries of its weights before every call (models keep theirs for life: their parameters never move).
 static int gemm_ctx_forget(GemmCtx& ctx, const float* W) {
   std::lock_guard<std::mutex> lk(ctx.mu());
-  for (GemmCtx::PlaneMap* mp : {&ctx.wc(), &ctx.w2p()}) {
+  for (GemmCtx::PlaneMap* mp : {&ctx.wc(), &ctx.w2p(), &ctx.wc16(), &ctx.w2p16()}) {
     auto it = mp->find(W);
     if (it == mp->end()) continue;
     DS2_CHECK_HIP(hipDeviceSynchronize());
@@ -1799,7 +1813,10 @@ extern "C" int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* 
   DS2_REQUIRE(rows > 0 && H > 0 && X && W1 && W2 && out, "ds2_op_mlp: bad argument");
   TRY(gemm_ctx_forget(g_gemm_ctx, W1));
   TRY(gemm_ctx_forget(g_gemm_ctx, W2));
-  const int rc = mlp_fused(nullptr, g_gemm_ctx, (hipStream_t)stream, rows, H, X, 256, W1, b1, W2, b2, gamma, R, 256, out, 256, act);
+  // (DS2_OP_MLP_F16X2=1: the two-term fp16 form the memory attention / memory encoder use in mode bf16x3k - tests/test_hip_ops.py)
+  const char* e2 = getenv("DS2_OP_MLP_F16X2");
+  const int rc = mlp_fused(nullptr, g_gemm_ctx, (hipStream_t)stream, rows, H, X, 256, W1, b1, W2, b2, gamma, R, 256, out, 256, act, false,
+                           e2 && atoi(e2) != 0);
   DS2_REQUIRE(rc != DS2_ERR_UNSUPPORTED, "ds2_op_mlp: needs a bf16x3 mode, width 256, H a multiple of 64 (<= 4096), act none / relu / gelu");
   return rc;
 }
