@@ -798,10 +798,10 @@ int launch_vt_split16(const float* v, int ldv, int batch, int L, void* vt, int d
   return DS2_OK;
 }
 
-// normalise unnormalised attention rows [rows][64] + (max, sum) into bf16 operand planes (attention_x4a.hip: one part)
-int launch_w8_merge64(const float* part_o, const float* part_ml, size_t rows, void* o_hi, void* o_lo, int ldop, hipStream_t st) {
+// merge nsplit parts of unnormalised attention rows [nsplit][rows][64] + (max, sum) into bf16 operand planes (attention_x4a.hip)
+int launch_w8_merge64(const float* part_o, const float* part_ml, int nsplit, size_t rows, void* o_hi, void* o_lo, int ldop, hipStream_t st) {
   const dim3 mg((unsigned)((rows * 16 + 255) / 256));
-  hipLaunchKernelGGL((k_w8_merge<64>), mg, dim3(256), 0, st, part_o, part_ml, 1, rows, nullptr, 0, nullptr, 0,
+  hipLaunchKernelGGL((k_w8_merge<64>), mg, dim3(256), 0, st, part_o, part_ml, nsplit, rows, nullptr, 0, nullptr, 0,
                      reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop);
   DS2_CHECK_LAUNCH();
   return DS2_OK;

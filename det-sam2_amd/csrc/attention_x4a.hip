@@ -91,9 +91,10 @@ struct X4AArgs {
   const char* k;          // fp16 key plane [batch * Lk][256]
   const char* vt;         // k_vt_pack32 tiles
   const char* qfrag;      // k_x4a_qprep
-  float* part_o;          // [batch * Lq][64] unnormalised
-  float* part_ml;         // [batch * Lq][2] (maximum in the log2 domain, sum)
+  float* part_o;          // [nsplit][batch * Lq][64] unnormalised
+  float* part_ml;         // [nsplit][batch * Lq][2] (maximum in the log2 domain, sum)
   int batch, Lq, Lk;
+  int nsplit;             // key split (few objects): workgroup (x, y) attends key tiles [y * kt_per, ...) - as k_attention_w8
 };
 
 __global__ __launch_bounds__(256, 1) void k_attention_x4a(X4AArgs a) {
@@ -107,20 +108,24 @@ __global__ __launch_bounds__(256, 1) void k_attention_x4a(X4AArgs a) {
     bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + bid / 8;
   }
   const int b = bid / nqb, q0i = (bid % nqb) * 256;
-  const int nkt = (a.Lk + BK - 1) / BK;   // keys >= Lk of the last tile: masked to -inf in the loop, V^T rows zero (k_vt_pack32)
+  const int nkt_all = (a.Lk + BK - 1) / BK;   // keys >= Lk of the last tile: masked to -inf in the loop, V^T rows zero (k_vt_pack32)
+  const int kt_per = (nkt_all + a.nsplit - 1) / a.nsplit, kt0 = (int)blockIdx.y * kt_per;
+  const int nkt = nkt_all - kt0 < kt_per ? nkt_all - kt0 : kt_per;
+  const bool last_part = kt0 + nkt == nkt_all;
   const size_t row0 = (size_t)b * a.Lq + q0i + wave * 64;            // this wave's first query row
-  const unsigned long long kb = reinterpret_cast<unsigned long long>(a.k + (size_t)b * a.Lk * 512);
-  const unsigned long long vb = reinterpret_cast<unsigned long long>(a.vt + (size_t)b * nkt * VT_BYTES);
+  const size_t prow0 = (size_t)blockIdx.y * a.batch * a.Lq + row0;   // ... in this part's slice of the partial results
+  const unsigned long long kb = reinterpret_cast<unsigned long long>(a.k + ((size_t)b * a.Lk + (size_t)kt0 * BK) * 512);
+  const unsigned long long vb = reinterpret_cast<unsigned long long>(a.vt + ((size_t)b * nkt_all + kt0) * VT_BYTES);
   const unsigned long long qb_ = reinterpret_cast<unsigned long long>(a.qfrag + (row0 / 64) * (32 * 1024));
-  const unsigned long long ob = reinterpret_cast<unsigned long long>(a.part_o + row0 * DV);
-  const unsigned long long mb = reinterpret_cast<unsigned long long>(a.part_ml + row0 * 2);
+  const unsigned long long ob = reinterpret_cast<unsigned long long>(a.part_o + prow0 * DV);
+  const unsigned long long mb = reinterpret_cast<unsigned long long>(a.part_ml + prow0 * 2);
   const unsigned ldsb = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)lds);
   const unsigned klo = __builtin_amdgcn_readfirstlane((unsigned)kb), khi = __builtin_amdgcn_readfirstlane((unsigned)(kb >> 32));
   const unsigned vlo = __builtin_amdgcn_readfirstlane((unsigned)vb), vhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
   const unsigned qlo = __builtin_amdgcn_readfirstlane((unsigned)qb_), qhi = __builtin_amdgcn_readfirstlane((unsigned)(qb_ >> 32));
   const unsigned olo = __builtin_amdgcn_readfirstlane((unsigned)ob), ohi = __builtin_amdgcn_readfirstlane((unsigned)(ob >> 32));
   const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mb), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mb >> 32));
-  const unsigned nval_s = __builtin_amdgcn_readfirstlane((unsigned)(a.Lk - (nkt - 1) * BK));
+  const unsigned nval_s = __builtin_amdgcn_readfirstlane((unsigned)(last_part ? a.Lk - (nkt_all - 1) * BK : BK));
   const unsigned nkt_s = __builtin_amdgcn_readfirstlane((unsigned)nkt), ldsb_s = __builtin_amdgcn_readfirstlane(ldsb);
   asm volatile(X4A_ASM_BODY
                :
@@ -137,14 +142,24 @@ bool attention_x4a_enabled() {
   const bool on = !(e && atoi(e) == 0);
   return on && DS2_ATTN_K_F16 && ds2_precision() == DS2_PREC_BF16X3K;
 }
-// full 256-query blocks, a grid that fills more than half of the chip (fewer: the 8-wave kernel's 128-query form with its key
-// split).  Lk need not be a multiple of 32, but the key plane must be readable (finite values) up to the end of the last tile.
-bool attention_x4a_supported(int batch, int Lq, int Lk, int dv, bool planes_out) {
-  return dv == DV && planes_out && Lq % 256 == 0 && Lk >= 4 * BK && batch * (Lq / 256) > 128;
+// key split when the grid of batch * Lq / 256 workgroups leaves CUs idle (few objects): parts of >= 16 key tiles, <= 8 parts
+static int x4a_nsplit(int batch, int Lq, int Lk) {
+  static const bool off = [] { const char* e = getenv("DS2_ATTN_KSPLIT"); return e && atoi(e) == 0; }();
+  const int nblk = batch * (Lq / 256), nkt = (Lk + BK - 1) / BK;
+  int ns = (off || nblk > 128) ? 1 : 256 / nblk;
+  if (ns > 8) ns = 8;
+  while (ns > 1 && (nkt + ns - 1) / ns < 16) --ns;
+  while (ns > 1 && (ns - 1) * ((nkt + ns - 1) / ns) >= nkt) --ns;   // (no empty last part)
+  return ns;
 }
-size_t attention_x4a_ws_bytes(int batch, int Lq) {
+// full 256-query blocks.  Lk need not be a multiple of 32, but the key plane must be readable (finite values) up to the end of
+// the last tile.
+bool attention_x4a_supported(int batch, int Lq, int Lk, int dv, bool planes_out) {
+  return dv == DV && planes_out && Lq % 256 == 0 && Lk >= 4 * BK && batch > 0;
+}
+size_t attention_x4a_ws_bytes(int batch, int Lq, int Lk) {
   const size_t rows = (size_t)batch * Lq;
-  return (rows / 64) * (32 * 1024) + rows * DV * sizeof(float) + rows * 2 * sizeof(float) + 1024;
+  return (rows / 64) * (32 * 1024) + (size_t)x4a_nsplit(batch, Lq, Lk) * (rows * DV * sizeof(float) + rows * 2 * sizeof(float)) + 1024;
 }
 
 int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
@@ -154,19 +169,20 @@ int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStr
   return DS2_OK;
 }
 
-int launch_w8_merge64(const float* part_o, const float* part_ml, size_t rows, void* o_hi, void* o_lo, int ldop, hipStream_t st);
+int launch_w8_merge64(const float* part_o, const float* part_ml, int nsplit, size_t rows, void* o_hi, void* o_lo, int ldop, hipStream_t st);
 
 int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void* vt32, int batch, int Lq, int Lk, float scale,
                          hipStream_t st, void* o_hi, void* o_lo, int ldop, const float* q_rope_cis, int q_rope_grid, bool q_shared,
                          void* ws, size_t ws_bytes) {
   DS2_REQUIRE(attention_x4a_supported(batch, Lq, Lk, DV, o_hi && o_lo), "attention_x4a: unsupported shape");
-  DS2_REQUIRE(ldq % 4 == 0 && ldop % 4 == 0 && q && k_f16 && vt32 && ws && ws_bytes >= attention_x4a_ws_bytes(batch, Lq),
+  DS2_REQUIRE(ldq % 4 == 0 && ldop % 4 == 0 && q && k_f16 && vt32 && ws && ws_bytes >= attention_x4a_ws_bytes(batch, Lq, Lk),
               "attention_x4a: bad argument / scratch too small");
   const size_t rows = (size_t)batch * Lq;
   char* w = reinterpret_cast<char*>(ws);
   char* qfrag = w;
   float* part_o = reinterpret_cast<float*>(w + (rows / 64) * (32 * 1024));
-  float* part_ml = part_o + rows * DV;
+  const int nsplit = x4a_nsplit(batch, Lq, Lk);
+  float* part_ml = part_o + (size_t)nsplit * rows * DV;
   int rope_w = 0;
   for (int x = 1; x * x <= q_rope_grid; ++x)
     if (x * x == q_rope_grid) rope_w = x;
@@ -175,8 +191,8 @@ int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void*
   hipLaunchKernelGGL(k_x4a_qprep, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, q, ldq, batch, Lq, q_shared ? 0 : Lq,
                      scale * 1.44269504088896340736f, q_rope_cis, q_rope_grid, rope_w, reinterpret_cast<uint4*>(qfrag));
   DS2_CHECK_LAUNCH();
-  X4AArgs a{reinterpret_cast<const char*>(k_f16), reinterpret_cast<const char*>(vt32), qfrag, part_o, part_ml, batch, Lq, Lk};
-  hipLaunchKernelGGL(k_attention_x4a, dim3(batch * (Lq / 256)), dim3(256), 0, st, a);
+  X4AArgs a{reinterpret_cast<const char*>(k_f16), reinterpret_cast<const char*>(vt32), qfrag, part_o, part_ml, batch, Lq, Lk, nsplit};
+  hipLaunchKernelGGL(k_attention_x4a, dim3(batch * (Lq / 256), nsplit), dim3(256), 0, st, a);
   DS2_CHECK_LAUNCH();
-  return launch_w8_merge64(part_o, part_ml, rows, o_hi, o_lo, ldop, st);
+  return launch_w8_merge64(part_o, part_ml, nsplit, rows, o_hi, o_lo, ldop, st);
 }

@@ -188,7 +188,7 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
 // (GemmSplitArgs::c_hi_f16), V^T tiles from launch_vt_pack32, result as bf16 operand planes; ws: attention_x4a_ws_bytes()
 bool attention_x4a_enabled();
 bool attention_x4a_supported(int batch, int Lq, int Lk, int dv, bool planes_out);
-size_t attention_x4a_ws_bytes(int batch, int Lq);
+size_t attention_x4a_ws_bytes(int batch, int Lq, int Lk);
 int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st);   // [batch][ceil(L/32)][64][32] fp16
 int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void* vt32, int batch, int Lq, int Lk, float scale,
                          hipStream_t st, void* o_hi, void* o_lo, int ldop, const float* q_rope_cis, int q_rope_grid, bool q_shared,

@@ -1053,7 +1053,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const size_t ksplit_bytes = split ? (size_t)8 * TOK * (256 + 2) * sizeof(float) : 0;
   // the assembly cross-attention (attention_x4a.hip): its own V^T tile order, Q fragments and unnormalised partial rows
   const bool x4a = split && k_f16 && attention_x4a_enabled() && attention_x4a_supported(B, TOK, Nk, 64, true);
-  const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK) : 0;
+  const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK, Nk) : 0;
   const size_t x4a_bytes = x4a ? x4a_ws_bytes + (size_t)B * nt_c * 4096 + 4096 : 0;
   const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (4u << 20);
   TRY(m->require(need, st));

@@ -11,7 +11,7 @@
 void ds2_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 thread_local int t_ds2_precision = -1;
 int g_ds2_default_precision = DS2_PREC_BF16X3K;
-int launch_w8_merge64(const float*, const float*, size_t, void*, void*, int, hipStream_t) { return 0; }
+int launch_w8_merge64(const float*, const float*, int, size_t, void*, void*, int, hipStream_t) { return 0; }
 
 __global__ void k_fill_f16(unsigned short* p, size_t n, unsigned seed) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   k_fill_f16<<<(kbytes / 2 + 255) / 256, 256>>>((unsigned short*)k, kbytes / 2, 1);
   k_fill_f16<<<(vbytes / 2 + 255) / 256, 256>>>((unsigned short*)vt, vbytes / 2, 2);
   k_fill_f16<<<(rows / 64 * 16384 + 255) / 256, 256>>>((unsigned short*)qf, rows / 64 * 16384, 3);
-  X4AArgs a{k, vt, qf, po, pml, B, Lq, Lk};
+  X4AArgs a{k, vt, qf, po, pml, B, Lq, Lk, 1};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(k_attention_x4a, dim3(B * (Lq / 256)), dim3(256), 0, 0, a);
   hipDeviceSynchronize();
