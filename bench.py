@@ -36,8 +36,9 @@ GEMM_PROBE = int(os.environ.get("DS2_ENCODE_BATCH", "16"))
 PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3k": 2500.0}
 DTYPE = {"fp32": "f32",
          "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
-         "bf16x3k": "bf16x3k (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product; the memory-attention SCORES are "
-                    "plain bf16 x bf16 products and its softmax weights one bf16 plane in P.V; fp32 accumulate/softmax/storage)"}
+         "bf16x3k": "bf16x3k (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product; in the memory attention the q / k / "
+                    "softmax-weight / value operands are ONE fp16 plane each, and the fused MLPs of the memory attention and memory "
+                    "encoder use 2 fp16 MFMAs per product (activations one fp16 plane, weights two); fp32 accumulate/softmax/storage)"}
 
 
 def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
@@ -136,6 +137,17 @@ def cpu_baseline(model_name, n_obj=16):
             "modelled_from_one_object": 1.0 / (t_enc + n_obj * t_one)}
 
 
+SUSTAINED_MFMA_TFLOPS = 1670.0   # measured: tools/experiments/x4a_bench.hip `strip` on all 256 CUs (profiles/r04_mfma_power_calibration.txt)
+
+
+def cross_kernel_name(precision):
+    if precision == "fp32":
+        return "k_attention<256,64>"
+    if precision == "bf16x3k" and os.environ.get("DS2_ATTN_X4A", "1") != "0":
+        return "k_attention_x4a + k_x4a_qprep + k_w8_merge<64>"
+    return "k_attention_w8<64,2>"
+
+
 def kernel_probe(pred, gen, st, last_tracked, table_path=None):
     """GEMM_PROBE more tracked frames of the same generator with HIP-event brackets per GEMM shape ("gemm M N K": the GEMM
     incl. its operand-split pre-pass), per GEMM KERNEL ("kern <name> M N K": the kernel alone) and per attention kernel,
@@ -176,7 +188,7 @@ def kernel_probe(pred, gen, st, last_tracked, table_path=None):
             k["launches"] += n
             k["shapes"][(M, N, Kd)] = (ms, n)
         elif tag == "kernel.cross_attention":
-            kern["k_attention_w8<64,2> (memory cross-attention)"] = {
+            kern[cross_kernel_name(pred.hip.get_precision()) + " (memory cross-attention)"] = {
                 "ms": ms, "flops": sum(cross_attention_flops(B, nk) for nk in nks) * pred.cfg.mem_attn_layers, "launches": n}
         elif tag == "kernel.self_attention":
             kern["k_attention_w8<256,1> (memory self-attention, incl. its V^T split)"] = {
@@ -470,11 +482,16 @@ def main():
         peak = PEAK_TFLOPS[a.precision]
         achieved = cross_attention_flops(B, nk) / (ca_ms / max(ca_n, 1) * 1e-3) / 1e12 if ca_n else None
         cross = {"bound": "mfma",
-                 "kernel": "memory cross-attention (k_attention_w8<64,2> in bf16x3 modes, k_attention<256,64> in fp32 mode), 1 launch/layer",
+                 "kernel": f"memory cross-attention ({cross_kernel_name(a.precision)}), 1 launch/layer",
                  "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": None if achieved is None else achieved / peak,
                  "traffic": None, "traffic_from_committed_pmc": committed_pmc_traffic("cross_attention", B, nk, a.precision),
                  "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
                  "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
+                 "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS,
+                 "frac_of_sustained": None if achieved is None else achieved / SUSTAINED_MFMA_TFLOPS,
+                 "sustained_note": "the fully loaded chip is POWER-limited: this kernel's own MFMA stream (real operands, nothing else) runs "
+                                   "at 1.67 PFLOP/s on 256 CUs and at the nominal 2.5 on 128 (profiles/r04_mfma_power_calibration.txt); "
+                                   "`peak` stays the guide's dense figure",
                  "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time INSIDE the timed "
                          "region (with async_encode the next encoder batch shares the CUs for ~60 % of it: reads ~5 % longer than the "
                          "kernel alone, which `by_kernel` below gives); executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 "

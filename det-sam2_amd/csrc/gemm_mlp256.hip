@@ -311,34 +311,79 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: lane (token, half) holds out[token][nb*32 + 8g + 4 half + e], e = 0..3: one float4 per (nb, g)
-    if (tok < a.rows) {
+    const bool ln = a.ln_w != nullptr;
+    float rsum = 0.f;
 #pragma unroll
-      for (int nb = 0; nb < MD / 32; ++nb) {
+    for (int nb = 0; nb < MD / 32; ++nb) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb * 32 + 8 * g + 4 * half;
-          float4 v = make_float4(out[nb][g * 4 + 0], out[nb][g * 4 + 1], out[nb][g * 4 + 2], out[nb][g * 4 + 3]);
-          if (a.b2) {
-            const float4 b = *reinterpret_cast<const float4*>(a.b2 + n);
-            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-          }
-          if (a.gamma) {
-            const float4 gm = *reinterpret_cast<const float4*>(a.gamma + n);
-            v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
-          }
-          if (a.R) {
-            const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.R + (size_t)tok * a.ldr + n));
-            v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
-          }
-          *reinterpret_cast<float4*>(a.out + (size_t)tok * a.ldo + n) = v;
-          if (a.out_hi) {   // (same split as k_split_rows: round to nearest even, lo = the rounded remainder)
-            uint2 h, l;
-            h.x = cvt_pk_bf16(v.x, v.y);
-            h.y = cvt_pk_bf16(v.z, v.w);
-            l.x = cvt_pk_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
-            l.y = cvt_pk_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
-            *reinterpret_cast<uint2*>(a.out_hi + (size_t)tok * a.ldop + n) = h;
-            *reinterpret_cast<uint2*>(a.out_lo + (size_t)tok * a.ldop + n) = l;
+      for (int g = 0; g < 4; ++g) {
+        const int n = nb * 32 + 8 * g + 4 * half;
+        float4 v = make_float4(out[nb][g * 4 + 0], out[nb][g * 4 + 1], out[nb][g * 4 + 2], out[nb][g * 4 + 3]);
+        if (a.b2) {
+          const float4 b = *reinterpret_cast<const float4*>(a.b2 + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (a.gamma) {
+          const float4 gm = *reinterpret_cast<const float4*>(a.gamma + n);
+          v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
+        }
+        if (a.R && tok < a.rows) {
+          const f32x4 r = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.R + (size_t)tok * a.ldr + n));
+          v.x += r[0]; v.y += r[1]; v.z += r[2]; v.w += r[3];
+        }
+        if (tok < a.rows) *reinterpret_cast<float4*>(a.out + (size_t)tok * a.ldo + n) = v;
+        if (ln) {   // keep the final values for the statistics (the accumulators are dead otherwise)
+          out[nb][g * 4 + 0] = v.x; out[nb][g * 4 + 1] = v.y; out[nb][g * 4 + 2] = v.z; out[nb][g * 4 + 3] = v.w;
+          rsum += (v.x + v.y) + (v.z + v.w);
+        } else if (a.out_hi && tok < a.rows) {   // (same split as k_split_rows: round to nearest even, lo = the rounded remainder)
+          uint2 h, l;
+          h.x = cvt_pk_bf16(v.x, v.y);
+          h.y = cvt_pk_bf16(v.z, v.w);
+          l.x = cvt_pk_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+          l.y = cvt_pk_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+          *reinterpret_cast<uint2*>(a.out_hi + (size_t)tok * a.ldop + n) = h;
+          *reinterpret_cast<uint2*>(a.out_lo + (size_t)tok * a.ldop + n) = l;
+        }
+      }
+    }
+    if (ln) {   // LayerNorm over the token's 256 values: 128 in this lane, 128 in lane ^ 32; two-pass statistics as k_layernorm_vec
+      auto both = [](float x) {
+        const unsigned u = __float_as_uint(x);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      };
+      const float mean = both(rsum) * (1.f / MD);
+      float q = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < MD / 32; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float d = out[nb][e] - mean;
+          q += d * d;
+        }
+      const float rstd = 1.f / sqrtf(both(q) * (1.f / MD) + a.ln_eps);
+      if (tok < a.rows) {
+#pragma unroll
+        for (int nb = 0; nb < MD / 32; ++nb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = nb * 32 + 8 * g + 4 * half;
+            const float4 w4 = *reinterpret_cast<const float4*>(a.ln_w + n), b4 = *reinterpret_cast<const float4*>(a.ln_b + n);
+            float4 y;
+            y.x = (out[nb][g * 4 + 0] - mean) * rstd * w4.x + b4.x;
+            y.y = (out[nb][g * 4 + 1] - mean) * rstd * w4.y + b4.y;
+            y.z = (out[nb][g * 4 + 2] - mean) * rstd * w4.z + b4.z;
+            y.w = (out[nb][g * 4 + 3] - mean) * rstd * w4.w + b4.w;
+            if (a.ln_out) *reinterpret_cast<float4*>(a.ln_out + (size_t)tok * a.ldln + n) = y;
+            if (a.out_hi) {
+              uint2 h, l;
+              h.x = cvt_pk_bf16(y.x, y.y);
+              h.y = cvt_pk_bf16(y.z, y.w);
+              l.x = cvt_pk_bf16(y.x - __uint_as_float(h.x << 16), y.y - __uint_as_float(h.x & 0xffff0000u));
+              l.y = cvt_pk_bf16(y.z - __uint_as_float(h.y << 16), y.w - __uint_as_float(h.y & 0xffff0000u));
+              *reinterpret_cast<uint2*>(a.out_hi + (size_t)tok * a.ldop + n) = h;
+              *reinterpret_cast<uint2*>(a.out_lo + (size_t)tok * a.ldop + n) = l;
+            }
           }
         }
       }

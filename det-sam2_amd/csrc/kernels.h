@@ -164,6 +164,10 @@ struct MlpArgs {
   // two-term fp16 products (mode bf16x3k, memory attention / memory encoder): W1 / W2 planes are FP16 (launch_split_rows
   // f16), X (read from its bf16 planes) and the hidden activations are rounded to ONE fp16 plane: x_h w_h + x_h w_l
   int f16x2;
+  // fused LayerNorm of the RESULT rows (round 4: the next layer's norm1 / the final norm of the memory attention): when ln_w is
+  // set, out_hi / out_lo receive the planes of LN(result) instead of the result's, and ln_out (nullable) its fp32 values;
+  // `out` still receives the un-normalised result (the residual stream)
+  const float *ln_w, *ln_b; float ln_eps; float* ln_out; int ldln;
 };
 bool mlp256_supported(const MlpArgs& a);
 int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st);

@@ -439,6 +439,12 @@ static bool f16x2_enabled() {
   const char* e = getenv("DS2_F16X2");   // (read per call: the tests compare both in one process)
   return !(e && atoi(e) == 0) && ds2_precision() == DS2_PREC_BF16X3K;
 }
+// LayerNorm fused into the fused MLP's epilogue (gemm_mlp256.hip): weights, and where LN(result) goes
+struct LnFuse {
+  const float *w, *b; float eps;
+  float* out_f32;                    // fp32 [rows, 256] (nullable)
+  const ds2_model::ActPlanes* planes;   // pre-allocated operand planes, ld 256 (nullable)
+};
 // DS2_MLP_FUSED=0 keeps the two-GEMM form (A/B runs)
 static bool mlp_fused_enabled() {
   static const bool v = [] { const char* e = getenv("DS2_MLP_FUSED"); return !(e && atoi(e) == 0); }();
@@ -449,10 +455,14 @@ static bool mlp_fused_enabled() {
 // A's operand planes must be registered (its producer emitted them) or are split here.
 static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H, const float* A, int lda, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* gamma, const float* R, int ldr, float* out,
-                     int ldo, int act, bool planes_too = false, bool f16x2 = false) {
+                     int ldo, int act, bool planes_too = false, bool f16x2 = false, const LnFuse* lnf = nullptr) {
   if (!ds2_split_mode() || !mlp_fused_enabled() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
   MlpArgs a{};
   a.f16x2 = f16x2 ? 1 : 0;
+  if (lnf) {   // LayerNorm of the result rows in the epilogue: planes (and / or fp32) of LN(result)
+    a.ln_w = lnf->w; a.ln_b = lnf->b; a.ln_eps = lnf->eps; a.ln_out = lnf->out_f32; a.ldln = 256;
+    if (lnf->planes) { a.out_hi = lnf->planes->hi; a.out_lo = lnf->planes->lo; a.ldop = lnf->planes->ld; }
+  }
   a.rows = rows; a.D = 256; a.H = H; a.ldx = 256; a.ldw1 = 256; a.ldw2 = H;
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.R = R; a.ldr = ldr; a.out = out; a.ldo = ldo; a.act = act;
   if (!mlp256_supported(a) || !(act == DS2_ACT_NONE || act == DS2_ACT_RELU || act == DS2_ACT_GELU)) return DS2_ERR_UNSUPPORTED;
@@ -491,7 +501,7 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     xh = sh; xl = sl;
   }
   a.X_hi = xh; a.X_lo = xl;
-  if (planes_too && m && ldo == 256) {   // the result also as the next GEMM's operand planes, registered under `out`
+  if (planes_too && !lnf && m && ldo == 256) {   // the result also as the next GEMM's operand planes, registered under `out`
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, out, rows, 256, &op, st));
     a.out_hi = op.hi; a.out_lo = op.lo; a.ldop = op.ld;
@@ -504,10 +514,12 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
 // two-layer MLP by state_dict prefixes: fused when the shape allows it, else the two GEMMs (hidden planes in `hbuf`)
 // planes_too: `out` feeds a GEMM next - the fused kernel writes its operand planes alongside the fp32 result
 static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::string& p2, int rows, int H, const float* A,
-                float* hbuf, float* out, int act, const float* R, const float* gamma, bool planes_too = false, bool f16x2 = false) {
+                float* hbuf, float* out, int act, const float* R, const float* gamma, bool planes_too = false, bool f16x2 = false,
+                const LnFuse* lnf = nullptr, bool* ln_done = nullptr) {
   m->act_planes.erase(out);   // (`out` is rewritten: planes registered for its previous contents are stale)
   const int rc = mlp_fused(m, m->gctx, st, rows, H, A, 256, m->P(p1 + ".weight"), m->P(p1 + ".bias"), m->P(p2 + ".weight"),
-                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too, f16x2);
+                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too, f16x2, lnf);
+  if (ln_done) *ln_done = lnf && rc == DS2_OK;
   if (rc != DS2_ERR_UNSUPPORTED) return rc;
   TRY(linear(m, st, p1, rows, H, 256, A, 256, hbuf, H, act, nullptr, 0, 0, nullptr, true));
   return linear(m, st, p2, rows, 256, H, hbuf, H, out, 256, DS2_ACT_NONE, R, 256, 0, gamma);
@@ -1055,7 +1067,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const bool x4a = split && k_f16 && attention_x4a_enabled() && attention_x4a_supported(B, TOK, Nk, 64, true);
   const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK, Nk) : 0;
   const size_t x4a_bytes = x4a ? x4a_ws_bytes + (size_t)B * nt_c * 4096 + 4096 : 0;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (4u << 20);
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (split ? (size_t)rows * 2048 + 4096 : 0) + (4u << 20);
   TRY(m->require(need, st));
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
@@ -1114,6 +1126,19 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   } else {
     TRY(launch_add_bcast(memory, 64, memory_pos, 64, 0, 1.0f, kin, 64, B * Nk, 64, st));
   }
+  // norm1 of layers 1.. and the final norm are computed in the epilogue of the previous layer's fused MLP (DS2_MA_FUSE_LN=0: as
+  // separate passes): their operand planes live outside the per-layer workspace marks, two sets used alternately
+  static const bool fuse_ln_on = [] { const char* e = getenv("DS2_MA_FUSE_LN"); return !(e && atoi(e) == 0); }();
+  const bool fuse_ln = split && fuse_ln_on && mlp_fused_enabled();
+  ds2_model::ActPlanes n1p[2] = {};
+  if (fuse_ln)
+    for (int i = 0; i < 2; ++i) {
+      n1p[i].hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * 512));
+      n1p[i].lo = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * 512));
+      n1p[i].ld = 256;
+      if (!n1p[i].hi || !n1p[i].lo) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
+    }
+  bool n1_ready = false, final_done = false;
   const float sc = 1.0f / 16.0f;  // 1/sqrt(256)
   for (int l = 0; l < m->cfg.mem_attn_layers; ++l) {
     const std::string p = "memory_attention.layers." + std::to_string(l);
@@ -1124,7 +1149,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     const bool once = (l == 0) && shared0;
     const int Bs = once ? 1 : B;
     const float* xin = once ? x1 : x;
-    TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
+    if (n1_ready) m->act_planes[t] = n1p[l & 1];   // emitted by the previous layer's MLP epilogue
+    else TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
     TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
     if (!split) TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));   // (the bf16x3 kernel rotates q while loading it)
     if (split) {
@@ -1213,10 +1239,17 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     }
     // -- FFN
     TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
-    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr, false, f16x2_enabled()));
+    const bool last = l + 1 == m->cfg.mem_attn_layers;
+    const std::string pn = last ? std::string("memory_attention.norm") : "memory_attention.layers." + std::to_string(l + 1) + ".norm1";
+    const LnFuse lnf{m->P(pn + ".weight"), m->P(pn + ".bias"), 1e-5f, last ? out : nullptr, last ? nullptr : &n1p[(l + 1) & 1]};
+    bool ln_done = false;
+    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr, false, f16x2_enabled(),
+             (fuse_ln && lnf.w && lnf.b) ? &lnf : nullptr, &ln_done));
+    n1_ready = ln_done && !last;
+    final_done = ln_done && last;
     m->release(layer_mark);
   }
-  TRY(layernorm(m, st, "memory_attention.norm", x, out, rows, 256, 1e-5f));
+  if (!final_done) TRY(layernorm(m, st, "memory_attention.norm", x, out, rows, 256, 1e-5f));
   CHECK_PARAMS();
   return DS2_OK;
 }
