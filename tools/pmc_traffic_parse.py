@@ -9,9 +9,15 @@ import sys
 B, NK, TOK = 16, 28736, 4096
 KERNELS = {   # key -> (name pattern, algorithmic bytes per launch)
     # Q fp32 + K hi plane + V^T planes (lo only for the 64 pointer tokens) read once, output planes written once
-    "cross_attention": ("%k_attention_w8<64%", B * (4.0 * TOK * 256 + 2.0 * NK * 256 + 2.0 * NK * 64 + 2.0 * 64 * 64 + 4.0 * TOK * 64)),
+    # round 4 (assembly kernel): Q fragments fp16 + K plane + V^T plane read once, unnormalised rows + (max, sum) written once
+    "cross_attention": ("%k_attention_x4a%", B * (2.0 * TOK * 256 + 2.0 * NK * 256 + 2.0 * NK * 64 + 4.0 * TOK * 64 + 8.0 * TOK)),
+    # its query pass (fp32 queries in, fp16 fragments out) and its merge (rows + statistics in, two bf16 planes out)
+    "cross_attention_qprep": ("%k_x4a_qprep%", B * TOK * 256 * (4.0 + 2.0)),
+    "cross_attention_merge": ("%k_w8_merge<64>%", B * TOK * (64 * 4.0 + 8.0 + 64 * 4.0)),
+    # the 8-wave kernel (mode bf16x3 / DS2_ATTN_X4A=0): Q fp32 + K hi plane + V^T planes (lo only for the 64 pointer tokens)
+    "cross_attention_w8": ("%k_attention_w8<64%", B * (4.0 * TOK * 256 + 2.0 * NK * 256 + 2.0 * NK * 64 + 2.0 * 64 * 64 + 4.0 * TOK * 64)),
     # memory-attention FFN, fused: X planes in, residual in, result out (fp32) + the weights once
-    "k_mlp256": ("%k_mlp256<1>%", B * TOK * 256 * (4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
+    "k_mlp256": ("%k_mlp256<1%", B * TOK * 256 * (4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
 }
 
 

@@ -92,7 +92,14 @@ def emu_linear(x, w, b=None):
     rows = x.numel() // x.shape[-1]
     if SCHEME == "exact" or rows <= 128:          # k_skinny_linear: exact fp32 in every mode
         return _orig_linear(x, w, b)
-    if ONLY and REGION[0] != ONLY and SCHEME != "bf16x3":
+    in_region = REGION[0] == ONLY
+    if ONLY == "encmlp":      # the MLP GEMMs of the Hiera blocks only (fc1: N = 4 K, fc2: K = 4 N)
+        in_region = REGION[0] == "enc" and (w.shape[0] == 4 * w.shape[1] or w.shape[1] == 4 * w.shape[0])
+    if ONLY == "encfc2":
+        in_region = REGION[0] == "enc" and w.shape[1] == 4 * w.shape[0]
+    if ONLY == "encfc1":
+        in_region = REGION[0] == "enc" and w.shape[0] == 4 * w.shape[1]
+    if ONLY and not in_region and SCHEME != "bf16x3":
         keep, SCHEME = SCHEME, "bf16x3"
         try:
             return emu_linear(x, w, b)
