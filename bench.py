@@ -504,6 +504,7 @@ def main():
             v = cand[name]
             is_gemm = name.startswith("k_gemm_split")
             dom = {"bound": "mfma", "kernel": name, "achieved": v["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": v["tflops"] / peak,
+                   "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": v["tflops"] / SUSTAINED_MFMA_TFLOPS,
                    "traffic": None,
                    "traffic_from_committed_pmc": committed_pmc_traffic(name.split()[0].split("<")[0] if is_gemm else "cross_attention", B, nk, a.precision),
                    "avg_launch_ms": v["avg_launch_ms"], "launches_per_frame": v["launches_per_frame"], "ms_per_frame": v["ms_per_frame"],
