@@ -252,6 +252,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
 #ifndef DS2_SMALLWIN
 #define DS2_SMALLWIN 1
 #endif
+  if (ds2_split_mode() && attention_winlds_supported(a)) return launch_attention_winlds(a, st);
   if (DS2_SMALLWIN && ds2_split_mode() && attention_smallwin_supported(a)) return launch_attention_smallwin(a, st);
   if (ds2_split_mode()) {
     const int rc = launch_attention_bf16x3(a, st);

@@ -168,6 +168,8 @@ bool attention_fewq_supported(const AttnArgs& a);                // Lq <= 16 aga
 int launch_attention_fewq(const AttnArgs& a, hipStream_t st);    // split-key exact fp32 path (attention_fewq.hip)
 bool attention_smallwin_supported(const AttnArgs& a);            // 16- / 64-key Hiera windows, bf16x3 (attention_smallwin.hip)
 int launch_attention_smallwin(const AttnArgs& a, hipStream_t st);
+bool attention_winlds_supported(const AttnArgs& a);               // 16 x 16 / 14 x 14 Hiera windows, head dim 72, whole window in LDS (attention_winlds.hip)
+int launch_attention_winlds(const AttnArgs& a, hipStream_t st);
 // Hiera global attention over operands pre-split per (image, head) (attention_hg.hip): the caller provides the plane buffers
 bool attention_hg_supported(const AttnArgs& a);
 size_t attention_hg_k_bytes(const AttnArgs& a);                  // K tile images (hi + lo planes)
