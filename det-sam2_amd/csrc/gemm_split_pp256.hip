@@ -121,6 +121,9 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_pp256(GemmSplitArgs g, in
       gv[tn] = (g.gamma && col < g.N) ? g.gamma[col] : 1.f;
     }
 
+    // a wave's 32 columns of a 128-column half lie beyond N (N = 1152: the whole second half of the fifth tile): no MFMAs for them
+    // (the wave still reads, stages and meets the barriers; on a power-limited chip the saved matrix work is time for the others)
+    const bool deadq[2] = {n0 + wn * 32 >= g.N, n0 + 128 + wn * 32 >= g.N};
     f32x16 acc[4][2];   // [qm * 2 + 32-row tile][qn]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_pp256(GemmSplitArgs g, in
     F.l[s] = *reinterpret_cast<const bf16x8*>(b_ + HPL);                                                        \
   }
 #define PP_MFMA(qm, qn, F)                                                                                      \
+  if (!deadq[qn])                                                                                               \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                               \
     if (!(g.drop_terms & 1))                                                                                    \
       _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \

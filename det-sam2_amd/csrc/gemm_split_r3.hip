@@ -13,6 +13,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef DS2_R3_NODEAD
+#define DS2_R3_NODEAD 0   // (A/B builds: 1 = every wave multiplies its padding columns as before)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -106,10 +110,18 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
     }                                                                                          \
   }
 #define R3_MFMA_TERM(F, X, Y)                                                                  \
-  _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                             \
-    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                           \
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.X[tm], F.Y[tn], acc[tm][tn], 0, 0, 0);
+  _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                             \
+    if (tn < live)                                                                             \
+      _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                         \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.X[tm], F.Y[tn], acc[tm][tn], 0, 0, 0);
 
+  // a wave whose columns lie (partly) beyond N (N = 576: the second wave column of the fifth 128-wide tile) multiplies zeros
+  // there: it keeps staging, reading and meeting the barriers but issues no MFMA for its dead 32-column blocks - on a
+  // power-limited chip that is time for the others.  live = 32-column blocks of this wave with at least one real column
+  int live_ = DS2_R3_NODEAD ? 2 : (g.N - (n0 + wn * 64) + 31) / 32;
+  live_ = live_ < 0 ? 0 : (live_ > 2 ? 2 : live_);
+  const int live = __builtin_amdgcn_readfirstlane(live_);
+  const bool dead = live == 0;
   FragsR F0, F1;
   int s0 = 0, s1 = STAGE, s2 = 2 * STAGE;       // stage offsets of tiles t, t+1, t+2
   R3_FILL(0, s0)
@@ -123,18 +135,22 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
     R3_READ(F1, s0, 1)
     R3_FILL(kt + 2, s2)
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F0, al, bh)
-    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F0, ah, bl)
-    R3_MFMA_TERM(F0, ah, bh)
-    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F1, al, bh)
+    if (!dead) {
+      if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F0, al, bh)
+      if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F0, ah, bl)
+      R3_MFMA_TERM(F0, ah, bh)
+      if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F1, al, bh)
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 landed; tile kt+2's 6 pieces stay in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     R3_READ(F0, s1, 0)
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's first reads AHEAD of the trailing MFMAs
-    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F1, ah, bl)
-    R3_MFMA_TERM(F1, ah, bh)
+    if (!dead) {
+      if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F1, ah, bl)
+      R3_MFMA_TERM(F1, ah, bh)
+    }
     const int t_ = s0; s0 = s1; s1 = s2; s2 = t_;
   }
 
