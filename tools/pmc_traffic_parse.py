@@ -16,8 +16,10 @@ KERNELS = {   # key -> (name pattern, algorithmic bytes per launch)
     "cross_attention_merge": ("%k_w8_merge<64>%", B * TOK * (64 * 4.0 + 8.0 + 64 * 4.0)),
     # the 8-wave kernel (mode bf16x3 / DS2_ATTN_X4A=0): Q fp32 + K hi plane + V^T planes (lo only for the 64 pointer tokens)
     "cross_attention_w8": ("%k_attention_w8<64%", B * (4.0 * TOK * 256 + 2.0 * NK * 256 + 2.0 * NK * 64 + 2.0 * 64 * 64 + 4.0 * TOK * 64)),
-    # memory-attention FFN, fused: X planes in, residual in, result out (fp32) + the weights once
-    "k_mlp256": ("%k_mlp256<1%", B * TOK * 256 * (4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
+    # memory-attention FFN, fused: X planes in, residual in, result out (fp32), LN(result) out as two planes (3 of 4 layers; fp32 in
+    # the last) + the weights once.  (FETCH_SIZE counts L2 misses: the 4 MB of weight planes every 128-row block re-reads compete
+    # with the token streams for a 4 MB L2 per XCD and are partly served from the MALL, not from HBM.)
+    "k_mlp256": ("%k_mlp256<1%", B * TOK * 256 * (4.0 + 4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
 }
 
 
