@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_vt_split16(const float* __restrict__ v,
     const int pos = 8 * ((key >> 2) & 3) + (key & 3) + 4 * (key >> 4);
     const unsigned lb = cvt_pk_bf16(x0 - bf_lo(hh), x1 - bf_hi(hh));
     if constexpr (F16) {
-      const unsigned hf = cvt_pk_f16(x0, x1);
+      const unsigned hf = cvt_pk_f16(ds2_sat_f16(x0), ds2_sat_f16(x1));
       h[pos >> 1] = hf;
       l[pos >> 1] = cvt_pk_f16(x0 - f16_lo(hf), x1 - f16_hi(hf));
     } else {
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
           for (int ks = 0; ks < KS; ++ks) {
             const float* qr = qrow + ks * 32;
             if constexpr (KLO) split8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7], q0[g][ks], q1[g][ks]);
-            else if constexpr (KF16) q0[g][ks] = pack8h(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7]);
+            else if constexpr (KF16) q0[g][ks] = pack8h(ds2_sat_f16(qr[0]), ds2_sat_f16(qr[1]), ds2_sat_f16(qr[2]), ds2_sat_f16(qr[3]),
+                                                        ds2_sat_f16(qr[4]), ds2_sat_f16(qr[5]), ds2_sat_f16(qr[6]), ds2_sat_f16(qr[7]));
             else q0[g][ks] = pack8(qr[0], qr[1], qr[2], qr[3], qr[4], qr[5], qr[6], qr[7]);
           }
         }
@@ -752,7 +753,7 @@ __global__ void k_rope_split(const float* x, int ldx, const float* cis, int batc
     v = make_float4(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x, v.z * c.z - v.w * c.w, v.z * c.w + v.w * c.z);
   }
   if (hi_f16) {           // bf16x3k mode: the keys of the scores are one fp16 plane
-    hi[i] = make_uint2(cvt_pk_f16(v.x, v.y), cvt_pk_f16(v.z, v.w));
+    hi[i] = make_uint2(cvt_pk_f16(ds2_sat_f16(v.x), ds2_sat_f16(v.y)), cvt_pk_f16(ds2_sat_f16(v.z), ds2_sat_f16(v.w)));
     return;
   }
   uint2 h, l;

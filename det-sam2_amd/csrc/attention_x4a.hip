@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_vt_pack32(const float* __restrict__ v, 
   for (int key = 0; key < 32; key += 2) {
     const float x0 = key < nvalid ? src[(size_t)key * ldv] : 0.f;
     const float x1 = key + 1 < nvalid ? src[(size_t)(key + 1) * ldv] : 0.f;
-    h[vt_pos32(key) >> 1] = cvt_pk_f16(x0, x1);
+    h[vt_pos32(key) >> 1] = cvt_pk_f16(ds2_sat_f16(x0), ds2_sat_f16(x1));
   }
   uint4* o = reinterpret_cast<uint4*>(vt + (bt * DV + dv) * 32);
 #pragma unroll
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_x4a_qprep(const float* __restrict__ q, 
     v0 = make_float4(v0.x * c0.x - v0.y * c0.y, v0.x * c0.y + v0.y * c0.x, v0.z * c0.z - v0.w * c0.w, v0.z * c0.w + v0.w * c0.z);
     v1 = make_float4(v1.x * c1.x - v1.y * c1.y, v1.x * c1.y + v1.y * c1.x, v1.z * c1.z - v1.w * c1.w, v1.z * c1.w + v1.w * c1.z);
   }
-  qfrag[i] = make_uint4(cvt_pk_f16(v0.x * sc, v0.y * sc), cvt_pk_f16(v0.z * sc, v0.w * sc), cvt_pk_f16(v1.x * sc, v1.y * sc),
-                        cvt_pk_f16(v1.z * sc, v1.w * sc));
+  auto pk = [](float x, float y) { return cvt_pk_f16(ds2_sat_f16(x), ds2_sat_f16(y)); };
+  qfrag[i] = make_uint4(pk(v0.x * sc, v0.y * sc), pk(v0.z * sc, v0.w * sc), pk(v1.x * sc, v1.y * sc), pk(v1.z * sc, v1.w * sc));
 }
 
 struct X4AArgs {

@@ -61,6 +61,10 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // (lane>>5): row = (r&3) + 8*(r>>2) + 4*h; the column is lane&31.
 __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// fp32 -> fp16 operand planes (mode bf16x3k) SATURATE: |x| > 65504 becomes +-65504, not inf - an out-of-range activation of a real
+// checkpoint must degrade a product, not turn the frame into NaNs (bf16 planes have fp32's range and need nothing)
+__device__ __forceinline__ float ds2_sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
+
 // ---- epilogue / activation codes shared by GEMM and LayerNorm
 enum { DS2_ACT_NONE = 0, DS2_ACT_RELU = 1, DS2_ACT_GELU = 2, DS2_ACT_SIGMOID = 3 };
 

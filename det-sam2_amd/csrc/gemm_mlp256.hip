@@ -49,7 +49,7 @@ __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {   // v_cvt_pk_f16_f32, round to nearest even
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2{a, b}), h2));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2{ds2_sat_f16(a), ds2_sat_f16(b)}), h2));   // (saturating)
 }
 constexpr int MD = 256;            // model width (k of phase A, n of phase B)
 constexpr int MBR = 128;           // token rows per workgroup

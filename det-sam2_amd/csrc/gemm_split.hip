@@ -62,7 +62,8 @@ __global__ void k_split_rows_f16(const float* x, int ldx, int rows, int cols, ui
   const size_t r = i / q;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 * 4 < cols) v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
-  const h2 h0 = __builtin_convertvector((f2{v.x, v.y}), h2), h1 = __builtin_convertvector((f2{v.z, v.w}), h2);
+  const h2 h0 = __builtin_convertvector((f2{ds2_sat_f16(v.x), ds2_sat_f16(v.y)}), h2);
+  const h2 h1 = __builtin_convertvector((f2{ds2_sat_f16(v.z), ds2_sat_f16(v.w)}), h2);
   const h2 l0 = __builtin_convertvector((f2{v.x - (float)h0[0], v.y - (float)h0[1]}), h2);
   const h2 l1 = __builtin_convertvector((f2{v.z - (float)h1[0], v.w - (float)h1[1]}), h2);
   hi[i] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
             typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             uint2 h;   // v_cvt_pk_f16_f32, round to nearest even
-            h.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{v[0], v[1]}), f16x2));
-            h.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{v[2], v[3]}), f16x2));
+            h.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ds2_sat_f16(v[0]), ds2_sat_f16(v[1])}), f16x2));
+            h.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ds2_sat_f16(v[2]), ds2_sat_f16(v[3])}), f16x2));
             *reinterpret_cast<uint2*>(e_Chi + (size_t)m * g.ldcp + n) = h;
           } else {
           uint2 h, l;

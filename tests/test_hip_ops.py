@@ -93,6 +93,28 @@ def test_fused_mlp(rows, H, act, use_r, use_g, f16x2, monkeypatch):
     assert torch.equal(got, again)                 # run-to-run bit identity (DMA ring hazards show up here)
 
 
+def test_fused_mlp_f16x2_saturates(monkeypatch):
+    """The fp16 operand planes of the two-term form saturate: an activation beyond fp16's range (6.5e4) gives a finite result
+    (the row it sits in is approximate), never inf / NaN, and the other rows are untouched."""
+    from det_sam2_amd.hip_model import HipOps
+    monkeypatch.setenv("DS2_OP_MLP_F16X2", "1")
+    o = HipOps("cuda:0")
+    o.set_precision("bf16x3")
+    g = torch.Generator().manual_seed(3)
+    X, W1, b1 = torch.randn(256, 256, generator=g), torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g)
+    W2, b2 = torch.randn(256, 128, generator=g) / 11, torch.randn(256, generator=g)
+    Xbig = X.clone()
+    Xbig[7, 5] = 3.0e6
+    d = o.device
+    ref = o.op_mlp(X.to(d), W1.to(d), b1.to(d), W2.to(d), b2.to(d), None, None, 1)
+    got = o.op_mlp(Xbig.to(d), W1.to(d), b1.to(d), W2.to(d), b2.to(d), None, None, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    keep = torch.ones(256, dtype=torch.bool)
+    keep[7] = False
+    assert torch.equal(got[keep.to(d)], ref[keep.to(d)])
+
+
 @pytest.mark.parametrize("M,N,K,act,use_r,r_mod", [
     (128, 256, 256, 0, True, 0),       # token-side projection, 16 objects x 8 tokens, residual
     (128, 2048, 256, 1, False, 0),     # two-way transformer MLP, first layer (ReLU)
