@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   const char* w1l = reinterpret_cast<const char*>(a.W1_lo);
   const char* w2h = reinterpret_cast<const char*>(a.W2_hi);
   const char* w2l = reinterpret_cast<const char*>(a.W2_lo);
-  const int nchunk = a.H / MHC;
+  // (hidden split: this workgroup walks the chunks [c_begin, c_end) of its part)
+  const int nchunk_all = a.H / MHC, nparts = a.hsplit > 1 ? a.hsplit : 1;
+  const int hp = nparts > 1 ? (int)blockIdx.y : 0;
+  const int c_begin = hp * (nchunk_all / nparts), c_end = c_begin + nchunk_all / nparts;
   // DMA: a piece = 16 rows x 64 B of one plane (1 KiB, one wave instruction); lane -> (row = lane >> 2, physical 16-byte
   // chunk = lane & 3) fetching the logical chunk (lane & 3) ^ ((lane >> 4) & 3)
   const int drow = lane >> 2;
@@ -203,15 +206,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
       for (int e = 0; e < 16; ++e) out[i][e] = 0.f;
 
     // ---- ring prologue: tiles 0..2 of chunk 0 (the X loads above are ordinary loads: drained with them)
-    MLP_DMA(0, 0, 0)
-    MLP_DMA(1, 0, 1)
-    MLP_DMA(2, 0, 2)
+    MLP_DMA(0, c_begin, 0)
+    MLP_DMA(1, c_begin, 1)
+    MLP_DMA(2, c_begin, 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();        // (also publishes b1s on the first row block)
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int c2 = 0; c2 < nchunk; c2 += 2) {
-      const int cn2 = (c2 + 2 < nchunk) ? c2 + 2 : 0;   // (the tail prefetches wrap around: uniform DMA accounting)
+    for (int c2 = c_begin; c2 < c_end; c2 += 2) {
+      const int cn2 = (c2 + 2 < c_end) ? c2 + 2 : c_begin;   // (the tail prefetches wrap around: uniform DMA accounting)
       // phase A step at pair position PP (tile T = PP % 6 of chunk c2 + PP / 6): W1 tile, 64 hidden x 64 k
 #define MLP_A(PP)                                                                                                         \
   {                                                                                                                       \
@@ -311,6 +314,18 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: lane (token, half) holds out[token][nb*32 + 8g + 4 half + e], e = 0..3: one float4 per (nb, g)
+    if (nparts > 1) {   // hidden split: the raw partial sums of this part; k_mlp256_merge finishes
+      if (tok < a.rows) {
+        float* pp = a.part + ((size_t)hp * a.rows + tok) * MD;
+#pragma unroll
+        for (int nb = 0; nb < MD / 32; ++nb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(pp + nb * 32 + 8 * g + 4 * half) =
+                make_float4(out[nb][g * 4 + 0], out[nb][g * 4 + 1], out[nb][g * 4 + 2], out[nb][g * 4 + 3]);
+      }
+      continue;
+    }
     const bool ln = a.ln_w != nullptr;
     float rsum = 0.f;
 #pragma unroll
@@ -399,7 +414,69 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
 #undef MLP_STEP_END
 }
 
+// Finish of the hidden split: one wave per token row, lane = 4 consecutive columns.  out = (sum of the parts + b2) * gamma + R;
+// optional LayerNorm of that row (two-pass statistics over the wave) and / or operand planes, as the fused epilogue.
+__global__ __launch_bounds__(256) void k_mlp256_merge(MlpArgs a) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (size_t)a.rows) return;
+  const int n = lane * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < a.hsplit; ++s) {
+    const float4 p = *reinterpret_cast<const float4*>(a.part + ((size_t)s * a.rows + row) * MD + n);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+  }
+  if (a.b2) {
+    const float4 b = *reinterpret_cast<const float4*>(a.b2 + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (a.gamma) {
+    const float4 gm = *reinterpret_cast<const float4*>(a.gamma + n);
+    v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
+  }
+  if (a.R) {
+    const float4 r = *reinterpret_cast<const float4*>(a.R + row * a.ldr + n);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  *reinterpret_cast<float4*>(a.out + row * a.ldo + n) = v;
+  float4 y = v;
+  if (a.ln_w) {
+    auto wsum = [](float x) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+      return x;
+    };
+    const float mean = wsum((v.x + v.y) + (v.z + v.w)) * (1.f / MD);
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    const float rstd = 1.f / sqrtf(wsum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.f / MD) + a.ln_eps);
+    const float4 w4 = *reinterpret_cast<const float4*>(a.ln_w + n), b4 = *reinterpret_cast<const float4*>(a.ln_b + n);
+    y = make_float4(d0 * rstd * w4.x + b4.x, d1 * rstd * w4.y + b4.y, d2 * rstd * w4.z + b4.z, d3 * rstd * w4.w + b4.w);
+    if (a.ln_out) *reinterpret_cast<float4*>(a.ln_out + row * a.ldln + n) = y;
+  }
+  if (a.out_hi) {
+    uint2 h, l;
+    h.x = cvt_pk_bf16(y.x, y.y);
+    h.y = cvt_pk_bf16(y.z, y.w);
+    l.x = cvt_pk_bf16(y.x - __uint_as_float(h.x << 16), y.y - __uint_as_float(h.x & 0xffff0000u));
+    l.y = cvt_pk_bf16(y.z - __uint_as_float(h.y << 16), y.w - __uint_as_float(h.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(a.out_hi + row * a.ldop + n) = h;
+    *reinterpret_cast<uint2*>(a.out_lo + row * a.ldop + n) = l;
+  }
+}
+
 }  // namespace
+
+// parts of the hidden dimension for `rows` token rows on `ncu` CUs: as many as keep every CU busy, <= 8, each a whole number of
+// chunk pairs (DS2_MLP_HSPLIT=0: never)
+int mlp256_hsplit(int rows, int H, int ncu) {
+  static const bool off = [] { const char* e = getenv("DS2_MLP_HSPLIT"); return e && atoi(e) == 0; }();
+  const int nrb = cdiv(rows, MBR), npair = H / (2 * MHC);
+  if (off || nrb * 2 > ncu) return 1;
+  int hs = ncu / nrb;
+  if (hs > 8) hs = 8;
+  while (hs > 1 && npair % hs) --hs;
+  return hs;
+}
 
 bool mlp256_supported(const MlpArgs& a) {
   return a.D == MD && a.H % (2 * MHC) == 0 && a.H <= 4096 /* chunk pairs; b1 in LDS */ && a.rows > 0 && a.ldx % 8 == 0 && a.ldw1 % 8 == 0 &&
@@ -417,15 +494,31 @@ int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float*
   return DS2_OK;
 }
 
-int launch_mlp256(const MlpArgs& a, hipStream_t st) {
-  DS2_REQUIRE(mlp256_supported(a), "mlp256: unsupported shape rows=%d D=%d H=%d", a.rows, a.D, a.H);
-  DS2_REQUIRE(a.X_hi && a.X_lo && a.W1_hi && a.W1_lo && a.W2_hi && a.W2_lo && a.out, "mlp256: null operand");
+int mlp256_ncu() {
   static const int ncu = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
   }();
+  return ncu;
+}
+// scratch the hidden split of a launch with `rows` rows needs (0: no split)
+size_t mlp256_part_bytes(int rows, int H) {
+  const int hs = mlp256_hsplit(rows, H, mlp256_ncu());
+  return hs > 1 ? (size_t)hs * rows * MD * sizeof(float) : 0;
+}
+
+int launch_mlp256(const MlpArgs& a, hipStream_t st) {
+  DS2_REQUIRE(mlp256_supported(a), "mlp256: unsupported shape rows=%d D=%d H=%d", a.rows, a.D, a.H);
+  DS2_REQUIRE(a.X_hi && a.X_lo && a.W1_hi && a.W1_lo && a.W2_hi && a.W2_lo && a.out, "mlp256: null operand");
+  const int ncu = mlp256_ncu();
   const int nrb = cdiv(a.rows, MBR);
+  MlpArgs b = a;
+  b.hsplit = 1;
+  if (a.part) {
+    const int hs = mlp256_hsplit(a.rows, a.H, ncu);
+    if (hs > 1 && a.part_bytes >= (size_t)hs * a.rows * MD * sizeof(float)) b.hsplit = hs;
+  }
   const int grid = nrb < ncu ? nrb : ncu;
   const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4;
   void (*kern)(MlpArgs) = nullptr;
@@ -441,7 +534,11 @@ int launch_mlp256(const MlpArgs& a, hipStream_t st) {
     DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[x2][a.act] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(grid, b.hsplit), dim3(256), smem, st, b);
   DS2_CHECK_LAUNCH();
+  if (b.hsplit > 1) {
+    hipLaunchKernelGGL(k_mlp256_merge, dim3(cdiv(a.rows, 4)), dim3(256), 0, st, b);
+    DS2_CHECK_LAUNCH();
+  }
   return DS2_OK;
 }

@@ -168,10 +168,16 @@ struct MlpArgs {
   // set, out_hi / out_lo receive the planes of LN(result) instead of the result's, and ln_out (nullable) its fp32 values;
   // `out` still receives the un-normalised result (the residual stream)
   const float *ln_w, *ln_b; float ln_eps; float* ln_out; int ldln;
+  // few rows (fewer 128-row blocks than half of the CUs: few objects): the hidden dimension is split over hsplit workgroups per
+  // row block; each writes its raw partial result to part [hsplit][rows][256] and k_mlp256_merge adds them up and applies the
+  // epilogue (bias, gamma, residual, LayerNorm, planes).  Set by launch_mlp256 when `part` (scratch) is provided.
+  float* part; size_t part_bytes; int hsplit;
 };
 bool mlp256_supported(const MlpArgs& a);
 int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st);
 int launch_mlp256(const MlpArgs& a, hipStream_t st);
+int mlp256_hsplit(int rows, int H, int ncu);       // parts of the hidden dimension a launch would be split into (1: none)
+size_t mlp256_part_bytes(int rows, int H);         // scratch (MlpArgs::part) that split needs, 0 if none
 
 // 8-wave variant on v_mfma_f32_16x16x32_bf16 (attention_w8.hip); V^T tiles use a different key permutation
 // n_exact_keys/flag (optional): the leading n_exact_keys keys are expected to be bf16-exact; *flag (device int) is

@@ -501,6 +501,20 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     xh = sh; xl = sl;
   }
   a.X_hi = xh; a.X_lo = xl;
+  if (const size_t pb = mlp256_part_bytes(rows, H)) {   // few rows: hidden dimension split over workgroups, parts merged after
+    a.part = reinterpret_cast<float*>(m ? m->alloc_bytes(pb) : nullptr);
+    if (!a.part && !m) {   // primitive call: a scratch of its own behind the operand split
+      static thread_local float* op_part = nullptr;
+      static thread_local size_t op_part_bytes = 0;
+      if (op_part_bytes < pb) {
+        if (op_part) (void)hipFree(op_part);
+        DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&op_part), pb));
+        op_part_bytes = pb;
+      }
+      a.part = op_part;
+    }
+    a.part_bytes = a.part ? pb : 0;
+  }
   if (planes_too && !lnf && m && ldo == 256) {   // the result also as the next GEMM's operand planes, registered under `out`
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, out, rows, 256, &op, st));
@@ -1067,7 +1081,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const bool x4a = split && k_f16 && attention_x4a_enabled() && attention_x4a_supported(B, TOK, Nk, 64, true);
   const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK, Nk) : 0;
   const size_t x4a_bytes = x4a ? x4a_ws_bytes + (size_t)B * nt_c * 4096 + 4096 : 0;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (split ? (size_t)rows * 2048 + 4096 : 0) + (4u << 20);
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (split ? (size_t)rows * 2048 + 4096 : 0) + mlp256_part_bytes(rows, F) + (4u << 20);
   TRY(m->require(need, st));
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
@@ -1694,7 +1708,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_encoder", st);
   const int rows = B * TOK;
-  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (size_t)rows * (256 * 4 + 1024 * 2) * 4 + (8u << 20);
+  const size_t need = ((size_t)B * 1048576 * 3 + (size_t)B * 16384 * (144 + 64 * 2) + (size_t)rows * (576 + 256 * 5 + 1024 + 64) + (size_t)TOK * 256) * 4 + (size_t)rows * (256 * 4 + 1024 * 2) * 4 + 2 * mlp256_part_bytes(rows, 1024) + (8u << 20);
   TRY(m->require(need, st));
   const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
   ALLOC(c1, (size_t)B * 262144 * 4);
