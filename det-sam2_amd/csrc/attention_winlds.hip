@@ -284,13 +284,255 @@ __global__ __launch_bounds__(512) void k_attention_winlds(AttnArgs a) {
   }
 }
 
+
+// ---- two-phase form for head dims whose K and V^T planes do not fit TOGETHER (hiera_t / hiera_s: 96; 14 x 14 windows):
+// K planes resident -> all scores of a wave's 32 queries in registers (7 tiles x 16) -> exact softmax over the whole window (no
+// running maximum, no rescale) -> the SAME LDS region re-filled with the V^T planes -> P.V.  Three barriers per workgroup, none
+// inside a phase; the V rows are fetched into registers behind the score phase so that their latency falls under the softmax.
+template <int DH>
+struct Win2pGeom {
+  static constexpr int WIN = 14, NTOK = WIN * WIN, NKT = (NTOK + 31) / 32, NKP = NKT * 32;
+  static constexpr int KS = DH / 16, NT = (DH + 31) / 32;
+  static constexpr int KROW2 = DH * 2, VROW = NKP * 2;
+  static constexpr int KPLANE = NKP * KROW2, VPLANE = NT * 32 * VROW;
+  static constexpr int REGION = 2 * (KPLANE > VPLANE ? KPLANE : VPLANE);
+  static constexpr int LDS_BYTES = OFF_K + REGION;
+  static_assert(DH % 16 == 0 && LDS_BYTES <= 160 * 1024, "head dim not supported by the two-phase window kernel");
+  // K rows of 192 bytes (48 banks) repeat their bank every 4 rows, rows of 224 bytes (56 banks) every 8
+  __host__ __device__ static constexpr int ksw(int r) { return DH == 96 ? ((r >> 2) & 3) : ((r >> 3) & 1); }
+  __host__ __device__ static constexpr int vsw(int dv) { return (dv >> 2) & 3; }
+};
+
+template <int DH>
+__global__ __launch_bounds__(512) void k_attention_win2p(AttnArgs a) {
+  using G = Win2pGeom<DH>;
+  constexpr int WIN = G::WIN, NTOK = G::NTOK, NKT = G::NKT, NKP = G::NKP, KS = G::KS, NT = G::NT;
+  constexpr int KROW2 = G::KROW2, VROW = G::VROW, KPLANE = G::KPLANE, VPLANE = G::VPLANE;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int* rowtab = reinterpret_cast<int*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.y, h = blockIdx.x;
+
+  if (tid < NKP) {
+    int row = -2;
+    if (tid < NTOK) {
+      int bw = b;
+      long base = 0;
+      if (a.wins > 0) { const int img = b / a.wins; bw = b - img * a.wins; base = (long)img * a.Hk * a.Wk; }
+      const int wy = bw / a.nwx, wx = bw - wy * a.nwx;
+      const int ly = tid / WIN, lx = tid - ly * WIN;
+      const int y = wy * WIN + ly, x = wx * WIN + lx;
+      row = (y < a.Hk && x < a.Wk) ? (int)(base + (long)y * a.Wk + x) : -1;
+    }
+    rowtab[tid] = row;
+  }
+  __syncthreads();
+
+  // ---- K planes (as k_attention_winlds)
+  {
+    constexpr int CH = DH / 8, NKI = (NKP * CH + 511) / 512;
+    float kv[NKI][8];
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int it = tid + i * 512;
+      const int r = it / CH, c = it - r * CH;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kv[i][j] = 0.f;
+      if (it < NKP * CH) {
+        const int row = rowtab[r];
+        const float* p = row >= 0 ? a.k + (size_t)row * a.ldk + h * DH : ((row == -1 && a.k_pad) ? a.k_pad + h * DH : nullptr);
+        if (p) {
+          const float4 x0 = *reinterpret_cast<const float4*>(p + c * 8), x1 = *reinterpret_cast<const float4*>(p + c * 8 + 4);
+          kv[i][0] = x0.x; kv[i][1] = x0.y; kv[i][2] = x0.z; kv[i][3] = x0.w; kv[i][4] = x1.x; kv[i][5] = x1.y; kv[i][6] = x1.z; kv[i][7] = x1.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      const int it = tid + i * 512;
+      if (it < NKP * CH) {
+        const int r = it / CH, c = it - r * CH;
+        bf16x8 hi, lo;
+        split8(kv[i], hi, lo);
+        const int off = r * KROW2 + ((c ^ G::ksw(r)) << 4);
+        *reinterpret_cast<bf16x8*>(lds + OFF_K + off) = hi;
+        *reinterpret_cast<bf16x8*>(lds + OFF_K + KPLANE + off) = lo;
+      }
+    }
+  }
+  // ---- Q of this wave's 32 queries
+  const int qi = wave * 32 + l31;
+  const bool wave_active = wave * 32 < NTOK;
+  const int qrow = (wave_active && qi < NTOK) ? rowtab[qi] : -2;
+  f32x16 S[NKT];
+  {
+    bf16x8 q0[KS], q1[KS];
+    const float sc = a.scale * 1.44269504088896340736f;
+    const float* qp = qrow >= 0 ? a.q + (size_t)qrow * a.ldq + h * DH : nullptr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (qp) {
+        const float4 x0 = *reinterpret_cast<const float4*>(qp + ks * 16 + half * 8), x1 = *reinterpret_cast<const float4*>(qp + ks * 16 + half * 8 + 4);
+        v[0] = x0.x * sc; v[1] = x0.y * sc; v[2] = x0.z * sc; v[3] = x0.w * sc;
+        v[4] = x1.x * sc; v[5] = x1.y * sc; v[6] = x1.z * sc; v[7] = x1.w * sc;
+      }
+      split8(v, q0[ks], q1[ks]);
+    }
+    __syncthreads();
+    // ---- phase 1: all scores of the window (no barrier inside)
+    if (wave_active) {
+      const int ksw = G::ksw(l31);          // (row kt * 32 + l31: the swizzle bits are bits of l31)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const unsigned char* kb = lds + OFF_K + (kt * 32 + l31) * KROW2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int co = ((2 * ks + half) ^ ksw) << 4;
+          const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kb + co);
+          const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kb + KPLANE + co);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0[ks], acc, 0, 0, 0);
+        }
+        S[kt] = acc;
+      }
+    }
+  }
+  // ---- V rows of the window into registers (all threads), consumed after the softmax
+  constexpr int NVI = (DH * (NKP / 8) + 511) / 512;
+  float vv[NVI][8];
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int it = tid + i * 512;
+    const int dv = it % DH, o = it / DH;
+    const int kt = o >> 2, s = (o >> 1) & 1, hh = o & 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      vv[i][j] = 0.f;
+      if (it < DH * (NKP / 8)) {
+        const int r = 8 * s + j;
+        const int row = rowtab[kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+        const float* p = row >= 0 ? a.v + (size_t)row * a.ldv + h * DH : ((row == -1 && a.v_pad) ? a.v_pad + h * DH : nullptr);
+        if (p) vv[i][j] = p[dv];
+      }
+    }
+  }
+  // ---- exact softmax over the window's keys: maximum, exponentials (in place), sum
+  float l_tot = 1.f;
+  if (wave_active) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (kt * 32 + mfma32_row(e, half) >= NTOK) S[kt][e] = -INFINITY;   // (compile-time: only the last tile has such rows)
+        m = fmaxf(m, S[kt][e]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        S[kt][e] = __builtin_amdgcn_exp2f(S[kt][e] - m);
+        l += S[kt][e];
+      }
+    l_tot = l + __shfl_xor(l, 32);
+  }
+  __syncthreads();   // every wave is done with the K planes
+  // ---- V^T planes into the same region
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int it = tid + i * 512;
+    if (it < DH * (NKP / 8)) {
+      const int dv = it % DH, o = it / DH;
+      bf16x8 hi, lo;
+      split8(vv[i], hi, lo);
+      const int off = dv * VROW + ((o ^ G::vsw(dv)) << 4);
+      *reinterpret_cast<bf16x8*>(lds + OFF_K + off) = hi;
+      *reinterpret_cast<bf16x8*>(lds + OFF_K + VPLANE + off) = lo;
+    }
+  }
+  __syncthreads();
+  if (!wave_active) return;   // (whole waves only: the MFMAs below want every lane of the wave)
+
+  // ---- phase 2: O^T = V^T P^T
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    bf16x8 pb0[2], pb1[2];
+    float p[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) p[e] = S[kt][e];
+    split8(p, pb0[0], pb1[0]);
+    split8(p + 8, pb0[1], pb1[1]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int dvr = t * 32 + l31 < DH ? t * 32 + l31 : t * 32 + l31 - 32;
+      const unsigned char* vb = lds + OFF_K + dvr * VROW;
+      const int vsw = G::vsw(dvr);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int co = ((kt * 4 + s * 2 + half) ^ vsw) << 4;
+        const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vb + co);
+        const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vb + VPLANE + co);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pb0[s], o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb1[s], o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pb0[s], o[t], 0, 0, 0);
+      }
+    }
+  }
+  const float inv = 1.f / l_tot;
+  if (qrow < 0) return;   // pad tokens of a border window and the slots beyond the 196th token have no output row
+  const size_t orow = (size_t)qrow;
+  if (a.o_hi) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int dv = t * 32 + 8 * k + 4 * half;
+        if (dv < DH) {
+#pragma clang fp contract(off)
+          const float v0 = o[t][4 * k] * inv, v1 = o[t][4 * k + 1] * inv, v2 = o[t][4 * k + 2] * inv, v3 = o[t][4 * k + 3] * inv;
+          uint2 hh, ll;
+          hh.x = cvt_pk_bf16(v0, v1);
+          hh.y = cvt_pk_bf16(v2, v3);
+          ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
+          ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+          *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + h * DH + dv) = hh;
+          *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + h * DH + dv) = ll;
+        }
+      }
+  } else {
+    float* op = a.o + orow * a.ldo + h * DH;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int dv = t * 32 + 8 * k + 4 * half;
+        if (dv < DH)
+          *reinterpret_cast<float4*>(op + dv) = make_float4(o[t][4 * k] * inv, o[t][4 * k + 1] * inv, o[t][4 * k + 2] * inv, o[t][4 * k + 3] * inv);
+      }
+  }
+}
+
 }  // namespace
 
 // 16 x 16 (hiera_l stage 3) or 14 x 14 windows of one or several images, queries and keys on the same grid, head dim 72;
 // DS2_ATTN_WINLDS=0 keeps the general kernel
 bool attention_winlds_supported(const AttnArgs& a) {
   static const bool off = [] { const char* e = getenv("DS2_ATTN_WINLDS"); return e && atoi(e) == 0; }();
-  return !off && a.D == D && a.DV == D && (a.win_q == 16 || a.win_q == 14) && a.win_k == a.win_q && a.Lq == a.win_q * a.win_q && a.Lk == a.Lq &&
+  const bool one_phase = a.D == D && (a.win_q == 16 || a.win_q == 14), two_phase = a.D == 96 && a.win_q == 14;
+  return !off && a.DV == a.D && (one_phase || two_phase) && a.win_k == a.win_q && a.Lq == a.win_q * a.win_q && a.Lk == a.Lq &&
          a.Hq == a.Hk && a.Wq == a.Wk &&
          a.nwx > 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && (a.o_hi ? a.ldop % 4 == 0 : a.ldo % 4 == 0) && a.heads <= 65535 &&
          a.batch <= 65535;
@@ -302,9 +544,11 @@ int launch_attention_winlds(const AttnArgs& a, hipStream_t st) {
   if (!attr_done) {
     DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_winlds<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_winlds<14>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention_win2p<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  if (a.win_q == 16) hipLaunchKernelGGL(k_attention_winlds<16>, dim3(a.heads, a.batch), dim3(512), WinGeom<16>::LDS_BYTES, st, a);
+  if (a.D == 96) hipLaunchKernelGGL(k_attention_win2p<96>, dim3(a.heads, a.batch), dim3(512), Win2pGeom<96>::LDS_BYTES, st, a);
+  else if (a.win_q == 16) hipLaunchKernelGGL(k_attention_winlds<16>, dim3(a.heads, a.batch), dim3(512), WinGeom<16>::LDS_BYTES, st, a);
   else hipLaunchKernelGGL(k_attention_winlds<14>, dim3(a.heads, a.batch), dim3(512), WinGeom<14>::LDS_BYTES, st, a);
   DS2_CHECK_LAUNCH();
   return DS2_OK;

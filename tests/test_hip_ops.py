@@ -232,6 +232,8 @@ def _window_ref(q_nat, k_nat, v_nat, kb, vb, side_q, side_k, win_q, win_k, heads
     (64, 16, 8, 72, False),
     # hiera_l stage 3: 14 x 14 windows, head dim 72 - the whole-window kernel attention_win14.hip in the split modes
     (64, 14, 8, 72, False), (28, 14, 2, 72, False),
+    # hiera_t / hiera_s stage 3: 14 x 14 windows, head dim 96 - the two-phase kernel (K planes, then V^T planes, in the same LDS)
+    (28, 14, 3, 96, False),
     # small windows (16 / 64 keys): register-only kernel attention_smallwin.hip in bf16x3 mode
     (64, 4, 4, 72, False), (64, 4, 2, 72, True), (32, 8, 2, 56, False), (64, 8, 3, 96, True), (16, 4, 1, 96, False),
     (64, 4, 2, 56, True), (64, 4, 2, 56, False), (64, 8, 2, 56, True), (64, 8, 2, 96, False), (64, 4, 3, 96, True),
