@@ -492,7 +492,9 @@ def main():
                  "sustained_note": "the fully loaded chip is POWER-limited: this kernel's own MFMA stream (real operands, nothing else) runs "
                                    "at 1.67 PFLOP/s on 256 CUs and at the nominal 2.5 on 128 (profiles/r04_mfma_power_calibration.txt); "
                                    "`peak` stays the guide's dense figure",
-                 "note": "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time INSIDE the timed "
+                 "note": "(mode bf16x3k: one 'launch' = k_x4a_qprep + k_attention_x4a + k_w8_merge<64>, ~28 + 980 + 7 us at the full bank - the "
+                         "rocprofv3 rows of the three kernels add up to avg_launch_ms) "
+                         "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time INSIDE the timed "
                          "region (with async_encode the next encoder batch shares the CUs for ~60 % of it: reads ~5 % longer than the "
                          "kernel alone, which `by_kernel` below gives); executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 "
                          "(frac <= 1/3), bf16x3k 1.0"}
