@@ -82,8 +82,9 @@ def apply_hydra_overrides(cfg, overrides):
     return dataclasses.replace(cfg, **changes) if changes else cfg
 
 
-def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode="eval", hydra_overrides_extra=[],
-                               apply_postprocessing=True, **kwargs):
+def resolve_build_cfg(config_file, hydra_overrides_extra=(), apply_postprocessing=True):
+    """The ModelCfg `build_sam2_video_predictor` builds: config file, the caller's overrides, then - as build_sam.py:124-136
+    APPENDS them after the caller's extras, and hydra lets the last override of a key win - the five postprocessing values."""
     import dataclasses
     cfg = resolve_config(config_file)
     if not apply_postprocessing:
@@ -91,7 +92,16 @@ def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode=
         # token 0 (MaskDecoder.dynamic_multimask_via_stability = False, mask_decoder.py:37), prompted masks enter the memory
         # encoder through the sigmoid (SAM2Base.binarize_mask_from_pts_for_mem_enc = False), no hole filling
         cfg = dataclasses.replace(cfg, dynamic_multimask_via_stability=False, binarize_mask_from_pts_for_mem_enc=False, fill_hole_area=0)
-    cfg = apply_hydra_overrides(cfg, hydra_overrides_extra)
+    cfg = apply_hydra_overrides(cfg, list(hydra_overrides_extra))
+    if apply_postprocessing:
+        cfg = dataclasses.replace(cfg, dynamic_multimask_via_stability=True, dynamic_multimask_stability_delta=0.05,
+                                  dynamic_multimask_stability_thresh=0.98, binarize_mask_from_pts_for_mem_enc=True, fill_hole_area=8)
+    return cfg
+
+
+def build_sam2_video_predictor(config_file, ckpt_path=None, device="cuda", mode="eval", hydra_overrides_extra=[],
+                               apply_postprocessing=True, **kwargs):
+    cfg = resolve_build_cfg(config_file, hydra_overrides_extra, apply_postprocessing)
     if mode != "eval":
         raise NotImplementedError("inference only (mode='eval')")
     dev = "cuda:0" if device in ("cuda", None) else str(device)

@@ -360,6 +360,14 @@ int heuristic_tile(const GemmSplitArgs& g) {
   // stages 1-2 (K = 144 / 288: five to nine K tiles, i.e. mostly epilogue) run 10-25 % faster persistent
   // (profiles/r02at_tile_time_s12.txt)
   if (tile == 3 && pp256 && gemm_split_pp256_supported(g) && b256 >= 256 && ncols > 128 && fits32) tile = 10;
+  // the assembly kernel with the overlapped epilogue (gemm_x4g.hip) wherever it takes the shape and fills the chip
+  // (DS2_GEMM_X4G=0: the kernels above, for A/B runs)
+  const char* x4g_e = getenv("DS2_GEMM_X4G");   // (read per call: the tests compare both paths in one process)
+  const bool x4g = !(x4g_e && atoi(x4g_e) == 0);
+  if (x4g && (tile == 3 || tile == 5 || tile == 10)) {
+    const int cfg = gemm_split_x4g_config(g, 0);
+    if (cfg != 0 && (long)(g.M / (cfg == 42 ? 256 : 128)) * (g.N / (cfg == 42 ? 128 : 192)) >= 256) tile = 11;
+  }
   return tile;
 }
 
@@ -390,6 +398,11 @@ int launch_tile_impl(const GemmSplitArgs& g_in, int tile, hipStream_t st, const 
   }
   // forced tiles (DS2_GEMM_TILE) fall back when a kernel cannot take the shape: persistent -> one-tile 256x256 -> ring
   const bool fits32 = (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32);   // 32-bit DMA offsets
+  if (tile >= 11 && tile <= 13) {   // 11: assembly kernel, its own choice of configuration; 12: 256 x 128; 13: 128 x 192
+    const int cfg = gemm_split_x4g_config(g, tile == 12 ? 42 : tile == 13 ? 23 : 0);
+    if (cfg != 0) return launch_gemm_split_x4g(g, cfg, st, kname);
+    tile = 10;
+  }
   if (tile == 10 && !(gemm_split_pp256_supported(g) && fits32)) tile = 5;
   if (tile == 5 && !fits32) tile = 3;
   if (tile == 10) { *kname = "k_gemm_split_pp256"; return launch_gemm_split_pp256(g, st); }
@@ -411,7 +424,8 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
               "gemm_split: bad dims M=%d N=%d Kp=%d lda=%d ldw=%d", g.M, g.N, g.Kp, g.lda, g.ldw);
   DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
-  static const int tile_env = [] { const char* e = getenv("DS2_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const char* tile_e = getenv("DS2_GEMM_TILE");   // (read per call: the tests force tiles in one process)
+  const int tile_env = tile_e ? atoi(tile_e) : 0;
   if (g.c_hi_f16) {   // fp16 key planes (mode bf16x3k): the K = 64 streaming kernel's epilogue is the one that writes them
     DS2_REQUIRE(gemm_split_k64_supported(g), "gemm_split: fp16 hi planes are produced by the K = 64 kernel only (M=%d N=%d Kp=%d)", g.M, g.N, g.Kp);
   } else

@@ -128,6 +128,10 @@ int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 2
 int launch_gemm_split_d256(const GemmSplitArgs& g, hipStream_t st);         // 256x256, two-stage LDS-DMA, one barrier per K tile
 int launch_gemm_split_pp256(const GemmSplitArgs& g, hipStream_t st);        // persistent p256 with loader / storer waves (no residual)
 bool gemm_split_pp256_supported(const GemmSplitArgs& g);
+// gemm_x4g.hip: assembly persistent kernel, epilogue of tile i under the main loop of tile i+1 (cfg 42: 256x128, 23: 128x192, 0: auto)
+int gemm_split_x4g_config(const GemmSplitArgs& g, int cfg);                 // configuration that can take the GEMM, 0 if none
+bool gemm_split_x4g_supported(const GemmSplitArgs& g);
+int launch_gemm_split_x4g(const GemmSplitArgs& g, int cfg, hipStream_t st, const char** kname);
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st,

@@ -1427,10 +1427,10 @@ extern "C" int ds2_prompt_encoder(ds2_model* m, int32_t B, const float* point_co
                                   int32_t pad, const float* mask_inputs, float* sparse, float* dense, void* stream) {
   DS2_REQUIRE(m && m->finalized && B > 0 && P >= 0 && P <= 256 && (pad == 0 || pad == 1) && (P == 0 || (point_coords && point_labels)),
               "ds2_prompt_encoder: bad argument");
-  DS2_REQUIRE(P + pad == 0 || sparse, "ds2_prompt_encoder: sparse output missing");
+  const int Ns = P + (P > 0 ? pad : 0);      // no points: no padding point either (prompt_encoder.py:155-160) - an empty [B,0,256]
+  DS2_REQUIRE(Ns == 0 || sparse, "ds2_prompt_encoder: sparse output missing");   // sparse tensor: mask-only / empty prompts
   ModelScope _dg(m);
   hipStream_t st = (hipStream_t)stream;
-  const int Ns = P + (P > 0 ? pad : 0);      // no points: no padding point either (prompt_encoder.py:155-160)
   TRY(m->require(((size_t)B * (6 + Ns) * 256 + (size_t)TOK * 256) * 4 + (1u << 20), st));
   if (Ns > 0) {
     ALLOC(tokens, (size_t)B * (6 + Ns) * 256);
@@ -1827,6 +1827,31 @@ extern "C" int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int3
                            const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
                            int32_t ldr, int32_t r_mod, void* stream) {
   return gemm((hipStream_t)stream, M, N, K, A, lda, W, ldw, bias, C, ldc, act, R, ldr, r_mod, gamma);
+}
+// C = act(A W^T + bias) returned as the consumer GEMM's operand planes (bf16 hi / lo, [M, round32(N)]) - what the Hiera MLP's first
+// Linear layer writes (GemmSplitArgs::C_hi / C_lo); split modes only
+extern "C" int ds2_op_gemm_planes(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
+                                  const float* bias, int32_t act, uint16_t* out_hi, uint16_t* out_lo, void* stream) {
+  DS2_REQUIRE(ds2_split_mode() && A && W && out_hi && out_lo && M > 0 && N > 0 && K > 0 && K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0,
+              "ds2_op_gemm_planes: bad argument (split modes only)");
+  hipStream_t st = (hipStream_t)stream;
+  const int Kp = round32i(K), ldcp = round32i(N);
+  const size_t ab = (size_t)M * Kp * 2, wb = (size_t)N * Kp * 2;
+  TRY(g_gemm_ctx.require(2 * ab + 2 * wb + 1024, st));
+  unsigned short* ah = reinterpret_cast<unsigned short*>(g_gemm_ctx.scratch);
+  unsigned short* al = ah + (size_t)M * Kp;
+  unsigned short* wh = al + (size_t)M * Kp;
+  unsigned short* wl = wh + (size_t)N * Kp;
+  TRY(launch_split_rows(A, lda, M, K, ah, al, Kp, st));
+  TRY(launch_split_rows(W, ldw, N, K, wh, wl, Kp, st));
+  if (ldcp != N) {
+    DS2_CHECK_HIP(hipMemsetAsync(out_hi, 0, (size_t)M * ldcp * 2, st));
+    DS2_CHECK_HIP(hipMemsetAsync(out_lo, 0, (size_t)M * ldcp * 2, st));
+  }
+  GemmSplitArgs g{};
+  g.M = M; g.N = N; g.Kp = Kp; g.A_hi = ah; g.A_lo = al; g.lda = Kp; g.W_hi = wh; g.W_lo = wl; g.ldw = Kp;
+  g.bias = bias; g.act = act; g.C_hi = out_hi; g.C_lo = out_lo; g.ldcp = ldcp;
+  return launch_gemm_split(g, st);
 }
 extern "C" int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
                                    const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,

@@ -55,8 +55,9 @@ class _FolderFrames(Sequence):
         self.folder, self.names = folder_path, []
         for name in sorted(f for f in os.listdir(folder_path) if f.endswith((".png", ".jpg", ".jpeg"))):
             try:
-                with Image.open(os.path.join(folder_path, name)):       # header only
-                    self.names.append(name)
+                with Image.open(os.path.join(folder_path, name)) as im:
+                    im.load()       # full decode: a truncated file with a valid header is skipped here, as the reference skips
+                    self.names.append(name)                             # whatever cv2.imread cannot decode (det_sam2_RT.py:507-524)
             except Exception:
                 print(f"--- cannot read frame file: {os.path.join(folder_path, name)}")
 

@@ -87,6 +87,18 @@ class HipOps:
                                          _p(R), 0 if R is None else R.stride(0), r_mod, self._stream()), "ds2_op_gemm")
         return out
 
+    def op_gemm_planes(self, A, W, bias=None, act=0):
+        """act(A W^T + bias) as bf16 operand planes (ds2_op_gemm_planes): -> (hi, lo) int16 tensors [M, round32(N)]."""
+        import torch
+        M, K = A.shape
+        N = W.shape[0]
+        ld = (N + 31) // 32 * 32
+        hi = torch.empty(M, ld, dtype=torch.int16, device=self.device)
+        lo = torch.empty(M, ld, dtype=torch.int16, device=self.device)
+        _capi.check(self.lib.ds2_op_gemm_planes(M, N, K, _p(A), A.stride(0), _p(W), W.stride(0), _p(bias), act, _p(hi), _p(lo),
+                                                self._stream()), "ds2_op_gemm_planes")
+        return hi, lo
+
     def op_linear_small(self, A, W, bias=None, act=0, gamma=None, R=None, r_mod=0):
         """Few-row Linear layer in exact fp32 (ds2_op_linear_small): A [M<=128,K], W [N,K] -> [M,N]."""
         M, K = A.shape

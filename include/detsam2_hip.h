@@ -252,6 +252,11 @@ int ds2_profile_tags(char* buf, int64_t cap);
 int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
                 const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,
                 int32_t ldr, int32_t r_mod, void* stream);
+/* The same GEMM with the result returned as bf16 operand planes (hi, lo: [M, round-up-32(N)] uint16 each, pad columns zero) instead of
+ * fp32 - the form the first Linear layer of the Hiera MLP hands to the second (hieradet.py:160-166 via sam2_utils.py MLP); split
+ * arithmetic modes only. */
+int ds2_op_gemm_planes(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
+                       const float* bias, int32_t act, uint16_t* out_hi, uint16_t* out_lo, void* stream);
 /* fused two-layer MLP of width 256: out = (act(X W1^T + b1) W2^T + b2) * gamma + R with X [rows,256], W1 [H,256], W2 [256,H],
  * R / out [rows,256]; b1, b2, gamma, R may be NULL.  The kernel behind MemoryAttentionLayer's FFN (memory_attention.py:93-98)
  * and CXBlock's pwconv1 / pwconv2 (memory_encoder.py:104-117) in the bf16x3 modes. */

@@ -418,6 +418,7 @@ def e2e_correct(name="sam2.1_hiera_t"):
 HELDOUT = {            # variant -> (weight_seed, logit_scale, structured frames)
     "s1": (1, 1.0, True),
     "lm": (1, 1.0 / 30.0, True),
+    "s2": (2, 1.0, True),              # round 5: a second structured-frame seed for the fixtures at the measured shape / config 3's model
 }
 
 

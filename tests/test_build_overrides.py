@@ -37,3 +37,15 @@ def test_decoder_stability_override_maps_onto_cfg():
     cfg = resolve_config("sam2.1_hiera_t")
     got = apply_hydra_overrides(cfg, ["++model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability=false"])
     assert cfg.dynamic_multimask_via_stability and not got.dynamic_multimask_via_stability
+
+
+def test_postprocessing_overrides_win_over_the_callers_extras():
+    """build_sam.py:124-136 appends the five postprocessing overrides AFTER hydra_overrides_extra: with apply_postprocessing they
+    win; without it the caller's values (on top of the constructor defaults) stand."""
+    from det_sam2_amd.build_sam import resolve_build_cfg
+    extras = ["++model.sam_mask_decoder_extra_args.dynamic_multimask_via_stability=false", "++model.fill_hole_area=0",
+              "++model.sam_mask_decoder_extra_args.dynamic_multimask_stability_thresh=0.9", "model.max_cond_frames_in_attn=4"]
+    on = resolve_build_cfg("sam2.1_hiera_t", extras, True)
+    assert (on.dynamic_multimask_via_stability, on.fill_hole_area, on.dynamic_multimask_stability_thresh, on.max_cond_frames_in_attn) == (True, 8, 0.98, 4)
+    off = resolve_build_cfg("sam2.1_hiera_t", extras, False)
+    assert (off.dynamic_multimask_via_stability, off.fill_hole_area, off.dynamic_multimask_stability_thresh, off.binarize_mask_from_pts_for_mem_enc) == (False, 0, 0.9, False)

@@ -78,6 +78,13 @@ def test_modules_match_reference_fixtures(mods, prec, golden_dir):
     # embeddings the (coords, labels = [2, 3]) point form gives before its padding token
     spb, _ = pe_mod(points=None, boxes=x["coords"].reshape(2, 4), masks=None)
     assert tuple(spb.shape) == (2, 2, 256) and torch.equal(spb, sp[:, :2])
+    # no points and no boxes: an EMPTY sparse tensor [B,0,256] + the dense embedding, as the reference returns
+    # (prompt_encoder.py:155-171) - with a mask prompt the mask_downscaling output, without one the no_mask_embed broadcast
+    sp0, de0 = pe_mod(points=None, boxes=None, masks=x["mask_prompt"])
+    assert tuple(sp0.shape) == (2, 0, 256) and torch.equal(de0, de)
+    sp1, de1 = pe_mod(points=None, boxes=None, masks=None)
+    assert tuple(sp1.shape) == (1, 0, 256) and tuple(de1.shape) == (1, 256, 64, 64)
+    assert torch.equal(de1[0], pe_mod(points=(x["coords"], x["labels"]), boxes=None, masks=None)[1][0])
     # ---- MaskDecoder.forward (mask_decoder.py:105-161) on the prompt encoder's own outputs, both multimask settings
     s_, d_ = pe_mod(points=(x["coords"], x["labels"]), boxes=None, masks=None)
     for mm in (True, False):

@@ -1,0 +1,752 @@
+#!/usr/bin/env python
+"""Generator of det-sam2_amd/csrc/gemm_x4g_body_<cfg>_<epi>.inc: the persistent bf16x3 GEMM whose EPILOGUE OF TILE i RUNS UNDER THE
+MAIN LOOP OF TILE i+1, as ONE inline-assembly statement with registers allocated by hand.
+
+Why (DESIGN.md "GEMM findings" 8): in k_gemm_split_pp256 the GELU / split / store epilogue of a 256x256 tile is as
+long as its 18-K-tile main loop and the matrix pipe idles through it; the 8-wave kernels are at 228 of 256 registers, so a second
+accumulator set does not fit.  Here: 4 waves, ONE per SIMD, 512 registers each.
+
+  wave tile   (32 MBW) x (32 NBW) blocks of 32x32; workgroup tile (64 MBW) x (64 NBW): cfg 42 -> 256x128, cfg 23 -> 128x192
+  a[0:16 NB)      live accumulators of tile i+1 (NB = MBW NBW blocks, v_mfma_f32_32x32x16_bf16, 3 terms per product, the order of
+                  every other tile kernel: a_lo w_hi, a_hi w_lo, a_hi w_hi per 16-deep sub-step -> bit-identical results)
+  a[128:128+16 NB) PARKED accumulators of tile i: copied there (v_accvgpr_mov) block by block during the last sub-step of tile i and
+                  drained - bias, GELU, bf16 split, lane-pair exchange, stores - as fillers behind the MFMAs of the first 16 K tiles
+                  of tile i+1 (one of 16 drain steps per K tile; K >= 17 * 32)
+  LDS             3-stage ring of 32-deep K tiles {A hi, A lo, W hi, W lo}, rows of 64 B, 16-byte chunks XOR-swizzled by
+                  (row >> 2) & 3 (the pp256 image), filled by LDS-DMA two K tiles ahead; ONE s_barrier per K tile placed after 3/4 of
+                  its MFMAs; the fragments of the next K tile's first sub-step are read behind the last quarter
+  epilogue forms  e1: C = acc + bias (fp32);  e2: planes(gelu(acc + bias)) (bf16 hi / lo, pairs of columns exchanged between
+                  neighbouring lanes so that a store writes 64-byte row segments);  e3: C = acc + bias + R (fp32, C may alias R)
+
+Instruction stream per wave: prologue, then K-tile bodies {D0..D15 (with drain step d), plain, last (parks)} and a tail (the drain of
+the workgroup's last tile, not overlapped).  Every wait is COUNTED: vmcnt by simulating the in-order VMEM stream (LDS-DMA, stores,
+residual / bias loads), lgkmcnt by simulating the LDS stream.  `lint()` checks the manual hazards (trans -> use, VALU vcc / SGPR ->
+mask, DPP source, m0 -> LDS-DMA, readfirstlane -> SALU).
+
+usage: gen_gemm_x4g.py <out.inc> <cfg: 42|23> <epi: e1|e2|e3> [flags: nodrain nostore nodma ...]  (flags: timing experiments only)
+"""
+import os
+import sys
+
+# ------------------------------------------------------------------------------------------------ configuration
+OUT, CFG, EPI = sys.argv[1], sys.argv[2], sys.argv[3]
+FLAGS = set(sys.argv[4:])
+MBW, NBW = int(CFG[0]), int(CFG[1])
+NB = MBW * NBW
+TM, TN = 64 * MBW, 64 * NBW
+PA_B, PW_B = TM * 64, TN * 64                 # bytes of one plane of a stage
+STAGE = 2 * (PA_B + PW_B)
+TL_OFF = 3 * STAGE                            # tile list (32-byte entries) behind the ring
+NSLOT = 6 * NB                                # MFMAs per K tile
+BAR_SLOT = (NSLOT * 3) // 4
+NDRAIN = 16                                   # drain steps = K tiles that carry one
+RP = MBW // 2                                 # row pairs (of 8 per block) per drain step
+STEPS_PER_MB = 8 // RP
+PA_N, PW_N = MBW, NBW                         # LDS-DMA pieces per plane and wave (16 rows x 64 B each)
+NP = 2 * (PA_N + PW_N)                        # pieces per wave and K tile
+ISSUE = int(os.environ.get("X4G_ISSUE", 4))
+GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
+
+# VGPR map (v0..v31 are left to the compiler)
+FX, FY = 32, 88                               # fragment sets: ah[mb] +4mb, al[mb] +16+4mb, wh[nb] +32+4nb, wl[nb] +44+4nb
+RA0, RA1, RW0, RW1 = 144, 145, 146, 147       # LDS read bases of the current stage (sub-step 0 / 1)
+DOA, DOW = 148, 152                           # LDS-DMA lane offsets: A pieces (<= 4), W pieces (<= 3)
+TLA, TL = 155, 156                            # tile-list address; entry (8 dwords)
+VOC, VOR, VOP, SEL = 164, 165, 166, 167       # lane offsets of C / R / plane stores, v_perm selector of the lane-pair exchange
+BIAS, KC2, L31, HALF = 168, 171, 172, 173
+T0, NTMP = 176, 60                            # temporaries 176..235
+# SGPR map (s32 / s33 and s96.. are reserved by the compiler; s0..s15 are left to it)
+S_AH, S_AL, S_WH, S_WL, S_BIAS, S_C, S_R, S_CH, S_CL = 36, 38, 40, 42, 44, 46, 48, 50, 52
+S_LDA, S_LDW, S_LDC, S_LDR, S_LDCP, S_NK = 54, 55, 56, 57, 58, 59
+P_AH, P_AL, P_WH, P_WL = 60, 62, 64, 66       # DMA cursor: source bases of its K tile
+S_KD, S_DDST, S_KC, S_TLEFT, S_RDELTA, S_NKM1, S_LEND, S_CST = 68, 69, 70, 71, 72, 73, 74, 75
+W_C, W_R, W_P, W_B = 76, 77, 78, 79           # this wave's offsets inside a tile (bytes)
+CUR, NXT = 80, 84                             # tile entries {c_off, r_off, p_off, b_off} of the compute / DMA tile
+D_C, D_R, D_H, D_L = 88, 90, 92, 94           # drain bases (64-bit) of the parked tile (s90..s95 double as prologue temporaries)
+ROWA, ROWB, ROWC, ROWD = 16, 18, 20, 22       # row address pairs
+ST = 24                                       # scalar temporaries 24..29
+G_C0, G_C1 = 30, 31                           # GELU constants
+S_STG, S_NSTG2 = 34, 35                       # STAGE, -2 STAGE
+S_WDA, S_WDW, S_DSTA, S_DSTW = 12, 13, 14, 15  # this wave's row offset inside a stage's A / W planes; DMA destinations of this K tile
+
+out = []
+lint_off = [False]
+
+
+def e(s):
+    out.append(s)
+
+
+def vr(b, n=1):
+    return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
+
+
+def ar(b, n=1):
+    return f"a{b}" if n == 1 else f"a[{b}:{b + n - 1}]"
+
+
+def sr(b, n=1):
+    return f"s{b}" if n == 1 else f"s[{b}:{b + n - 1}]"
+
+
+def frag(base, kind, i):
+    return vr(base + {"ah": 0, "al": 16, "wh": 32, "wl": 44}[kind] + 4 * i, 4)
+
+
+def acc(b):
+    return ar(16 * b, 16)
+
+
+def cost(ins):
+    op = ins.split()[0]
+    if op in ("v_exp_f32", "v_rcp_f32"):
+        return 8
+    if op == "s_nop":
+        return int(ins.split()[1]) + 1
+    if op.endswith(":"):
+        return 0
+    return ISSUE
+
+
+# ------------------------------------------------------------------------------------------------ counted waits
+class Stream:
+    """in-order completion stream (vmcnt / lgkmcnt): ops are appended by name; need(name) returns the s_waitcnt count that guarantees
+    completion of the LAST op of that name (None if already known complete)"""
+
+    def __init__(self, carry=()):
+        self.ops = list(carry)
+        self.done = 0
+
+    def issue(self, name):
+        self.ops.append(name)
+
+    def need(self, name):
+        idx = max(i for i, n in enumerate(self.ops) if n == name)
+        if idx < self.done:
+            return None
+        self.done = idx + 1
+        return len(self.ops) - idx - 1
+
+    def wait_all(self):
+        self.done = len(self.ops)
+
+
+# canonical LDS sequence issued behind the barrier of every body (and by the prologue): the tile-list entry, then the fragments of
+# the next K tile's sub-step 0 in the order its MFMAs want them
+def x_order():
+    o = []
+    for mb in range(MBW):
+        o.append(("al", mb))
+        if mb == 0:
+            o += [("wh", nb) for nb in range(NBW)]
+    o += [("ah", mb) for mb in range(MBW)] + [("wl", nb) for nb in range(NBW)]
+    return o
+
+
+def y_order():
+    return x_order()
+
+
+POST_BAR = ["TL0", "TL1"] + [f"X{k}{i}" for k, i in x_order()]
+
+
+def read_ins(setbase, kind, i, sub):
+    base = {("a", 0): RA0, ("a", 1): RA1, ("w", 0): RW0, ("w", 1): RW1}[(kind[0], sub)]
+    plane = 1 if kind[1] == "l" else 0
+    off = i * 2048 + plane * (PA_B if kind[0] == "a" else PW_B)
+    return f"ds_read_b128 {frag(setbase, kind, i)}, {vr(base)} offset:{off}"
+
+
+# ------------------------------------------------------------------------------------------------ pieces of a body
+def dma_pieces():
+    """LDS-DMA of the DMA cursor's K tile into stage S_DDST: NP (m0 write, copy) pairs"""
+    L = []
+    for plane, (pa, pw) in enumerate(((P_AH, P_WH), (P_AL, P_WL))):
+        for j in range(PA_N):
+            L.append([f"s_add_u32 m0, {sr(S_DSTA)}, {plane * PA_B + j * 1024}", f"global_load_lds_dwordx4 {vr(DOA + j)}, {sr(pa, 2)}"])
+        for j in range(PW_N):
+            L.append([f"s_add_u32 m0, {sr(S_DSTW)}, {2 * PA_B + plane * PW_B + j * 1024}", f"global_load_lds_dwordx4 {vr(DOW + j)}, {sr(pw, 2)}"])
+    return L
+
+
+def dma_dst_setup():
+    """destinations of this wave's pieces in stage S_DDST (wave w stages rows [16 MBW w, +16 MBW) of A and [16 NBW w, ..) of W)"""
+    return [f"s_add_u32 {sr(S_DSTA)}, {sr(S_DDST)}, {sr(S_WDA)}", f"s_add_u32 {sr(S_DSTW)}, {sr(S_DDST)}, {sr(S_WDW)}"]
+
+
+def advance_block(n):
+    """DMA cursor -> next K tile (wrap: next tile of the list, whose entry sits in TL since the previous body) + stage rotation"""
+    L = [f"s_add_u32 {sr(S_KD)}, {sr(S_KD)}, 1", f"s_cmp_lt_u32 {sr(S_KD)}, {sr(S_NK)}", f"s_cbranch_scc1 L_adv_{n}",
+         f"s_mov_b32 {sr(S_KD)}, 0"]
+    for i in range(6):
+        L.append(f"v_readfirstlane_b32 {sr(ST + i if i < 2 else NXT + i - 2)}, {vr(TL + i)}")
+    L += ["s_nop 4",
+          f"s_add_u32 {sr(P_AH)}, {sr(S_AH)}, {sr(ST)}", f"s_addc_u32 {sr(P_AH + 1)}, {sr(S_AH + 1)}, 0",
+          f"s_add_u32 {sr(P_AL)}, {sr(S_AL)}, {sr(ST)}", f"s_addc_u32 {sr(P_AL + 1)}, {sr(S_AL + 1)}, 0",
+          f"s_add_u32 {sr(P_WH)}, {sr(S_WH)}, {sr(ST + 1)}", f"s_addc_u32 {sr(P_WH + 1)}, {sr(S_WH + 1)}, 0",
+          f"s_add_u32 {sr(P_WL)}, {sr(S_WL)}, {sr(ST + 1)}", f"s_addc_u32 {sr(P_WL + 1)}, {sr(S_WL + 1)}, 0",
+          f"v_add_u32 {vr(TLA)}, 32, {vr(TLA)}", f"s_branch L_advd_{n}", f"L_adv_{n}:"]
+    for p in (P_AH, P_AL, P_WH, P_WL):
+        L += [f"s_add_u32 {sr(p)}, {sr(p)}, 64", f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0"]
+    L.append(f"L_advd_{n}:")
+    return L
+
+
+def rotate_dma_dst():
+    return [f"s_add_u32 {sr(S_DDST)}, {sr(S_DDST)}, {STAGE}", f"s_cmp_eq_u32 {sr(S_DDST)}, {sr(S_LEND)}",
+            f"s_cselect_b32 {sr(S_DDST)}, %[ldsb], {sr(S_DDST)}"]
+
+
+def rotate_read_delta():
+    return [f"s_add_u32 {sr(S_CST)}, {sr(S_CST)}, 1", f"s_cmp_eq_u32 {sr(S_CST)}, 3", f"s_cselect_b32 {sr(S_CST)}, 0, {sr(S_CST)}",
+            f"s_cselect_b32 {sr(S_RDELTA)}, {sr(S_NSTG2)}, {sr(S_STG)}"]
+
+
+# ------------------------------------------------------------------------------------------------ drain steps
+def row_of(mb, r):
+    return mb * 32 + (r & 3) + 8 * (r >> 2)
+
+
+def park(mb, nb, r):
+    return ar(128 + (mb * NBW + nb) * 16 + r)
+
+
+class Drain:
+    """the filler stream of drain step d of the parked tile.  Items: instruction strings; ("vm", ins, name) VMEM ops; ("needvm", name)"""
+
+    def __init__(self, d):
+        self.F = []
+        self.tix = 0
+        mb, sub = divmod(d, STEPS_PER_MB)
+        pairs = [sub * RP + i for i in range(RP)]
+        getattr(self, EPI)(mb, pairs)
+
+    def tmp(self, n):
+        if self.tix + n > NTMP:
+            self.tix = 0
+        b = T0 + self.tix
+        self.tix += n
+        return b
+
+    def add(self, s):
+        self.F.append(s)
+
+    def rowaddr(self, pair, base, row, ld, esz):
+        self.add(f"s_mul_i32 {sr(ST + 4)}, {sr(ld)}, {row * esz}")
+        self.add(f"s_add_u32 {sr(pair)}, {sr(base)}, {sr(ST + 4)}")
+        self.add(f"s_addc_u32 {sr(pair + 1)}, {sr(base + 1)}, 0")
+
+    def store(self, voff, data, pair, off, name):
+        if "nostore" in FLAGS:
+            return
+        self.F.append(("vm", f"global_store_dword {vr(voff)}, {vr(data)}, {sr(pair, 2)} offset:{off}", name))
+
+    def e1(self, mb, pairs):
+        k = 0
+        for q in pairs:
+            for r in (2 * q, 2 * q + 1):
+                pair = (ROWA, ROWB, ROWC, ROWD)[k % 4]
+                k += 1
+                self.rowaddr(pair, D_C, row_of(mb, r), S_LDC, 4)
+                for nb in range(NBW):
+                    t = self.tmp(1)
+                    self.add(f"v_accvgpr_read_b32 {vr(t)}, {park(mb, nb, r)}")
+                    self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(BIAS + nb)}")
+                    self.store(VOC, t, pair, nb * 128, "st")
+
+    def e3(self, mb, pairs):
+        rows = [(q, r) for q in pairs for r in (2 * q, 2 * q + 1)]
+        rt = {}
+        for i, (q, r) in enumerate(rows):                     # residual loads first (their row pairs are not reused before the stores)
+            self.rowaddr(ROWC if i % 2 == 0 else ROWD, D_R, row_of(mb, r), S_LDR, 4)
+            for nb in range(NBW):
+                t = self.tmp(1)
+                rt[(r, nb)] = t
+                self.F.append(("vm", f"global_load_dword {vr(t)}, {vr(VOR)}, {sr(ROWC if i % 2 == 0 else ROWD, 2)} offset:{nb * 128}", f"R{r}_{nb}"))
+        for i, (q, r) in enumerate(rows):
+            pair = ROWA if i % 2 == 0 else ROWB
+            self.rowaddr(pair, D_C, row_of(mb, r), S_LDC, 4)
+            for nb in range(NBW):
+                t = self.tmp(1)
+                self.add(f"v_accvgpr_read_b32 {vr(t)}, {park(mb, nb, r)}")
+                self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(BIAS + nb)}")
+                self.F.append(("needvm", f"R{r}_{nb}"))
+                self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(rt[(r, nb)])}")
+                self.store(VOC, t, pair, nb * 128, "st")
+
+    def e2(self, mb, pairs):
+        for i, q in enumerate(pairs):
+            ph, pl = (ROWA, ROWB) if i % 2 == 0 else (ROWC, ROWD)
+            self.rowaddr(ph, D_H, row_of(mb, 2 * q), S_LDCP, 2)
+            self.rowaddr(pl, D_L, row_of(mb, 2 * q), S_LDCP, 2)
+            for nb in range(NBW):
+                b = self.tmp(20)
+                x, z, t, p, ee, qq = ([b + 2 * j, b + 2 * j + 1] for j in range(6))      # [chain A, chain B]
+                h, l, f0, f1, hn, ln, oh, ol = (b + 12 + j for j in range(8))
+                A = self.add
+                msk = ("vcc", sr(ST + 2, 2))
+                for c, r in enumerate((2 * q, 2 * q + 1)):
+                    A(f"v_accvgpr_read_b32 {vr(x[c])}, {park(mb, nb, r)}")
+                for c in range(2):
+                    A(f"v_add_f32 {vr(x[c])}, {vr(x[c])}, {vr(BIAS + nb)}")
+                if "nogelu" not in FLAGS:
+                    for c in range(2):
+                        A(f"v_mul_f32_e64 {vr(z[c])}, |{vr(x[c])}|, {sr(G_C0)}")
+                    for c in range(2):
+                        A(f"v_fma_f32 {vr(t[c])}, {vr(z[c])}, {sr(G_C1)}, 1.0")
+                    for c in range(2):
+                        A(f"v_rcp_f32 {vr(t[c])}, {vr(t[c])}")
+                    for c in range(2):
+                        A(f"v_mul_f32_e64 {vr(ee[c])}, {vr(z[c])}, -{vr(z[c])}")
+                    for c in range(2):
+                        A(f"v_fmamk_f32 {vr(p[c])}, {vr(t[c])}, 0x3f87dc22, {vr(KC2)}")
+                    for c in range(2):
+                        A(f"v_mul_f32 {vr(ee[c])}, 0x3fb8aa3b, {vr(ee[c])}")
+                    for c in range(2):
+                        A(f"v_fmaak_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}, 0x3fb5f0e3")
+                    for c in range(2):
+                        A(f"v_exp_f32 {vr(ee[c])}, {vr(ee[c])}")
+                    for c in range(2):
+                        A(f"v_fmaak_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}, 0xbe91a98e")
+                    for c in range(2):
+                        A(f"v_fmaak_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}, 0x3e827906")
+                    for c in range(2):
+                        A(f"v_mul_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}")
+                    for c in range(2):
+                        A(f"v_mul_f32 {vr(p[c])}, 0.5, {vr(p[c])}")
+                    for c in range(2):
+                        A(f"v_mul_f32 {vr(p[c])}, {vr(ee[c])}, {vr(p[c])}")
+                    for c in range(2):
+                        A(f"v_cmp_le_f32_e64 {msk[c]}, 0, {vr(x[c])}")
+                    for c in range(2):
+                        A(f"v_sub_f32 {vr(qq[c])}, 1.0, {vr(p[c])}")
+                    for c in range(2):
+                        A(f"v_cndmask_b32_e64 {vr(p[c])}, {vr(p[c])}, {vr(qq[c])}, {msk[c]}")
+                    for c in range(2):
+                        A(f"v_mul_f32 {vr(x[c])}, {vr(x[c])}, {vr(p[c])}")
+                # bf16 hi / lo of the two rows, columns paired between neighbouring lanes (module docstring)
+                A(f"v_cvt_pk_bf16_f32 {vr(h)}, {vr(x[0])}, {vr(x[1])}")
+                A(f"v_lshlrev_b32 {vr(f0)}, 16, {vr(h)}")
+                A(f"v_and_b32 {vr(f1)}, 0xffff0000, {vr(h)}")
+                A(f"v_sub_f32 {vr(f0)}, {vr(x[0])}, {vr(f0)}")
+                A(f"v_sub_f32 {vr(f1)}, {vr(x[1])}, {vr(f1)}")
+                A(f"v_cvt_pk_bf16_f32 {vr(l)}, {vr(f0)}, {vr(f1)}")
+                A(f"v_mov_b32_dpp {vr(hn)}, {vr(h)} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                A(f"v_perm_b32 {vr(oh)}, {vr(hn)}, {vr(h)}, {vr(SEL)}")
+                self.store(VOP, oh, ph, nb * 64, "st")
+                A(f"v_mov_b32_dpp {vr(ln)}, {vr(l)} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                A(f"v_perm_b32 {vr(ol)}, {vr(ln)}, {vr(l)}, {vr(SEL)}")
+                self.store(VOP, ol, pl, nb * 64, "st")
+
+
+def drain_items(d):
+    if "nodrain" in FLAGS:
+        return []
+    return Drain(d).F
+
+
+# ------------------------------------------------------------------------------------------------ one K-tile body
+body_n = [0]
+
+
+def body(kind, d=None, pred_post=0):
+    """kind: 'plain' | 'drain' (step d) | 'last'.  pred_post: VMEM ops the predecessor issued after its last DMA piece (minimum over
+    the possible predecessors).  Returns the number of VMEM ops this body issues after its last DMA piece."""
+    n = body_n[0]
+    body_n[0] += 1
+    lg = Stream(POST_BAR)
+    vm_issued = [0]          # VMEM ops of this body, program order
+    vm_names = []
+    dma_last = [None]
+
+    def emit_vm(ins, name):
+        e(ins)
+        vm_names.append(name)
+        vm_issued[0] += 1
+
+    def need_lg(name):
+        c = lg.need(name)
+        if c is not None:
+            e(f"s_waitcnt lgkmcnt({min(c, 15)})")
+
+    # --- filler queue: [advance block] [DMA pieces + dst rotation] [read-delta rotation] [drain step]
+    Q = []
+    Q.append(("blk", advance_block(n)))
+    Q += dma_dst_setup()
+    if "nodma" not in FLAGS:
+        for m0w, cp in dma_pieces():
+            Q.append(m0w)
+            Q.append(("dma", cp))
+    Q += rotate_dma_dst() + rotate_read_delta()
+    if kind == "drain":
+        if d == 0:
+            Q.append(("waitvm_older",))      # the bias loads of `last` (older than everything this body issued)
+        Q += drain_items(d)
+    pos = [0]
+    debt = [0.0]
+
+    def emit_one():
+        it = Q[pos[0]]
+        pos[0] += 1
+        if isinstance(it, str):
+            e(it)
+            return cost(it)
+        if it[0] == "blk":
+            need_lg("TL1")
+            for s in it[1]:
+                e(s)
+            return 6 * ISSUE
+        if it[0] == "dma":
+            e("s_nop 0")
+            emit_vm(it[1], "dma")
+            dma_last[0] = vm_issued[0]
+            return 2 * ISSUE
+        if it[0] == "vm":
+            emit_vm(it[1], it[2])
+            return ISSUE
+        if it[0] == "needvm":
+            idx = max(i for i, nm in enumerate(vm_names) if nm == it[1])
+            e(f"s_waitcnt vmcnt({min(vm_issued[0] - idx - 1, 63)})")
+            return ISSUE
+        if it[0] == "waitvm_older":
+            e(f"s_waitcnt vmcnt({min(vm_issued[0], 63)})")
+            return ISSUE
+        raise ValueError(it)
+
+    def fill(budget):
+        debt[0] += budget
+        while pos[0] < len(Q) and debt[0] > 0:
+            debt[0] -= emit_one()
+
+    def flush():
+        while pos[0] < len(Q):
+            emit_one()
+
+    # --- MFMA slots
+    def sub_slots(setbase, block_major):
+        terms = [("al", "wh"), ("ah", "wl"), ("ah", "wh")]
+        blocks = [(mb, nb) for mb in range(MBW) for nb in range(NBW)]
+        if block_major:
+            return [(mb, nb, ka, kb, setbase) for mb, nb in blocks for ka, kb in terms]
+        return [(mb, nb, ka, kb, setbase) for ka, kb in terms for mb, nb in blocks]
+
+    slots = sub_slots(FX, False) + sub_slots(FY, kind == "last")
+    yq = [("Y", k, i) for k, i in y_order()]
+    xq = None
+    park_q = []              # (slot index after which block b may be parked)
+    first = kind == "drain" and d == 0
+    for si, (mb, nb, ka, kb, sb) in enumerate(slots):
+        pre = "X" if sb == FX else "Y"
+        if si == BAR_SLOT:
+            # tile t+1 landed (this wave's pieces; DMA of tile t+2 and younger ops stay in flight), everybody past its reads of tile t-1
+            flush_dma = [q for q in Q[pos[0]:] if not isinstance(q, str) and q[0] == "dma"]
+            assert not flush_dma, "DMA pieces must be issued before the barrier slot"
+            nvm = pred_post + vm_issued[0]
+            e(f"s_waitcnt vmcnt({min(nvm, 63)})")
+            e("s_waitcnt lgkmcnt(0)")           # (this wave's reads of the stage the next DMA overwrites: long complete)
+            lg.wait_all()
+            if "nobarrier" not in FLAGS:
+                e("s_barrier")
+            e(f"v_add_u32 {vr(RA0)}, {sr(S_RDELTA)}, {vr(RA0)}")
+            e(f"v_add_u32 {vr(RW0)}, {sr(S_RDELTA)}, {vr(RW0)}")
+            e(f"ds_read_b128 {vr(TL, 4)}, {vr(TLA)}")
+            lg.issue("TL0")
+            e(f"ds_read_b128 {vr(TL + 4, 4)}, {vr(TLA)} offset:16")
+            lg.issue("TL1")
+            xq = [("X", k, i) for k, i in x_order()]
+        need_lg(f"{pre}{ka}{mb}")
+        need_lg(f"{pre}{kb}{nb}")
+        b = mb * NBW + nb
+        c = "0" if (first and sb == FX and (ka, kb) == ("al", "wh")) else acc(b)
+        if "nomfma" not in FLAGS:
+            e(f"v_mfma_f32_32x32x16_bf16 {acc(b)}, {frag(sb, ka, mb)}, {frag(sb, kb, nb)}, {c}")
+        spent = 0
+        if yq and si < BAR_SLOT and "noread" not in FLAGS:
+            _, k, i = yq.pop(0)
+            e(read_ins(FY, k, i, 1))
+            lg.issue(f"Y{k}{i}")
+            spent += ISSUE
+        if xq:
+            for _ in range(2 if len(xq) > (NSLOT - 1 - si) else 1):
+                if xq and "noread" not in FLAGS:
+                    _, k, i = xq.pop(0)
+                    e(read_ins(FX, k, i, 0))
+                    lg.issue(f"X{k}{i}")
+                    spent += ISSUE
+        if kind == "last" and sb == FY and (ka, kb) == ("ah", "wh"):
+            park_q.append((si + 3, b))          # three more MFMAs (>= 96 cycles) before the block's accumulators are read
+        while park_q and park_q[0][0] <= si:
+            _, pb = park_q.pop(0)
+            for r in range(16):
+                e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
+            spent += 16 * ISSUE
+        fill(GAP - spent)
+    assert not yq and not xq, (yq, xq)
+    flush()
+    e(f"v_add_u32 {vr(RA1)}, {sr(S_RDELTA)}, {vr(RA1)}")
+    e(f"v_add_u32 {vr(RW1)}, {sr(S_RDELTA)}, {vr(RW1)}")
+    post = vm_issued[0] - (dma_last[0] or 0)
+    if kind == "last":
+        e("s_nop 15")
+        while park_q:
+            _, pb = park_q.pop(0)
+            for r in range(16):
+                e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
+        post += last_setup(emit_vm)
+    return post
+
+
+def last_setup(emit_vm):
+    """after parking: drain bases and bias of the parked tile (CUR), CUR <- NXT"""
+    for base, arg, off in ((D_C, S_C, CUR), (D_R, S_R, CUR + 1), (D_H, S_CH, CUR + 2), (D_L, S_CL, CUR + 2)):
+        wv = {CUR: W_C, CUR + 1: W_R, CUR + 2: W_P}[off]
+        e(f"s_add_u32 {sr(ST)}, {sr(off)}, {sr(wv)}")
+        e(f"s_add_u32 {sr(base)}, {sr(arg)}, {sr(ST)}")
+        e(f"s_addc_u32 {sr(base + 1)}, {sr(arg + 1)}, 0")
+    e(f"s_add_u32 {sr(ST)}, {sr(CUR + 3)}, {sr(W_B)}")
+    e(f"s_add_u32 {sr(ROWA)}, {sr(S_BIAS)}, {sr(ST)}")
+    e(f"s_addc_u32 {sr(ROWA + 1)}, {sr(S_BIAS + 1)}, 0")
+    e(f"v_lshlrev_b32 {vr(T0)}, 2, {vr(L31)}")
+    for nb in range(NBW):
+        emit_vm(f"global_load_dword {vr(BIAS + nb)}, {vr(T0)}, {sr(ROWA, 2)} offset:{nb * 128}", "bias")
+    for i in range(4):
+        e(f"s_mov_b32 {sr(CUR + i)}, {sr(NXT + i)}")
+    return NBW
+
+
+# ------------------------------------------------------------------------------------------------ prologue / tail
+def prologue():
+    t0, t1, t2, t3 = T0, T0 + 1, T0 + 2, T0 + 3
+    e("s_mov_b32 s90, %[klo]")
+    e("s_mov_b32 s91, %[khi]")
+    e(f"s_load_dwordx16 {sr(36, 16)}, s[90:91], 0x0")
+    e(f"s_load_dwordx8 {sr(52, 8)}, s[90:91], 0x40")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"s_mov_b32 {sr(G_C0)}, 0x3f3504f3")
+    e(f"s_mov_b32 {sr(G_C1)}, 0x3ea7ba05")
+    e(f"v_mov_b32 {vr(KC2)}, 0xbfba00e3")
+    e(f"v_and_b32 {vr(L31)}, 31, %[lane]")
+    e(f"v_lshrrev_b32 {vr(HALF)}, 5, %[lane]")
+    e("s_lshr_b32 s92, %[wave], 1")          # wm
+    e("s_and_b32 s93, %[wave], 1")           # wn
+    # LDS read bases
+    e(f"v_lshrrev_b32 {vr(t0)}, 2, {vr(L31)}")
+    e(f"v_and_b32 {vr(t0)}, 3, {vr(t0)}")                                  # sw
+    e(f"s_mul_i32 s94, s92, {2048 * MBW}")
+    e("s_add_u32 s94, s94, %[ldsb]")
+    e(f"s_mul_i32 s95, s93, {2048 * NBW}")
+    e("s_add_u32 s95, s95, %[ldsb]")
+    e(f"s_add_u32 s95, s95, {2 * PA_B}")
+    e(f"v_lshlrev_b32 {vr(t1)}, 6, {vr(L31)}")
+    for s, (ra, rw) in enumerate(((RA0, RW0), (RA1, RW1))):
+        e(f"v_or_b32 {vr(t2)}, {2 * s}, {vr(HALF)}")
+        e(f"v_xor_b32 {vr(t2)}, {vr(t2)}, {vr(t0)}")
+        e(f"v_lshl_add_u32 {vr(t2)}, {vr(t2)}, 4, {vr(t1)}")
+        e(f"v_add_u32 {vr(ra)}, s94, {vr(t2)}")
+        e(f"v_add_u32 {vr(rw)}, s95, {vr(t2)}")
+    # LDS-DMA lane offsets: row = wave * 16 MBW + 16 j + (lane >> 2), chunk lc = (lane & 3) ^ ((lane >> 4) & 3)
+    e(f"v_lshrrev_b32 {vr(t0)}, 4, %[lane]")
+    e(f"v_and_b32 {vr(t0)}, 3, {vr(t0)}")
+    e(f"v_and_b32 {vr(t1)}, 3, %[lane]")
+    e(f"v_xor_b32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
+    e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                              # lc * 16
+    e(f"v_lshrrev_b32 {vr(t1)}, 2, %[lane]")                               # rowl
+    for cnt, per, ld, dst in ((PA_N, 16 * MBW, S_LDA, DOA), (PW_N, 16 * NBW, S_LDW, DOW)):
+        e(f"s_mul_i32 s94, %[wave], {per}")
+        e(f"v_add_u32 {vr(t2)}, s94, {vr(t1)}")
+        e(f"s_lshl_b32 s94, {sr(ld)}, 1")
+        e(f"v_mul_lo_u32 {vr(t2)}, {vr(t2)}, s94")
+        e(f"v_add_u32 {vr(dst)}, {vr(t2)}, {vr(t0)}")
+        e(f"s_lshl_b32 s94, {sr(ld)}, 5")                                  # 16 rows
+        for j in range(1, cnt):
+            e(f"v_add_u32 {vr(dst + j)}, s94, {vr(dst + j - 1)}")
+    # store lane offsets
+    for vo, ld in ((VOC, S_LDC), (VOR, S_LDR)):
+        e(f"s_lshl_b32 s94, {sr(ld)}, 4")                                  # 4 rows * 4 bytes
+        e(f"v_mul_lo_u32 {vr(t2)}, {vr(HALF)}, s94")
+        e(f"v_lshl_add_u32 {vr(vo)}, {vr(L31)}, 2, {vr(t2)}")
+    e(f"v_and_b32 {vr(t0)}, 1, {vr(L31)}")
+    e(f"v_lshl_add_u32 {vr(t1)}, {vr(HALF)}, 2, {vr(t0)}")                 # 4 half + odd
+    e(f"s_lshl_b32 s94, {sr(S_LDCP)}, 1")
+    e(f"v_mul_lo_u32 {vr(t1)}, {vr(t1)}, s94")
+    e(f"v_and_b32 {vr(t2)}, 30, {vr(L31)}")
+    e(f"v_lshl_add_u32 {vr(VOP)}, {vr(t2)}, 1, {vr(t1)}")
+    e(f"v_mov_b32 {vr(t1)}, 0x05040100")
+    e(f"v_mov_b32 {vr(t2)}, 0x03020706")
+    e(f"v_cmp_eq_u32 vcc, 1, {vr(t0)}")
+    e("s_nop 1")
+    e(f"v_cndmask_b32 {vr(SEL)}, {vr(t1)}, {vr(t2)}, vcc")
+    # this wave's offsets inside a tile
+    for dst, ld, esz in ((W_C, S_LDC, 4), (W_R, S_LDR, 4), (W_P, S_LDCP, 2)):
+        e(f"s_mul_i32 s94, s92, {32 * MBW}")
+        e(f"s_mul_i32 s94, s94, {sr(ld)}")
+        e(f"s_mul_i32 s95, s93, {32 * NBW}")
+        e("s_add_u32 s94, s94, s95")
+        e(f"s_mul_i32 {sr(dst)}, s94, {esz}")
+    e(f"s_mul_i32 {sr(W_B)}, s93, {32 * NBW * 4}")
+    # loop state
+    e(f"s_sub_u32 {sr(S_NKM1)}, {sr(S_NK)}, 1")
+    e(f"s_add_u32 {sr(S_LEND)}, %[ldsb], {3 * STAGE}")
+    e(f"s_mov_b32 {sr(S_TLEFT)}, %[ntiles]")
+    e(f"s_mov_b32 {sr(S_KC)}, 0")
+    e(f"s_mov_b32 {sr(S_CST)}, 0")
+    e(f"s_mov_b32 {sr(S_RDELTA)}, {STAGE}")
+    e(f"s_mov_b32 {sr(S_STG)}, {STAGE}")
+    e(f"s_mov_b32 {sr(S_NSTG2)}, {-2 * STAGE & 0xffffffff}")
+    for i in range(16 * NB):
+        e(f"v_accvgpr_write_b32 a{i}, 0")
+    # first tile entry
+    e(f"v_mov_b32 {vr(TLA)}, %[ldsb]")
+    e(f"v_add_u32 {vr(TLA)}, {TL_OFF}, {vr(TLA)}")
+    e(f"ds_read_b128 {vr(TL, 4)}, {vr(TLA)}")
+    e(f"ds_read_b128 {vr(TL + 4, 4)}, {vr(TLA)} offset:16")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(6):
+        e(f"v_readfirstlane_b32 {sr(ST + i if i < 2 else CUR + i - 2)}, {vr(TL + i)}")
+    e("s_nop 4")
+    for p, a, o in ((P_AH, S_AH, ST), (P_AL, S_AL, ST), (P_WH, S_WH, ST + 1), (P_WL, S_WL, ST + 1)):
+        e(f"s_add_u32 {sr(p)}, {sr(a)}, {sr(o)}")
+        e(f"s_addc_u32 {sr(p + 1)}, {sr(a + 1)}, 0")
+    for i in range(4):
+        e(f"s_mov_b32 {sr(NXT + i)}, {sr(CUR + i)}")
+    e(f"v_add_u32 {vr(TLA)}, 32, {vr(TLA)}")
+    # K tiles 0 and 1
+    e(f"s_mov_b32 {sr(S_DDST)}, %[ldsb]")
+    e(f"s_mul_i32 {sr(S_WDA)}, %[wave], {MBW * 1024}")
+    e(f"s_mul_i32 {sr(S_WDW)}, %[wave], {NBW * 1024}")
+    for kt in range(2):
+        for s_ in dma_dst_setup():
+            e(s_)
+        for m0w, cp in dma_pieces():
+            e(m0w)
+            e("s_nop 0")
+            e(cp)
+        for s in rotate_dma_dst():
+            e(s)
+        if kt == 0:
+            for p in (P_AH, P_AL, P_WH, P_WL):
+                e(f"s_add_u32 {sr(p)}, {sr(p)}, 64")
+                e(f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0")
+    e(f"s_mov_b32 {sr(S_KD)}, 1")
+    e(f"s_waitcnt vmcnt({NP})")
+    e("s_barrier")
+    e(f"ds_read_b128 {vr(TL, 4)}, {vr(TLA)}")
+    e(f"ds_read_b128 {vr(TL + 4, 4)}, {vr(TLA)} offset:16")
+    for k, i in x_order():
+        e(read_ins(FX, k, i, 0))
+    e("s_branch L_plain")
+
+
+def tail():
+    """the drain of the workgroup's last tile: the 16 steps in a row"""
+    e("L_tail:")
+    e("s_waitcnt vmcnt(0)")
+    vm = []
+    for d in range(NDRAIN):
+        for it in drain_items(d):
+            if isinstance(it, str):
+                e(it)
+            elif it[0] == "vm":
+                e(it[1])
+                vm.append(it[2])
+            elif it[0] == "needvm":
+                idx = max(i for i, nm in enumerate(vm) if nm == it[1])
+                e(f"s_waitcnt vmcnt({min(len(vm) - idx - 1, 63)})")
+    e("s_waitcnt vmcnt(0)")
+    e("s_waitcnt lgkmcnt(0)")
+
+
+def lint(L):
+    """manual hazards of gfx950 that nothing else checks for hand-written code (wait states: an instruction = 1, s_nop n = n + 1)"""
+    def toks(ins):
+        return ins.replace(",", " ").replace("|", " ").replace("-v", " v").split()
+
+    def regs(tok):
+        if len(tok) > 2 and tok[0] in "vsa" and tok[1] == "[":
+            a, b = tok[2:-1].split(":")
+            return {f"{tok[0]}{i}" for i in range(int(a), int(b) + 1)}
+        return {tok}
+
+    def srcs(ins):
+        r = set()
+        for t in toks(ins)[2:]:
+            r |= regs(t)
+        return r
+
+    def dst(ins):
+        return regs(toks(ins)[1])
+
+    def within(i, n):
+        """instructions following L[i] that start fewer than n wait states after it"""
+        w, res = 0, []
+        for x in L[i + 1:i + 12]:
+            if x.endswith(":"):
+                continue
+            if w >= n:
+                break
+            res.append(x)
+            w += int(x.split()[1]) + 1 if x.startswith("s_nop") else 1
+        return res
+
+    for i, ins in enumerate(L):
+        op = ins.split()[0]
+        if op.endswith(":") or op.startswith("s_waitcnt") or op in ("s_barrier", "s_nop", "s_branch") or op.startswith("s_cbranch"):
+            continue
+        if op in ("v_exp_f32", "v_rcp_f32"):                               # trans result -> VALU read: 1 wait state
+            for x in within(i, 1):
+                assert dst(ins).isdisjoint(srcs(x)), (i, ins, x)
+        if op.startswith("v_cmp"):                                         # VALU mask write -> VALU mask read: 2 wait states
+            for x in within(i, 2):
+                assert not (x.startswith("v_cndmask") and not dst(ins).isdisjoint(regs(toks(x)[-1]))), (i, ins, x)
+        if op.startswith("v_") and not op.startswith("v_cmp"):             # VALU VGPR write -> DPP read: 2 wait states
+            for x in within(i, 2):
+                if x.startswith("v_mov_b32_dpp"):
+                    assert dst(ins).isdisjoint(regs(toks(x)[2])), (i, ins, x)
+        if op.startswith("s_") and toks(ins)[1] == "m0":                   # SALU m0 write -> LDS-DMA: 1 wait state
+            for x in within(i, 1):
+                assert not x.startswith("global_load_lds"), (i, ins, x)
+        if op == "v_readfirstlane_b32":                                    # VALU SGPR write -> SALU / VMEM read: 5 wait states (s_nop 4)
+            for x in within(i, 5):
+                if not x.startswith("v_readfirstlane"):
+                    assert dst(ins).isdisjoint(srcs(x)), (i, ins, x)
+
+
+def main():
+    prologue()
+    last_post = NBW
+    e("L_drain:")
+    pp = last_post
+    posts = []
+    for d in range(NDRAIN):
+        pp = body("drain", d, pp)
+        posts.append(pp)
+        e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
+    e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
+    e("s_cbranch_scc0 L_last")
+    e("L_plain:")
+    body("plain", None, 0)
+    e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
+    e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
+    e("s_cbranch_scc1 L_plain")
+    e("L_last:")
+    body("last", None, 0)
+    e(f"s_mov_b32 {sr(S_KC)}, 0")
+    e(f"s_sub_u32 {sr(S_TLEFT)}, {sr(S_TLEFT)}, 1")
+    e(f"s_cmp_eq_u32 {sr(S_TLEFT)}, 0")
+    e("s_cbranch_scc0 L_drain")
+    tail()
+    lint(out)
+    import re
+    out[:] = [re.sub(r"\bL_\w+", lambda m: m.group(0) + "_%=", ln) for ln in out]
+    nm = f"X4G_{CFG}_{EPI.upper()}"
+    clob = [f'"v{i}"' for i in range(32, 240)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(12, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
+    txt = (f"// GENERATED by tools/gen/gen_gemm_x4g.py {CFG} {EPI} - do not edit.\n"
+           f"// {len(out)} instructions; workgroup tile {TM} x {TN}, LDS {3 * STAGE + 16384} bytes\n"
+           f"#define {nm}_BODY \\\n" + " \\\n".join('    "' + ln + '\\n\\t"' for ln in out) + "\n"
+           f"#define {nm}_CLOBBERS " + ", ".join(clob) + "\n")
+    open(OUT, "w").write(txt)
+    print(len(out), "instructions;", sum(1 for x in out if x.startswith("v_mfma")), "MFMAs; drain posts", posts)
+
+
+if __name__ == "__main__":
+    main()
