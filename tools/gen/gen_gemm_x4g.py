@@ -45,6 +45,13 @@ STEPS_PER_MB = 8 // RP
 PA_N, PW_N = MBW, NBW                         # LDS-DMA pieces per plane and wave (16 rows x 64 B each)
 NP = 2 * (PA_N + PW_N)                        # pieces per wave and K tile
 ISSUE = int(os.environ.get("X4G_ISSUE", 4))
+# form of the drain per epilogue, measured in one call (gpurun_out/r05_f_stores.txt; X4G_WIDE / X4G_STMOD override for A/B builds):
+#   e1 (fp32, 453 MB at the qkv shape): quad transposes + 16-byte non-temporal stores 384 us, plain 403, dword stores 440 (pp256: 405)
+#   e2 (GELU + planes): the lane-pair exchange + dword stores 521 us, transposes + 8-byte stores 555 (the extra VALU work costs more)
+#   e3 (residual): dword loads / stores 176 - 178 us, transposes 186
+_DEF_WIDE, _DEF_STMOD = {"e1": ("1", "nt"), "e2": ("0", ""), "e3": ("0", "nt")}[EPI]
+_stmod = os.environ.get("X4G_STMOD", _DEF_STMOD)
+STMOD = (" " + _stmod) if _stmod and _stmod != "none" else ""      # cache policy of the result stores (nt | sc1 | sc0 sc1 | none)
 GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
 
 # VGPR map (v0..v31 are left to the compiler)
@@ -54,7 +61,8 @@ DOA, DOW = 148, 152                           # LDS-DMA lane offsets: A pieces (
 TLA, TL = 155, 156                            # tile-list address; entry (8 dwords)
 VOC, VOR, VOP, SEL = 164, 165, 166, 167       # lane offsets of C / R / plane stores, v_perm selector of the lane-pair exchange
 BIAS, KC2, L31, HALF = 168, 171, 172, 173
-T0, NTMP = 176, 60                            # temporaries 176..235
+T0, NTMP = 176, 40                            # temporaries 176..215
+RBUF = 216                                    # e3: two sets of residual values (216..231), loaded one drain step ahead
 # SGPR map (s32 / s33 and s96.. are reserved by the compiler; s0..s15 are left to it)
 S_AH, S_AL, S_WH, S_WL, S_BIAS, S_C, S_R, S_CH, S_CL = 36, 38, 40, 42, 44, 46, 48, 50, 52
 S_LDA, S_LDW, S_LDC, S_LDR, S_LDCP, S_NK = 54, 55, 56, 57, 58, 59
@@ -67,6 +75,7 @@ ROWA, ROWB, ROWC, ROWD = 16, 18, 20, 22       # row address pairs
 ST = 24                                       # scalar temporaries 24..29
 G_C0, G_C1 = 30, 31                           # GELU constants
 S_STG, S_NSTG2 = 34, 35                       # STAGE, -2 STAGE
+S_M1, S_M2 = 8, 10                            # lane masks (lane & 1), (lane & 2) of the quad transposes
 S_WDA, S_WDW, S_DSTA, S_DSTW = 12, 13, 14, 15  # this wave's row offset inside a stage's A / W planes; DMA destinations of this K tile
 
 out = []
@@ -203,20 +212,190 @@ def rotate_read_delta():
 
 
 # ------------------------------------------------------------------------------------------------ drain steps
-def row_of(mb, r):
-    return mb * 32 + (r & 3) + 8 * (r >> 2)
+# The parked tile is drained in UNITS of 4 accumulator registers (mb, g, nb): registers 4g..4g+3 of block (mb, nb) = rows
+# 32 mb + 8 g + 4 half + {0,1,2,3}, column 32 nb + l31 of the wave tile.  A 4 x 4 transpose inside every quad of lanes (two DPP
+# butterfly stages) turns "lane = column, registers = rows" into "lane i of a quad = row i, registers = 4 consecutive columns", so
+# that the result leaves in 16-byte (fp32) / 8-byte (bf16 planes) pieces and a store instruction writes 8 rows x 128 / 64 bytes:
+# the kernel is bound by the number of VMEM instructions (LDS-DMA + stores share the CU's one address path), not by their bytes.
+UNITS = [(mb, g, nb) for mb in range(MBW) for g in range(4) for nb in range(NBW)]
+
+
+def step_units(d):
+    return UNITS[d * len(UNITS) // NDRAIN:(d + 1) * len(UNITS) // NDRAIN]
 
 
 def park(mb, nb, r):
     return ar(128 + (mb * NBW + nb) * 16 + r)
 
 
+XOR1 = "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+XOR2 = "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+
+
 class Drain:
+    """the filler stream of drain step d of the parked tile.  Items: instruction strings; ("vm", ins, name) VMEM ops; ("needprev", d)"""
+
+    def __init__(self, d):
+        self.F = []
+        self.tix = 0
+        self.d = d
+        getattr(self, EPI)(step_units(d))
+
+    def tmp(self, n):
+        if self.tix + n > NTMP:
+            self.tix = 0
+        b = T0 + self.tix
+        self.tix += n
+        return b
+
+    def add(self, s):
+        self.F.append(s)
+
+    def rowaddr(self, pair, base, row, ld, esz):
+        self.add(f"s_mul_i32 {sr(ST + 4)}, {sr(ld)}, {row * esz}")
+        self.add(f"s_add_u32 {sr(pair)}, {sr(base)}, {sr(ST + 4)}")
+        self.add(f"s_addc_u32 {sr(pair + 1)}, {sr(base + 1)}, 0")
+
+    def store(self, width, voff, data, pair, off):
+        if "nostore" in FLAGS:
+            return
+        op = {4: "global_store_dwordx4", 2: "global_store_dwordx2"}[width]
+        self.F.append(("vm", f"{op} {vr(voff)}, {vr(data, width)}, {sr(pair, 2)} offset:{off}{STMOD}", "st"))
+
+    def transpose4(self, t):
+        """4 x 4 transpose of v[t..t+3] across the lanes of every quad (x: two scratch registers)"""
+        A = self.add
+        x = self.tmp(4)
+        for (mask, ctl, pairs) in ((S_M2, XOR2, ((0, 2), (1, 3))), (S_M1, XOR1, ((0, 1), (2, 3)))):
+            for j, (a, b) in enumerate(pairs):       # lanes with the bit set send their a, the others their b
+                A(f"v_cndmask_b32_e64 {vr(x + j)}, {vr(t + b)}, {vr(t + a)}, {sr(mask, 2)}")
+            A("s_nop 0")
+            for j, (a, b) in enumerate(pairs):
+                A(f"v_mov_b32_dpp {vr(x + 2 + j)}, {vr(x + j)} {ctl}")
+            for j, (a, b) in enumerate(pairs):
+                A(f"v_cndmask_b32_e64 {vr(t + a)}, {vr(t + a)}, {vr(x + 2 + j)}, {sr(mask, 2)}")
+                A(f"v_cndmask_b32_e64 {vr(t + b)}, {vr(x + 2 + j)}, {vr(t + b)}, {sr(mask, 2)}")
+
+    def read_bias(self, t, mb, g, nb):
+        for k in range(4):
+            self.add(f"v_accvgpr_read_b32 {vr(t + k)}, {park(mb, nb, 4 * g + k)}")
+        for k in range(4):
+            self.add(f"v_add_f32 {vr(t + k)}, {vr(t + k)}, {vr(BIAS + nb)}")
+
+    def e1(self, units):
+        for i, (mb, g, nb) in enumerate(units):
+            pair = (ROWA, ROWB)[i % 2]
+            self.rowaddr(pair, D_C, mb * 32 + 8 * g, S_LDC, 4)
+            t = self.tmp(4)
+            self.read_bias(t, mb, g, nb)
+            self.transpose4(t)
+            self.store(4, VOC, t, pair, nb * 128)
+
+    @staticmethod
+    def e3_loads(d):
+        """residual loads of drain step d into buffer set d % 2 (issued ONE STEP AHEAD: by body d-1, by `last` for d = 0), in the
+        transposed layout of the stores: lane i of a quad = row i, 4 consecutive columns"""
+        L = []
+        for i, (mb, g, nb) in enumerate(step_units(d)):
+            pair = ROWC if i % 2 == 0 else ROWD
+            L += [f"s_mul_i32 {sr(ST + 4)}, {sr(S_LDR)}, {(mb * 32 + 8 * g) * 4}", f"s_add_u32 {sr(pair)}, {sr(D_R)}, {sr(ST + 4)}",
+                  f"s_addc_u32 {sr(pair + 1)}, {sr(D_R + 1)}, 0"]
+            L.append(("vm", f"global_load_dwordx4 {vr(RBUF + (d % 2) * 8 + i * 4, 4)}, {vr(VOR)}, {sr(pair, 2)} offset:{nb * 128}", f"Rstep{d}"))
+        return L
+
+    def e3(self, units):
+        d = self.d
+        if d + 1 < NDRAIN:
+            self.F += self.e3_loads(d + 1)
+        self.F.append(("needprev", d))
+        for i, (mb, g, nb) in enumerate(units):
+            pair = (ROWA, ROWB)[i % 2]
+            self.rowaddr(pair, D_C, mb * 32 + 8 * g, S_LDC, 4)
+            t = self.tmp(4)
+            self.read_bias(t, mb, g, nb)
+            self.transpose4(t)
+            for k in range(4):
+                self.add(f"v_add_f32 {vr(t + k)}, {vr(t + k)}, {vr(RBUF + (d % 2) * 8 + i * 4 + k)}")
+            self.store(4, VOC, t, pair, nb * 128)
+
+    def gelu4(self, x):
+        """ds2_gelu (common.h) on v[x..x+3], the compiled instruction sequence of the other kernels, four chains interleaved"""
+        A = self.add
+        b = self.tmp(16)
+        z, t, p, ee = ([b + 4 * j + c for c in range(4)] for j in range(4))
+        msk = ("vcc", sr(ST + 2, 2), sr(ROWC, 2), sr(ROWD, 2))
+        R4 = range(4)
+        for c in R4: A(f"v_mul_f32_e64 {vr(z[c])}, |{vr(x + c)}|, {sr(G_C0)}")
+        for c in R4: A(f"v_fma_f32 {vr(t[c])}, {vr(z[c])}, {sr(G_C1)}, 1.0")
+        for c in R4: A(f"v_rcp_f32 {vr(t[c])}, {vr(t[c])}")
+        for c in R4: A(f"v_mul_f32_e64 {vr(ee[c])}, {vr(z[c])}, -{vr(z[c])}")
+        for c in R4: A(f"v_fmamk_f32 {vr(p[c])}, {vr(t[c])}, 0x3f87dc22, {vr(KC2)}")
+        for c in R4: A(f"v_mul_f32 {vr(ee[c])}, 0x3fb8aa3b, {vr(ee[c])}")
+        for c in R4: A(f"v_fmaak_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}, 0x3fb5f0e3")
+        for c in R4: A(f"v_exp_f32 {vr(ee[c])}, {vr(ee[c])}")
+        for c in R4: A(f"v_fmaak_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}, 0xbe91a98e")
+        for c in R4: A(f"v_fmaak_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}, 0x3e827906")
+        for c in R4: A(f"v_mul_f32 {vr(p[c])}, {vr(t[c])}, {vr(p[c])}")
+        for c in R4: A(f"v_mul_f32 {vr(p[c])}, 0.5, {vr(p[c])}")
+        for c in R4: A(f"v_mul_f32 {vr(p[c])}, {vr(ee[c])}, {vr(p[c])}")
+        for c in R4: A(f"v_cmp_le_f32_e64 {msk[c]}, 0, {vr(x + c)}")
+        for c in R4: A(f"v_sub_f32 {vr(z[c])}, 1.0, {vr(p[c])}")
+        for c in R4: A(f"v_cndmask_b32_e64 {vr(p[c])}, {vr(p[c])}, {vr(z[c])}, {msk[c]}")
+        for c in R4: A(f"v_mul_f32 {vr(x + c)}, {vr(x + c)}, {vr(p[c])}")
+
+    def e2(self, units):
+        A = self.add
+        for i, (mb, g, nb) in enumerate(units):
+            ph, pl = (ROWA, ROWB)
+            self.rowaddr(ph, D_H, mb * 32 + 8 * g, S_LDCP, 2)
+            self.rowaddr(pl, D_L, mb * 32 + 8 * g, S_LDCP, 2)
+            x = self.tmp(4)
+            self.read_bias(x, mb, g, nb)
+            if "nogelu" not in FLAGS:
+                self.gelu4(x)
+            w = self.tmp(16)
+            hA, hB, lA, lB, f0, f1, f2, f3 = (w + j for j in range(8))
+            n0, n1, o0, o1, xs, ys = (w + 8 + j for j in range(6))
+            # bf16 hi / lo of rows (0, 1) -> A, rows (2, 3) -> B (the split of the other kernels: lo = bf16(v - float(hi)))
+            A(f"v_cvt_pk_bf16_f32 {vr(hA)}, {vr(x)}, {vr(x + 1)}")
+            A(f"v_cvt_pk_bf16_f32 {vr(hB)}, {vr(x + 2)}, {vr(x + 3)}")
+            A(f"v_lshlrev_b32 {vr(f0)}, 16, {vr(hA)}")
+            A(f"v_and_b32 {vr(f1)}, 0xffff0000, {vr(hA)}")
+            A(f"v_lshlrev_b32 {vr(f2)}, 16, {vr(hB)}")
+            A(f"v_and_b32 {vr(f3)}, 0xffff0000, {vr(hB)}")
+            for k, f in enumerate((f0, f1, f2, f3)):
+                A(f"v_sub_f32 {vr(f)}, {vr(x + k)}, {vr(f)}")
+            A(f"v_cvt_pk_bf16_f32 {vr(lA)}, {vr(f0)}, {vr(f1)}")
+            A(f"v_cvt_pk_bf16_f32 {vr(lB)}, {vr(f2)}, {vr(f3)}")
+            for (pa, pb, pair) in ((hA, hB, ph), (lA, lB, pl)):
+                o = self.tmp(2)          # (even-aligned pair: the 8-byte store's data)
+                # stage 1 (lane ^ 1): even lanes keep row 0 / 2 with columns (c, c+1), odd lanes row 1 / 3 with columns (c-1, c)
+                A(f"v_mov_b32_dpp {vr(n0)}, {vr(pa)} {XOR1}")
+                A(f"v_mov_b32_dpp {vr(n1)}, {vr(pb)} {XOR1}")
+                A(f"v_perm_b32 {vr(o0)}, {vr(n0)}, {vr(pa)}, {vr(SEL)}")
+                A(f"v_perm_b32 {vr(o1)}, {vr(n1)}, {vr(pb)}, {vr(SEL)}")
+                # stage 2 (lane ^ 2): lanes 0, 1 of a quad end with rows 0, 1 (A), lanes 2, 3 with rows 2, 3 (B), 4 columns each
+                A(f"v_cndmask_b32_e64 {vr(xs)}, {vr(o1)}, {vr(o0)}, {sr(S_M2, 2)}")
+                A("s_nop 1")
+                A(f"v_mov_b32_dpp {vr(ys)}, {vr(xs)} {XOR2}")
+                A(f"v_cndmask_b32_e64 {vr(o)}, {vr(o0)}, {vr(ys)}, {sr(S_M2, 2)}")
+                A(f"v_cndmask_b32_e64 {vr(o + 1)}, {vr(ys)}, {vr(o1)}, {sr(S_M2, 2)}")
+                self.store(2, VOP, o, pair, nb * 64)
+
+
+# ---- the first form of the drain (kept for A/B runs, X4G_WIDE=0): no transposes - fp32 results leave as dword stores of 2 rows x
+# 128 bytes, bf16 planes as dword stores after ONE lane-pair exchange (4 rows x 64 bytes per instruction)
+def row_of(mb, r):
+    return mb * 32 + (r & 3) + 8 * (r >> 2)
+
+
+class DrainNarrow:
     """the filler stream of drain step d of the parked tile.  Items: instruction strings; ("vm", ins, name) VMEM ops; ("needvm", name)"""
 
     def __init__(self, d):
         self.F = []
         self.tix = 0
+        self.d = d
         mb, sub = divmod(d, STEPS_PER_MB)
         pairs = [sub * RP + i for i in range(RP)]
         getattr(self, EPI)(mb, pairs)
@@ -239,7 +418,7 @@ class Drain:
     def store(self, voff, data, pair, off, name):
         if "nostore" in FLAGS:
             return
-        self.F.append(("vm", f"global_store_dword {vr(voff)}, {vr(data)}, {sr(pair, 2)} offset:{off}", name))
+        self.F.append(("vm", f"global_store_dword {vr(voff)}, {vr(data)}, {sr(pair, 2)} offset:{off}{STMOD}", name))
 
     def e1(self, mb, pairs):
         k = 0
@@ -254,15 +433,25 @@ class Drain:
                     self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(BIAS + nb)}")
                     self.store(VOC, t, pair, nb * 128, "st")
 
-    def e3(self, mb, pairs):
-        rows = [(q, r) for q in pairs for r in (2 * q, 2 * q + 1)]
-        rt = {}
-        for i, (q, r) in enumerate(rows):                     # residual loads first (their row pairs are not reused before the stores)
-            self.rowaddr(ROWC if i % 2 == 0 else ROWD, D_R, row_of(mb, r), S_LDR, 4)
+    @staticmethod
+    def e3_loads(d):
+        mb, sub = divmod(d, STEPS_PER_MB)
+        rows = [r for q in (sub * RP + i for i in range(RP)) for r in (2 * q, 2 * q + 1)]
+        L = []
+        for i, r in enumerate(rows):
+            pair = ROWC if i % 2 == 0 else ROWD
+            L += [f"s_mul_i32 {sr(ST + 4)}, {sr(S_LDR)}, {row_of(mb, r) * 4}", f"s_add_u32 {sr(pair)}, {sr(D_R)}, {sr(ST + 4)}",
+                  f"s_addc_u32 {sr(pair + 1)}, {sr(D_R + 1)}, 0"]
             for nb in range(NBW):
-                t = self.tmp(1)
-                rt[(r, nb)] = t
-                self.F.append(("vm", f"global_load_dword {vr(t)}, {vr(VOR)}, {sr(ROWC if i % 2 == 0 else ROWD, 2)} offset:{nb * 128}", f"R{r}_{nb}"))
+                L.append(("vm", f"global_load_dword {vr(RBUF + (d % 2) * 8 + i * NBW + nb)}, {vr(VOR)}, {sr(pair, 2)} offset:{nb * 128}", f"Rstep{d}"))
+        return L
+
+    def e3(self, mb, pairs):
+        d = self.d
+        if d + 1 < NDRAIN:
+            self.F += self.e3_loads(d + 1)
+        self.F.append(("needprev", d))
+        rows = [(q, r) for q in pairs for r in (2 * q, 2 * q + 1)]
         for i, (q, r) in enumerate(rows):
             pair = ROWA if i % 2 == 0 else ROWB
             self.rowaddr(pair, D_C, row_of(mb, r), S_LDC, 4)
@@ -270,8 +459,7 @@ class Drain:
                 t = self.tmp(1)
                 self.add(f"v_accvgpr_read_b32 {vr(t)}, {park(mb, nb, r)}")
                 self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(BIAS + nb)}")
-                self.F.append(("needvm", f"R{r}_{nb}"))
-                self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(rt[(r, nb)])}")
+                self.add(f"v_add_f32 {vr(t)}, {vr(t)}, {vr(RBUF + (d % 2) * 8 + i * NBW + nb)}")
                 self.store(VOC, t, pair, nb * 128, "st")
 
     def e2(self, mb, pairs):
@@ -339,17 +527,30 @@ class Drain:
                 self.store(VOP, ol, pl, nb * 64, "st")
 
 
+
+WIDE = os.environ.get("X4G_WIDE", _DEF_WIDE) != "0"
+
+
 def drain_items(d):
     if "nodrain" in FLAGS:
         return []
-    return Drain(d).F
+    return (Drain(d) if WIDE else DrainNarrow(d)).F
+
+
+def n_loads(d):
+    """residual loads of e3 step d"""
+    return len(step_units(d)) if WIDE else 2 * RP * NBW
+
+
+def n_stores(d):
+    return len(step_units(d)) if WIDE else 2 * RP * NBW
 
 
 # ------------------------------------------------------------------------------------------------ one K-tile body
 body_n = [0]
 
 
-def body(kind, d=None, pred_post=0):
+def body(kind, d=None, pred_post=0, prev_after=0):
     """kind: 'plain' | 'drain' (step d) | 'last'.  pred_post: VMEM ops the predecessor issued after its last DMA piece (minimum over
     the possible predecessors).  Returns the number of VMEM ops this body issues after its last DMA piece."""
     n = body_n[0]
@@ -408,6 +609,9 @@ def body(kind, d=None, pred_post=0):
             idx = max(i for i, nm in enumerate(vm_names) if nm == it[1])
             e(f"s_waitcnt vmcnt({min(vm_issued[0] - idx - 1, 63)})")
             return ISSUE
+        if it[0] == "needprev":              # the loads the previous body issued for this step (it issued prev_after VMEM ops after them)
+            e(f"s_waitcnt vmcnt({min(prev_after + vm_issued[0], 63)})")
+            return ISSUE
         if it[0] == "waitvm_older":
             e(f"s_waitcnt vmcnt({min(vm_issued[0], 63)})")
             return ISSUE
@@ -461,16 +665,18 @@ def body(kind, d=None, pred_post=0):
         if "nomfma" not in FLAGS:
             e(f"v_mfma_f32_32x32x16_bf16 {acc(b)}, {frag(sb, ka, mb)}, {frag(sb, kb, nb)}, {c}")
         spent = 0
-        if yq and si < BAR_SLOT and "noread" not in FLAGS:
+        if yq and si < BAR_SLOT:
             _, k, i = yq.pop(0)
-            e(read_ins(FY, k, i, 1))
+            if "noread" not in FLAGS:
+                e(read_ins(FY, k, i, 1))
             lg.issue(f"Y{k}{i}")
             spent += ISSUE
         if xq:
             for _ in range(2 if len(xq) > (NSLOT - 1 - si) else 1):
-                if xq and "noread" not in FLAGS:
+                if xq:
                     _, k, i = xq.pop(0)
-                    e(read_ins(FX, k, i, 0))
+                    if "noread" not in FLAGS:
+                        e(read_ins(FX, k, i, 0))
                     lg.issue(f"X{k}{i}")
                     spent += ISSUE
         if kind == "last" and sb == FY and (ka, kb) == ("ah", "wh"):
@@ -500,7 +706,10 @@ def last_setup(emit_vm):
     """after parking: drain bases and bias of the parked tile (CUR), CUR <- NXT"""
     for base, arg, off in ((D_C, S_C, CUR), (D_R, S_R, CUR + 1), (D_H, S_CH, CUR + 2), (D_L, S_CL, CUR + 2)):
         wv = {CUR: W_C, CUR + 1: W_R, CUR + 2: W_P}[off]
-        e(f"s_add_u32 {sr(ST)}, {sr(off)}, {sr(wv)}")
+        if "stsame" in FLAGS:                  # (timing experiment: every tile's result goes to the first tile's place)
+            e(f"s_mov_b32 {sr(ST)}, {sr(wv)}")
+        else:
+            e(f"s_add_u32 {sr(ST)}, {sr(off)}, {sr(wv)}")
         e(f"s_add_u32 {sr(base)}, {sr(arg)}, {sr(ST)}")
         e(f"s_addc_u32 {sr(base + 1)}, {sr(arg + 1)}, 0")
     e(f"s_add_u32 {sr(ST)}, {sr(CUR + 3)}, {sr(W_B)}")
@@ -509,9 +718,17 @@ def last_setup(emit_vm):
     e(f"v_lshlrev_b32 {vr(T0)}, 2, {vr(L31)}")
     for nb in range(NBW):
         emit_vm(f"global_load_dword {vr(BIAS + nb)}, {vr(T0)}, {sr(ROWA, 2)} offset:{nb * 128}", "bias")
+    n = NBW
+    if EPI == "e3" and "nodrain" not in FLAGS:
+        for it in (Drain if WIDE else DrainNarrow).e3_loads(0):
+            if isinstance(it, str):
+                e(it)
+            else:
+                emit_vm(it[1], it[2])
+                n += 1
     for i in range(4):
         e(f"s_mov_b32 {sr(CUR + i)}, {sr(NXT + i)}")
-    return NBW
+    return n
 
 
 # ------------------------------------------------------------------------------------------------ prologue / tail
@@ -560,22 +777,37 @@ def prologue():
         e(f"s_lshl_b32 s94, {sr(ld)}, 5")                                  # 16 rows
         for j in range(1, cnt):
             e(f"v_add_u32 {vr(dst + j)}, s94, {vr(dst + j - 1)}")
-    # store lane offsets
-    for vo, ld in ((VOC, S_LDC), (VOR, S_LDR)):
-        e(f"s_lshl_b32 s94, {sr(ld)}, 4")                                  # 4 rows * 4 bytes
-        e(f"v_mul_lo_u32 {vr(t2)}, {vr(HALF)}, s94")
-        e(f"v_lshl_add_u32 {vr(vo)}, {vr(L31)}, 2, {vr(t2)}")
+    if WIDE:
+        # store lane offsets (layout AFTER the quad transposes): lane -> row 4 half + (l31 & 3), columns (l31 & 28) .. + 3
+        e(f"v_and_b32 {vr(t0)}, 3, {vr(L31)}")
+        e(f"v_lshl_add_u32 {vr(t1)}, {vr(HALF)}, 2, {vr(t0)}")                 # 4 half + (l31 & 3)
+        e(f"v_and_b32 {vr(t2)}, 28, {vr(L31)}")
+        for vo, ld, sh in ((VOC, S_LDC, 2), (VOR, S_LDR, 2), (VOP, S_LDCP, 1)):
+            e(f"s_lshl_b32 s94, {sr(ld)}, {sh}")                               # bytes per row
+            e(f"v_mul_lo_u32 {vr(t3)}, {vr(t1)}, s94")
+            e(f"v_lshl_add_u32 {vr(vo)}, {vr(t2)}, {sh}, {vr(t3)}")
+    if not WIDE:        # lane = column: row 4 half, column l31 (fp32); row 4 half + (l31 & 1), columns l31 & 30 (planes)
+        for vo, ld in ((VOC, S_LDC), (VOR, S_LDR)):
+            e(f"s_lshl_b32 s94, {sr(ld)}, 4")
+            e(f"v_mul_lo_u32 {vr(t2)}, {vr(HALF)}, s94")
+            e(f"v_lshl_add_u32 {vr(vo)}, {vr(L31)}, 2, {vr(t2)}")
+        e(f"v_and_b32 {vr(t0)}, 1, {vr(L31)}")
+        e(f"v_lshl_add_u32 {vr(t1)}, {vr(HALF)}, 2, {vr(t0)}")
+        e(f"s_lshl_b32 s94, {sr(S_LDCP)}, 1")
+        e(f"v_mul_lo_u32 {vr(t1)}, {vr(t1)}, s94")
+        e(f"v_and_b32 {vr(t2)}, 30, {vr(L31)}")
+        e(f"v_lshl_add_u32 {vr(VOP)}, {vr(t2)}, 1, {vr(t1)}")
+    # selector of the first exchange stage of the bf16 planes (lane ^ 1), lane masks of the transposes
     e(f"v_and_b32 {vr(t0)}, 1, {vr(L31)}")
-    e(f"v_lshl_add_u32 {vr(t1)}, {vr(HALF)}, 2, {vr(t0)}")                 # 4 half + odd
-    e(f"s_lshl_b32 s94, {sr(S_LDCP)}, 1")
-    e(f"v_mul_lo_u32 {vr(t1)}, {vr(t1)}, s94")
-    e(f"v_and_b32 {vr(t2)}, 30, {vr(L31)}")
-    e(f"v_lshl_add_u32 {vr(VOP)}, {vr(t2)}, 1, {vr(t1)}")
     e(f"v_mov_b32 {vr(t1)}, 0x05040100")
     e(f"v_mov_b32 {vr(t2)}, 0x03020706")
     e(f"v_cmp_eq_u32 vcc, 1, {vr(t0)}")
     e("s_nop 1")
     e(f"v_cndmask_b32 {vr(SEL)}, {vr(t1)}, {vr(t2)}, vcc")
+    e(f"s_mov_b32 {sr(S_M1)}, 0xaaaaaaaa")
+    e(f"s_mov_b32 {sr(S_M1 + 1)}, 0xaaaaaaaa")
+    e(f"s_mov_b32 {sr(S_M2)}, 0xcccccccc")
+    e(f"s_mov_b32 {sr(S_M2 + 1)}, 0xcccccccc")
     # this wave's offsets inside a tile
     for dst, ld, esz in ((W_C, S_LDC, 4), (W_R, S_LDR, 4), (W_P, S_LDCP, 2)):
         e(f"s_mul_i32 s94, s92, {32 * MBW}")
@@ -652,6 +884,10 @@ def tail():
             elif it[0] == "needvm":
                 idx = max(i for i, nm in enumerate(vm) if nm == it[1])
                 e(f"s_waitcnt vmcnt({min(len(vm) - idx - 1, 63)})")
+            elif it[0] == "needprev":
+                idx = [i for i, nm in enumerate(vm) if nm == f"Rstep{it[1]}"]
+                if idx:
+                    e(f"s_waitcnt vmcnt({min(len(vm) - max(idx) - 1, 63)})")
     e("s_waitcnt vmcnt(0)")
     e("s_waitcnt lgkmcnt(0)")
 
@@ -713,12 +949,14 @@ def lint(L):
 
 def main():
     prologue()
-    last_post = NBW
+    e3on = EPI == "e3" and "nodrain" not in FLAGS
+    nst = lambda d: n_stores(d) if (e3on and "nostore" not in FLAGS) else 0   # stores of e3 step d (issued behind the loads of d + 1)
+    last_post = NBW + (n_loads(0) if e3on else 0)
     e("L_drain:")
     pp = last_post
     posts = []
     for d in range(NDRAIN):
-        pp = body("drain", d, pp)
+        pp = body("drain", d, pp, 0 if d == 0 else nst(d - 1))
         posts.append(pp)
         e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
     e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
@@ -739,7 +977,7 @@ def main():
     import re
     out[:] = [re.sub(r"\bL_\w+", lambda m: m.group(0) + "_%=", ln) for ln in out]
     nm = f"X4G_{CFG}_{EPI.upper()}"
-    clob = [f'"v{i}"' for i in range(32, 240)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(12, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
+    clob = [f'"v{i}"' for i in range(32, 240)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(8, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
     txt = (f"// GENERATED by tools/gen/gen_gemm_x4g.py {CFG} {EPI} - do not edit.\n"
            f"// {len(out)} instructions; workgroup tile {TM} x {TN}, LDS {3 * STAGE + 16384} bytes\n"
            f"#define {nm}_BODY \\\n" + " \\\n".join('    "' + ln + '\\n\\t"' for ln in out) + "\n"
