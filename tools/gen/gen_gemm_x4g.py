@@ -36,14 +36,15 @@ NB = MBW * NBW
 TM, TN = 64 * MBW, 64 * NBW
 PA_B, PW_B = TM * 64, TN * 64                 # bytes of one plane of a stage
 STAGE = 2 * (PA_B + PW_B)
-TL_OFF = 3 * STAGE                            # tile list (32-byte entries) behind the ring
+NSTAGE = int(os.environ.get("X4G_NSTAGE", 160 * 1024 // STAGE if 160 * 1024 // STAGE < 4 else 4))   # LDS ring: 3 stages of 48 KiB (cfg 42), 4 of 40 KiB (cfg 23)
+LOOK = NSTAGE - 1                             # K tiles in flight ahead of the one being multiplied
 NSLOT = 6 * NB                                # MFMAs per K tile
 BAR_SLOT = (NSLOT * 3) // 4
 NDRAIN = 16                                   # drain steps = K tiles that carry one
 RP = MBW // 2                                 # row pairs (of 8 per block) per drain step
 STEPS_PER_MB = 8 // RP
 PA_N, PW_N = MBW, NBW                         # LDS-DMA pieces per plane and wave (16 rows x 64 B each)
-NP = 2 * (PA_N + PW_N)                        # pieces per wave and K tile
+NP = 2 * ((0 if 'onlyw' in FLAGS else PA_N) + (0 if 'onlya' in FLAGS else PW_N))   # pieces per wave and K tile
 ISSUE = int(os.environ.get("X4G_ISSUE", 4))
 # form of the drain per epilogue, measured in one call (gpurun_out/r05_f_stores.txt; X4G_WIDE / X4G_STMOD override for A/B builds):
 #   e1 (fp32, 453 MB at the qkv shape): quad transposes + 16-byte non-temporal stores 384 us, plain 403, dword stores 440 (pp256: 405)
@@ -58,7 +59,7 @@ GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behin
 FX, FY = 32, 88                               # fragment sets: ah[mb] +4mb, al[mb] +16+4mb, wh[nb] +32+4nb, wl[nb] +44+4nb
 RA0, RA1, RW0, RW1 = 144, 145, 146, 147       # LDS read bases of the current stage (sub-step 0 / 1)
 DOA, DOW = 148, 152                           # LDS-DMA lane offsets: A pieces (<= 4), W pieces (<= 3)
-TLA, TL = 155, 156                            # tile-list address; entry (8 dwords)
+TLT = 156                                     # tile-list temporaries (wrap block)
 VOC, VOR, VOP, SEL = 164, 165, 166, 167       # lane offsets of C / R / plane stores, v_perm selector of the lane-pair exchange
 BIAS, KC2, L31, HALF = 168, 171, 172, 173
 T0, NTMP = 176, 40                            # temporaries 176..215
@@ -74,7 +75,8 @@ D_C, D_R, D_H, D_L = 88, 90, 92, 94           # drain bases (64-bit) of the park
 ROWA, ROWB, ROWC, ROWD = 16, 18, 20, 22       # row address pairs
 ST = 24                                       # scalar temporaries 24..29
 G_C0, G_C1 = 30, 31                           # GELU constants
-S_STG, S_NSTG2 = 34, 35                       # STAGE, -2 STAGE
+S_STG, S_NSTG2 = 34, 35                       # STAGE, -(NSTAGE - 1) STAGE
+S_TLI = 29                                    # index of the DMA cursor's tile in the workgroup's tile list (ST + 5)
 S_M1, S_M2 = 8, 10                            # lane masks (lane & 1), (lane & 2) of the quad transposes
 S_WDA, S_WDW, S_DSTA, S_DSTW = 12, 13, 14, 15  # this wave's row offset inside a stage's A / W planes; DMA destinations of this K tile
 
@@ -156,7 +158,7 @@ def y_order():
     return x_order()
 
 
-POST_BAR = ["TL0", "TL1"] + [f"X{k}{i}" for k, i in x_order()]
+POST_BAR = [f"X{k}{i}" for k, i in x_order()]
 
 
 def read_ins(setbase, kind, i, sub):
@@ -170,10 +172,23 @@ def read_ins(setbase, kind, i, sub):
 def dma_pieces():
     """LDS-DMA of the DMA cursor's K tile into stage S_DDST: NP (m0 write, copy) pairs"""
     L = []
+    ldmod = " nt" if "ldnt" in FLAGS else ""
     for plane, (pa, pw) in enumerate(((P_AH, P_WH), (P_AL, P_WL))):
         for j in range(PA_N):
-            L.append([f"s_add_u32 m0, {sr(S_DSTA)}, {plane * PA_B + j * 1024}", f"global_load_lds_dwordx4 {vr(DOA + j)}, {sr(pa, 2)}"])
+            if "onlyw" in FLAGS:
+                continue
+            if "areg" in FLAGS:
+                L.append(["s_nop 0", f"global_load_dwordx4 {vr(232 + 4 * ((plane * PA_N + j) % 6), 4)}, {vr(DOA + j)}, {sr(pa, 2)}"])
+                continue
+            L.append([f"s_add_u32 m0, {sr(S_DSTA)}, {plane * PA_B + j * 1024}", f"global_load_lds_dwordx4 {vr(DOA + j)}, {sr(pa, 2)}{ldmod}"])
         for j in range(PW_N):
+            if "onlya" in FLAGS:
+                continue
+            if "wreg" in FLAGS:          # (timing experiment: the W pieces as plain loads into registers instead of LDS-DMA)
+                L.append(["s_nop 0", f"global_load_dwordx4 {vr(232 + 4 * ((plane * PW_N + j) % 6), 4)}, {vr(DOW + j)}, {sr(pw, 2)}"])
+                continue
+            if "areg" in FLAGS:
+                pass
             L.append([f"s_add_u32 m0, {sr(S_DSTW)}, {2 * PA_B + plane * PW_B + j * 1024}", f"global_load_lds_dwordx4 {vr(DOW + j)}, {sr(pw, 2)}"])
     return L
 
@@ -183,20 +198,37 @@ def dma_dst_setup():
     return [f"s_add_u32 {sr(S_DSTA)}, {sr(S_DDST)}, {sr(S_WDA)}", f"s_add_u32 {sr(S_DSTW)}, {sr(S_DDST)}, {sr(S_WDW)}"]
 
 
+def tile_entry(dst):
+    """tile S_TLI of this workgroup's list -> DMA source bases + entry offsets {c, r, p, b} into s[dst..dst+3].  The list lives in TWO
+    VGPRs (entry i in lane i & 63 of %[tl0] / %[tl1]: tile_m << 16 | tile_n, written by the kernel's C++ prologue; entries past
+    the last tile repeat it - the DMA cursor runs ahead of the end)."""
+    t0, t1, t2 = ST, ST + 1, ST + 4
+    L = [f"s_and_b32 {sr(t2)}, {sr(S_TLI)}, {0 if 'sametile' in FLAGS else 63}", "s_nop 3",
+         f"v_readlane_b32 {sr(t0)}, %[tl0], {sr(t2)}", f"v_readlane_b32 {sr(t1)}, %[tl1], {sr(t2)}", "s_nop 4",
+         f"s_cmp_lt_u32 {sr(S_TLI)}, 64", f"s_cselect_b32 {sr(t0)}, {sr(t0)}, {sr(t1)}",
+         f"s_lshr_b32 {sr(t1)}, {sr(t0)}, 16", f"s_and_b32 {sr(t0)}, {sr(t0)}, 0xffff",           # t1 = tile_m, t0 = tile_n
+         f"s_mul_i32 {sr(t1)}, {sr(t1)}, {TM}", f"s_mul_i32 {sr(t0)}, {sr(t0)}, {TN}",             # m0, n0
+         # A / W planes: byte offsets of the tile's first rows
+         f"s_mul_i32 {sr(t2)}, {sr(t1)}, {sr(S_LDA)}", f"s_lshl_b32 {sr(t2)}, {sr(t2)}, 1",
+         f"s_add_u32 {sr(P_AH)}, {sr(S_AH)}, {sr(t2)}", f"s_addc_u32 {sr(P_AH + 1)}, {sr(S_AH + 1)}, 0",
+         f"s_add_u32 {sr(P_AL)}, {sr(S_AL)}, {sr(t2)}", f"s_addc_u32 {sr(P_AL + 1)}, {sr(S_AL + 1)}, 0",
+         f"s_mul_i32 {sr(t2)}, {sr(t0)}, {sr(S_LDW)}", f"s_lshl_b32 {sr(t2)}, {sr(t2)}, 1",
+         f"s_add_u32 {sr(P_WH)}, {sr(S_WH)}, {sr(t2)}", f"s_addc_u32 {sr(P_WH + 1)}, {sr(S_WH + 1)}, 0",
+         f"s_add_u32 {sr(P_WL)}, {sr(S_WL)}, {sr(t2)}", f"s_addc_u32 {sr(P_WL + 1)}, {sr(S_WL + 1)}, 0"]
+    for k, (ld, sh) in enumerate(((S_LDC, 2), (S_LDR, 2), (S_LDCP, 1))):                             # (m0 ld + n0) * element size
+        L += [f"s_mul_i32 {sr(t2)}, {sr(t1)}, {sr(ld)}", f"s_add_u32 {sr(t2)}, {sr(t2)}, {sr(t0)}", f"s_lshl_b32 {sr(dst + k)}, {sr(t2)}, {sh}"]
+    L.append(f"s_lshl_b32 {sr(dst + 3)}, {sr(t0)}, 2")
+    return L
+
+
 def advance_block(n):
-    """DMA cursor -> next K tile (wrap: next tile of the list, whose entry sits in TL since the previous body) + stage rotation"""
+    """DMA cursor -> next K tile (wrap: K tile 0 of the next tile of the list)"""
     L = [f"s_add_u32 {sr(S_KD)}, {sr(S_KD)}, 1", f"s_cmp_lt_u32 {sr(S_KD)}, {sr(S_NK)}", f"s_cbranch_scc1 L_adv_{n}",
-         f"s_mov_b32 {sr(S_KD)}, 0"]
-    for i in range(6):
-        L.append(f"v_readfirstlane_b32 {sr(ST + i if i < 2 else NXT + i - 2)}, {vr(TL + i)}")
-    L += ["s_nop 4",
-          f"s_add_u32 {sr(P_AH)}, {sr(S_AH)}, {sr(ST)}", f"s_addc_u32 {sr(P_AH + 1)}, {sr(S_AH + 1)}, 0",
-          f"s_add_u32 {sr(P_AL)}, {sr(S_AL)}, {sr(ST)}", f"s_addc_u32 {sr(P_AL + 1)}, {sr(S_AL + 1)}, 0",
-          f"s_add_u32 {sr(P_WH)}, {sr(S_WH)}, {sr(ST + 1)}", f"s_addc_u32 {sr(P_WH + 1)}, {sr(S_WH + 1)}, 0",
-          f"s_add_u32 {sr(P_WL)}, {sr(S_WL)}, {sr(ST + 1)}", f"s_addc_u32 {sr(P_WL + 1)}, {sr(S_WL + 1)}, 0",
-          f"v_add_u32 {vr(TLA)}, 32, {vr(TLA)}", f"s_branch L_advd_{n}", f"L_adv_{n}:"]
+         f"s_mov_b32 {sr(S_KD)}, 0", f"s_add_u32 {sr(S_TLI)}, {sr(S_TLI)}, 1"]
+    L += tile_entry(NXT)
+    L += [f"s_branch L_advd_{n}", f"L_adv_{n}:"]
     for p in (P_AH, P_AL, P_WH, P_WL):
-        L += [f"s_add_u32 {sr(p)}, {sr(p)}, 64", f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0"]
+        L += [f"s_add_u32 {sr(p)}, {sr(p)}, {128 if 'p128' in FLAGS else 64}", f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0"]
     L.append(f"L_advd_{n}:")
     return L
 
@@ -207,7 +239,7 @@ def rotate_dma_dst():
 
 
 def rotate_read_delta():
-    return [f"s_add_u32 {sr(S_CST)}, {sr(S_CST)}, 1", f"s_cmp_eq_u32 {sr(S_CST)}, 3", f"s_cselect_b32 {sr(S_CST)}, 0, {sr(S_CST)}",
+    return [f"s_add_u32 {sr(S_CST)}, {sr(S_CST)}, 1", f"s_cmp_eq_u32 {sr(S_CST)}, {NSTAGE}", f"s_cselect_b32 {sr(S_CST)}, 0, {sr(S_CST)}",
             f"s_cselect_b32 {sr(S_RDELTA)}, {sr(S_NSTG2)}, {sr(S_STG)}"]
 
 
@@ -550,7 +582,7 @@ def n_stores(d):
 body_n = [0]
 
 
-def body(kind, d=None, pred_post=0, prev_after=0):
+def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
     """kind: 'plain' | 'drain' (step d) | 'last'.  pred_post: VMEM ops the predecessor issued after its last DMA piece (minimum over
     the possible predecessors).  Returns the number of VMEM ops this body issues after its last DMA piece."""
     n = body_n[0]
@@ -593,7 +625,6 @@ def body(kind, d=None, pred_post=0, prev_after=0):
             e(it)
             return cost(it)
         if it[0] == "blk":
-            need_lg("TL1")
             for s in it[1]:
                 e(s)
             return 6 * ISSUE
@@ -645,7 +676,9 @@ def body(kind, d=None, pred_post=0, prev_after=0):
             # tile t+1 landed (this wave's pieces; DMA of tile t+2 and younger ops stay in flight), everybody past its reads of tile t-1
             flush_dma = [q for q in Q[pos[0]:] if not isinstance(q, str) and q[0] == "dma"]
             assert not flush_dma, "DMA pieces must be issued before the barrier slot"
-            nvm = pred_post + vm_issued[0]
+            # VMEM ops younger than the last piece of K tile t+1 (issued LOOK - 1 bodies ago): hist[j] = (all ops, ops after the
+            # last DMA piece) of the body j + 1 before this one, minimum over its possible predecessors
+            nvm = hist[LOOK - 2][1] + sum(hist[j][0] for j in range(LOOK - 2)) + vm_issued[0]
             e(f"s_waitcnt vmcnt({min(nvm, 63)})")
             e("s_waitcnt lgkmcnt(0)")           # (this wave's reads of the stage the next DMA overwrites: long complete)
             lg.wait_all()
@@ -653,10 +686,6 @@ def body(kind, d=None, pred_post=0, prev_after=0):
                 e("s_barrier")
             e(f"v_add_u32 {vr(RA0)}, {sr(S_RDELTA)}, {vr(RA0)}")
             e(f"v_add_u32 {vr(RW0)}, {sr(S_RDELTA)}, {vr(RW0)}")
-            e(f"ds_read_b128 {vr(TL, 4)}, {vr(TLA)}")
-            lg.issue("TL0")
-            e(f"ds_read_b128 {vr(TL + 4, 4)}, {vr(TLA)} offset:16")
-            lg.issue("TL1")
             xq = [("X", k, i) for k, i in x_order()]
         need_lg(f"{pre}{ka}{mb}")
         need_lg(f"{pre}{kb}{nb}")
@@ -698,8 +727,9 @@ def body(kind, d=None, pred_post=0, prev_after=0):
             _, pb = park_q.pop(0)
             for r in range(16):
                 e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
-        post += last_setup(emit_vm)
-    return post
+        last_setup(emit_vm)
+        post = vm_issued[0] - (dma_last[0] or 0)
+    return (vm_issued[0], post)
 
 
 def last_setup(emit_vm):
@@ -768,13 +798,17 @@ def prologue():
     e(f"v_xor_b32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
     e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                              # lc * 16
     e(f"v_lshrrev_b32 {vr(t1)}, 2, %[lane]")                               # rowl
+    if "p128" in FLAGS:                  # (timing experiment: pieces of 8 rows x 128 B - what a 64-deep K tile would fetch)
+        e(f"v_and_b32 {vr(t0)}, 7, %[lane]")
+        e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")
+        e(f"v_lshrrev_b32 {vr(t1)}, 3, %[lane]")
     for cnt, per, ld, dst in ((PA_N, 16 * MBW, S_LDA, DOA), (PW_N, 16 * NBW, S_LDW, DOW)):
         e(f"s_mul_i32 s94, %[wave], {per}")
         e(f"v_add_u32 {vr(t2)}, s94, {vr(t1)}")
         e(f"s_lshl_b32 s94, {sr(ld)}, 1")
         e(f"v_mul_lo_u32 {vr(t2)}, {vr(t2)}, s94")
         e(f"v_add_u32 {vr(dst)}, {vr(t2)}, {vr(t0)}")
-        e(f"s_lshl_b32 s94, {sr(ld)}, 5")                                  # 16 rows
+        e(f"s_lshl_b32 s94, {sr(ld)}, {4 if 'p128' in FLAGS else 5}")                                  # 16 rows
         for j in range(1, cnt):
             e(f"v_add_u32 {vr(dst + j)}, s94, {vr(dst + j - 1)}")
     if WIDE:
@@ -818,35 +852,26 @@ def prologue():
     e(f"s_mul_i32 {sr(W_B)}, s93, {32 * NBW * 4}")
     # loop state
     e(f"s_sub_u32 {sr(S_NKM1)}, {sr(S_NK)}, 1")
-    e(f"s_add_u32 {sr(S_LEND)}, %[ldsb], {3 * STAGE}")
+    e(f"s_add_u32 {sr(S_LEND)}, %[ldsb], {NSTAGE * STAGE}")
     e(f"s_mov_b32 {sr(S_TLEFT)}, %[ntiles]")
     e(f"s_mov_b32 {sr(S_KC)}, 0")
     e(f"s_mov_b32 {sr(S_CST)}, 0")
     e(f"s_mov_b32 {sr(S_RDELTA)}, {STAGE}")
     e(f"s_mov_b32 {sr(S_STG)}, {STAGE}")
-    e(f"s_mov_b32 {sr(S_NSTG2)}, {-2 * STAGE & 0xffffffff}")
+    e(f"s_mov_b32 {sr(S_NSTG2)}, {-(NSTAGE - 1) * STAGE & 0xffffffff}")
     for i in range(16 * NB):
         e(f"v_accvgpr_write_b32 a{i}, 0")
     # first tile entry
-    e(f"v_mov_b32 {vr(TLA)}, %[ldsb]")
-    e(f"v_add_u32 {vr(TLA)}, {TL_OFF}, {vr(TLA)}")
-    e(f"ds_read_b128 {vr(TL, 4)}, {vr(TLA)}")
-    e(f"ds_read_b128 {vr(TL + 4, 4)}, {vr(TLA)} offset:16")
-    e("s_waitcnt lgkmcnt(0)")
-    for i in range(6):
-        e(f"v_readfirstlane_b32 {sr(ST + i if i < 2 else CUR + i - 2)}, {vr(TL + i)}")
-    e("s_nop 4")
-    for p, a, o in ((P_AH, S_AH, ST), (P_AL, S_AL, ST), (P_WH, S_WH, ST + 1), (P_WL, S_WL, ST + 1)):
-        e(f"s_add_u32 {sr(p)}, {sr(a)}, {sr(o)}")
-        e(f"s_addc_u32 {sr(p + 1)}, {sr(a + 1)}, 0")
+    e(f"s_mov_b32 {sr(S_TLI)}, 0")
+    for x in tile_entry(CUR):
+        e(x)
     for i in range(4):
         e(f"s_mov_b32 {sr(NXT + i)}, {sr(CUR + i)}")
-    e(f"v_add_u32 {vr(TLA)}, 32, {vr(TLA)}")
     # K tiles 0 and 1
     e(f"s_mov_b32 {sr(S_DDST)}, %[ldsb]")
     e(f"s_mul_i32 {sr(S_WDA)}, %[wave], {MBW * 1024}")
     e(f"s_mul_i32 {sr(S_WDW)}, %[wave], {NBW * 1024}")
-    for kt in range(2):
+    for kt in range(LOOK):
         for s_ in dma_dst_setup():
             e(s_)
         for m0w, cp in dma_pieces():
@@ -855,15 +880,13 @@ def prologue():
             e(cp)
         for s in rotate_dma_dst():
             e(s)
-        if kt == 0:
+        if kt < LOOK - 1:
             for p in (P_AH, P_AL, P_WH, P_WL):
                 e(f"s_add_u32 {sr(p)}, {sr(p)}, 64")
                 e(f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0")
-    e(f"s_mov_b32 {sr(S_KD)}, 1")
-    e(f"s_waitcnt vmcnt({NP})")
+    e(f"s_mov_b32 {sr(S_KD)}, {LOOK - 1}")
+    e(f"s_waitcnt vmcnt({(LOOK - 1) * NP})")
     e("s_barrier")
-    e(f"ds_read_b128 {vr(TL, 4)}, {vr(TLA)}")
-    e(f"ds_read_b128 {vr(TL + 4, 4)}, {vr(TLA)} offset:16")
     for k, i in x_order():
         e(read_ins(FX, k, i, 0))
     e("s_branch L_plain")
@@ -951,23 +974,25 @@ def main():
     prologue()
     e3on = EPI == "e3" and "nodrain" not in FLAGS
     nst = lambda d: n_stores(d) if (e3on and "nostore" not in FLAGS) else 0   # stores of e3 step d (issued behind the loads of d + 1)
-    last_post = NBW + (n_loads(0) if e3on else 0)
+    pl = (NP, 0)                                         # a plain body: its DMA pieces only (the minimum any body issues)
+    last_info = (NP + NBW + (n_loads(0) if e3on else 0), NBW + (n_loads(0) if e3on else 0))
     e("L_drain:")
-    pp = last_post
-    posts = []
+    infos = []
     for d in range(NDRAIN):
-        pp = body("drain", d, pp, 0 if d == 0 else nst(d - 1))
-        posts.append(pp)
+        h1 = infos[d - 1] if d >= 1 else last_info
+        h2 = infos[d - 2] if d >= 2 else (last_info if d == 1 else pl)
+        infos.append(body("drain", d, (h1, h2), 0 if d == 0 else nst(d - 1)))
         e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
     e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
     e("s_cbranch_scc0 L_last")
     e("L_plain:")
-    body("plain", None, 0)
+    body("plain", None, (pl, pl))
     e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
     e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
     e("s_cbranch_scc1 L_plain")
     e("L_last:")
-    body("last", None, 0)
+    li = body("last", None, (pl, pl))
+    assert li == last_info, (li, last_info)
     e(f"s_mov_b32 {sr(S_KC)}, 0")
     e(f"s_sub_u32 {sr(S_TLEFT)}, {sr(S_TLEFT)}, 1")
     e(f"s_cmp_eq_u32 {sr(S_TLEFT)}, 0")
@@ -977,13 +1002,13 @@ def main():
     import re
     out[:] = [re.sub(r"\bL_\w+", lambda m: m.group(0) + "_%=", ln) for ln in out]
     nm = f"X4G_{CFG}_{EPI.upper()}"
-    clob = [f'"v{i}"' for i in range(32, 240)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(8, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
+    clob = [f'"v{i}"' for i in range(32, 256)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(8, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
     txt = (f"// GENERATED by tools/gen/gen_gemm_x4g.py {CFG} {EPI} - do not edit.\n"
-           f"// {len(out)} instructions; workgroup tile {TM} x {TN}, LDS {3 * STAGE + 16384} bytes\n"
+           f"// {len(out)} instructions; workgroup tile {TM} x {TN}, LDS {NSTAGE * STAGE} bytes ({NSTAGE} stages)\n"
            f"#define {nm}_BODY \\\n" + " \\\n".join('    "' + ln + '\\n\\t"' for ln in out) + "\n"
            f"#define {nm}_CLOBBERS " + ", ".join(clob) + "\n")
     open(OUT, "w").write(txt)
-    print(len(out), "instructions;", sum(1 for x in out if x.startswith("v_mfma")), "MFMAs; drain posts", posts)
+    print(len(out), "instructions;", sum(1 for x in out if x.startswith("v_mfma")), "MFMAs;", NSTAGE, "stages; drain (ops, post)", infos)
 
 
 if __name__ == "__main__":

@@ -58,7 +58,10 @@ def main():
     ops = HipOps("cuda:0")
     d = ops.device
     ok = True
-    for (M, N, K, form) in (SMALL if which == "small" else BIG):
+    shapes = SMALL if which == "small" else BIG
+    if "--only" in sys.argv:
+        shapes = [shapes[int(i)] for i in sys.argv[sys.argv.index("--only") + 1].split(",")]
+    for (M, N, K, form) in shapes:
         g = torch.Generator().manual_seed(M + 3 * N + 7 * K + form)
         A = torch.randn(M, K, generator=g).to(d)
         W = (torch.randn(N, K, generator=g) * 0.05).to(d)
