@@ -34,17 +34,23 @@ FLAGS = set(sys.argv[4:])
 MBW, NBW = int(CFG[0]), int(CFG[1])
 NB = MBW * NBW
 TM, TN = 64 * MBW, 64 * NBW
-PA_B, PW_B = TM * 64, TN * 64                 # bytes of one plane of a stage
+KSUB = int(os.environ.get("X4G_KSUB", 2 if CFG == "23" else 1))   # 32-deep sub-tiles per LDS stage: the 128 x 192 tile stages 64-deep K
+RBYTES = 64 * KSUB                              # tiles, so that an LDS-DMA piece is 8 rows x 128 B = FULL L2 lines (gpurun_out/r05_l_dma.txt:
+PA_B, PW_B = TM * RBYTES, TN * RBYTES             # the skeleton of the loop halves its time against 16 rows x 64 B); bytes of one plane of a stage
 STAGE = 2 * (PA_B + PW_B)
-NSTAGE = int(os.environ.get("X4G_NSTAGE", 160 * 1024 // STAGE if 160 * 1024 // STAGE < 4 else 4))   # LDS ring: 3 stages of 48 KiB (cfg 42), 4 of 40 KiB (cfg 23)
-LOOK = NSTAGE - 1                             # K tiles in flight ahead of the one being multiplied
-NSLOT = 6 * NB                                # MFMAs per K tile
+if KSUB == 2:
+    NSTAGE, LOOK, DMA_POST = 2, 2, True       # two 80 KiB stages; the DMA of K tile t+2 is issued BEHIND the barrier of body t (which frees its stage)
+else:
+    NSTAGE = int(os.environ.get("X4G_NSTAGE", min(4, 160 * 1024 // STAGE)))   # 3 stages of 48 KiB (cfg 42)
+    LOOK, DMA_POST = NSTAGE - 1, False        # K tiles in flight ahead of the one being multiplied; DMA issued at the top of a body
+NQ = 2 * KSUB                                 # 16-deep sub-steps of a body (fragment sets X, Y alternate)
+NSLOT = 3 * NB * NQ                           # MFMAs per body
 BAR_SLOT = (NSLOT * 3) // 4
-NDRAIN = 16                                   # drain steps = K tiles that carry one
-RP = MBW // 2                                 # row pairs (of 8 per block) per drain step
+NDRAIN = 16 // KSUB                           # bodies that carry a drain step
+RP = MBW // 2                                 # (narrow drain) row pairs (of 8 per block) per step, 16 steps
 STEPS_PER_MB = 8 // RP
-PA_N, PW_N = MBW, NBW                         # LDS-DMA pieces per plane and wave (16 rows x 64 B each)
-NP = 2 * ((0 if 'onlyw' in FLAGS else PA_N) + (0 if 'onlya' in FLAGS else PW_N))   # pieces per wave and K tile
+PA_N, PW_N = MBW * KSUB, NBW * KSUB           # LDS-DMA pieces (1 KiB) per plane, wave and body
+NP = 2 * ((0 if 'onlyw' in FLAGS else PA_N) + (0 if 'onlya' in FLAGS else PW_N))   # pieces per wave and body
 ISSUE = int(os.environ.get("X4G_ISSUE", 4))
 # form of the drain per epilogue, measured in one call (gpurun_out/r05_f_stores.txt; X4G_WIDE / X4G_STMOD override for A/B builds):
 #   e1 (fp32, 453 MB at the qkv shape): quad transposes + 16-byte non-temporal stores 384 us, plain 403, dword stores 440 (pp256: 405)
@@ -57,13 +63,14 @@ GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behin
 
 # VGPR map (v0..v31 are left to the compiler)
 FX, FY = 32, 88                               # fragment sets: ah[mb] +4mb, al[mb] +16+4mb, wh[nb] +32+4nb, wl[nb] +44+4nb
-RA0, RA1, RW0, RW1 = 144, 145, 146, 147       # LDS read bases of the current stage (sub-step 0 / 1)
-DOA, DOW = 148, 152                           # LDS-DMA lane offsets: A pieces (<= 4), W pieces (<= 3)
+RA, RW = 144, 148                             # LDS read bases of the current stage, one per sub-step (<= 4 each)
+DOA, DOW = 152, 156                           # LDS-DMA lane offsets: A pieces (<= 4), W pieces (<= 6)
 TLT = 156                                     # tile-list temporaries (wrap block)
 VOC, VOR, VOP, SEL = 164, 165, 166, 167       # lane offsets of C / R / plane stores, v_perm selector of the lane-pair exchange
 BIAS, KC2, L31, HALF = 168, 171, 172, 173
 T0, NTMP = 176, 40                            # temporaries 176..215
-RBUF = 216                                    # e3: two sets of residual values (216..231), loaded one drain step ahead
+RBUF = 216                                    # e3: two sets of residual values, loaded one drain step ahead
+RS = 12 if KSUB == 2 else 8                   # registers of a set
 # SGPR map (s32 / s33 and s96.. are reserved by the compiler; s0..s15 are left to it)
 S_AH, S_AL, S_WH, S_WL, S_BIAS, S_C, S_R, S_CH, S_CL = 36, 38, 40, 42, 44, 46, 48, 50, 52
 S_LDA, S_LDW, S_LDC, S_LDR, S_LDCP, S_NK = 54, 55, 56, 57, 58, 59
@@ -161,10 +168,10 @@ def y_order():
 POST_BAR = [f"X{k}{i}" for k, i in x_order()]
 
 
-def read_ins(setbase, kind, i, sub):
-    base = {("a", 0): RA0, ("a", 1): RA1, ("w", 0): RW0, ("w", 1): RW1}[(kind[0], sub)]
+def read_ins(setbase, kind, i, q):
+    base = (RA if kind[0] == "a" else RW) + q
     plane = 1 if kind[1] == "l" else 0
-    off = i * 2048 + plane * (PA_B if kind[0] == "a" else PW_B)
+    off = i * 32 * RBYTES + plane * (PA_B if kind[0] == "a" else PW_B)
     return f"ds_read_b128 {frag(setbase, kind, i)}, {vr(base)} offset:{off}"
 
 
@@ -228,7 +235,7 @@ def advance_block(n):
     L += tile_entry(NXT)
     L += [f"s_branch L_advd_{n}", f"L_adv_{n}:"]
     for p in (P_AH, P_AL, P_WH, P_WL):
-        L += [f"s_add_u32 {sr(p)}, {sr(p)}, {128 if 'p128' in FLAGS else 64}", f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0"]
+        L += [f"s_add_u32 {sr(p)}, {sr(p)}, {128 if 'p128' in FLAGS else 64 * KSUB}", f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0"]
     L.append(f"L_advd_{n}:")
     return L
 
@@ -332,7 +339,7 @@ class Drain:
             pair = ROWC if i % 2 == 0 else ROWD
             L += [f"s_mul_i32 {sr(ST + 4)}, {sr(S_LDR)}, {(mb * 32 + 8 * g) * 4}", f"s_add_u32 {sr(pair)}, {sr(D_R)}, {sr(ST + 4)}",
                   f"s_addc_u32 {sr(pair + 1)}, {sr(D_R + 1)}, 0"]
-            L.append(("vm", f"global_load_dwordx4 {vr(RBUF + (d % 2) * 8 + i * 4, 4)}, {vr(VOR)}, {sr(pair, 2)} offset:{nb * 128}", f"Rstep{d}"))
+            L.append(("vm", f"global_load_dwordx4 {vr(RBUF + (d % 2) * RS + i * 4, 4)}, {vr(VOR)}, {sr(pair, 2)} offset:{nb * 128}", f"Rstep{d}"))
         return L
 
     def e3(self, units):
@@ -347,7 +354,7 @@ class Drain:
             self.read_bias(t, mb, g, nb)
             self.transpose4(t)
             for k in range(4):
-                self.add(f"v_add_f32 {vr(t + k)}, {vr(t + k)}, {vr(RBUF + (d % 2) * 8 + i * 4 + k)}")
+                self.add(f"v_add_f32 {vr(t + k)}, {vr(t + k)}, {vr(RBUF + (d % 2) * RS + i * 4 + k)}")
             self.store(4, VOC, t, pair, nb * 128)
 
     def gelu4(self, x):
@@ -560,13 +567,18 @@ class DrainNarrow:
 
 
 
-WIDE = os.environ.get("X4G_WIDE", _DEF_WIDE) != "0"
+WIDE = os.environ.get("X4G_WIDE", "1" if (KSUB == 2 and EPI != "e2") else _DEF_WIDE) != "0"
 
 
 def drain_items(d):
     if "nodrain" in FLAGS:
         return []
-    return (Drain(d) if WIDE else DrainNarrow(d)).F
+    if WIDE:
+        return Drain(d).F
+    if KSUB == 2:                        # a 64-deep body carries two of the 16 narrow steps (e2 only: no state between steps)
+        assert EPI == "e2"
+        return DrainNarrow(2 * d).F + DrainNarrow(2 * d + 1).F
+    return DrainNarrow(d).F
 
 
 def n_loads(d):
@@ -583,8 +595,9 @@ body_n = [0]
 
 
 def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
-    """kind: 'plain' | 'drain' (step d) | 'last'.  pred_post: VMEM ops the predecessor issued after its last DMA piece (minimum over
-    the possible predecessors).  Returns the number of VMEM ops this body issues after its last DMA piece."""
+    """kind: 'plain' | 'drain' (step d) | 'last'.  hist[j] = (VMEM ops, VMEM ops after the last DMA piece) of the body j + 1 before
+    this one (minimum over its possible predecessors); prev_after: VMEM ops the previous body issued after the residual loads it
+    issued for this step (e3).  Returns this body's (VMEM ops, VMEM ops after its last DMA piece)."""
     n = body_n[0]
     body_n[0] += 1
     lg = Stream(POST_BAR)
@@ -602,18 +615,23 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
         if c is not None:
             e(f"s_waitcnt lgkmcnt({min(c, 15)})")
 
-    # --- filler queue: [advance block] [DMA pieces + dst rotation] [read-delta rotation] [drain step]
-    Q = []
-    Q.append(("blk", advance_block(n)))
-    Q += dma_dst_setup()
+    # --- filler queues.  DMA block: [cursor advance] [destinations] [pieces] [stage rotation]; with DMA_POST it is queued at the
+    #     barrier slot (the barrier frees the stage it overwrites), else at the top of the body.
+    Qdma = [("blk", advance_block(n))] + dma_dst_setup()
     if "nodma" not in FLAGS:
         for m0w, cp in dma_pieces():
-            Q.append(m0w)
-            Q.append(("dma", cp))
-    Q += rotate_dma_dst() + rotate_read_delta()
+            Qdma.append(m0w)
+            Qdma.append(("dma", cp))
+    Qdma += rotate_dma_dst()
+    Q = []
+    if kind == "last" and DMA_POST:
+        Q += last_setup()                    # (older than this body's DMA pieces: the next body waits for them with the pieces in flight)
+    if not DMA_POST:
+        Q += Qdma
+    Q += rotate_read_delta()
     if kind == "drain":
         if d == 0:
-            Q.append(("waitvm_older",))      # the bias loads of `last` (older than everything this body issued)
+            Q.append(("waitvm_setup",))      # the bias (+ residual) loads of `last`
         Q += drain_items(d)
     pos = [0]
     debt = [0.0]
@@ -643,8 +661,8 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
         if it[0] == "needprev":              # the loads the previous body issued for this step (it issued prev_after VMEM ops after them)
             e(f"s_waitcnt vmcnt({min(prev_after + vm_issued[0], 63)})")
             return ISSUE
-        if it[0] == "waitvm_older":
-            e(f"s_waitcnt vmcnt({min(vm_issued[0], 63)})")
+        if it[0] == "waitvm_setup":          # `last` issued its set-up loads before (DMA_POST) / after its NP DMA pieces
+            e(f"s_waitcnt vmcnt({min((NP if DMA_POST else 0) + vm_issued[0], 63)})")
             return ISSUE
         raise ValueError(it)
 
@@ -657,48 +675,53 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
         while pos[0] < len(Q):
             emit_one()
 
-    # --- MFMA slots
-    def sub_slots(setbase, block_major):
+    # --- MFMA slots: NQ sub-steps of 3 NB MFMAs; sub-step q multiplies fragment set X (q even) / Y (q odd)
+    def sub_slots(q, block_major):
+        setbase = FX if q % 2 == 0 else FY
         terms = [("al", "wh"), ("ah", "wl"), ("ah", "wh")]
         blocks = [(mb, nb) for mb in range(MBW) for nb in range(NBW)]
         if block_major:
-            return [(mb, nb, ka, kb, setbase) for mb, nb in blocks for ka, kb in terms]
-        return [(mb, nb, ka, kb, setbase) for ka, kb in terms for mb, nb in blocks]
+            return [(mb, nb, ka, kb, setbase, q) for mb, nb in blocks for ka, kb in terms]
+        return [(mb, nb, ka, kb, setbase, q) for ka, kb in terms for mb, nb in blocks]
 
-    slots = sub_slots(FX, False) + sub_slots(FY, kind == "last")
-    yq = [("Y", k, i) for k, i in y_order()]
+    slots = []
+    for q in range(NQ):
+        slots += sub_slots(q, kind == "last" and q == NQ - 1)
+    rq = {q: list(y_order()) for q in range(1, NQ)}      # fragment reads of sub-step q, issued behind the MFMAs of sub-step q - 1
     xq = None
     park_q = []              # (slot index after which block b may be parked)
     first = kind == "drain" and d == 0
-    for si, (mb, nb, ka, kb, sb) in enumerate(slots):
+    for si, (mb, nb, ka, kb, sb, q) in enumerate(slots):
         pre = "X" if sb == FX else "Y"
         if si == BAR_SLOT:
-            # tile t+1 landed (this wave's pieces; DMA of tile t+2 and younger ops stay in flight), everybody past its reads of tile t-1
-            flush_dma = [q for q in Q[pos[0]:] if not isinstance(q, str) and q[0] == "dma"]
-            assert not flush_dma, "DMA pieces must be issued before the barrier slot"
-            # VMEM ops younger than the last piece of K tile t+1 (issued LOOK - 1 bodies ago): hist[j] = (all ops, ops after the
-            # last DMA piece) of the body j + 1 before this one, minimum over its possible predecessors
+            # K tile t+1 landed (this wave's pieces; younger VMEM ops stay in flight), everybody past its reads of this stage's
+            # predecessor.  VMEM ops younger than the last piece of K tile t+1 (issued LOOK - 1 bodies ago):
+            if not DMA_POST:
+                assert not [x for x in Q[pos[0]:] if not isinstance(x, str) and x[0] == "dma"], "DMA pieces must precede the barrier slot"
             nvm = hist[LOOK - 2][1] + sum(hist[j][0] for j in range(LOOK - 2)) + vm_issued[0]
             e(f"s_waitcnt vmcnt({min(nvm, 63)})")
-            e("s_waitcnt lgkmcnt(0)")           # (this wave's reads of the stage the next DMA overwrites: long complete)
+            e("s_waitcnt lgkmcnt(0)")           # (this wave's reads of the stage the next DMA overwrites)
             lg.wait_all()
             if "nobarrier" not in FLAGS:
                 e("s_barrier")
-            e(f"v_add_u32 {vr(RA0)}, {sr(S_RDELTA)}, {vr(RA0)}")
-            e(f"v_add_u32 {vr(RW0)}, {sr(S_RDELTA)}, {vr(RW0)}")
+            e(f"v_add_u32 {vr(RA)}, {sr(S_RDELTA)}, {vr(RA)}")
+            e(f"v_add_u32 {vr(RW)}, {sr(S_RDELTA)}, {vr(RW)}")
             xq = [("X", k, i) for k, i in x_order()]
+            if DMA_POST:
+                Q[pos[0]:pos[0]] = Qdma
         need_lg(f"{pre}{ka}{mb}")
         need_lg(f"{pre}{kb}{nb}")
         b = mb * NBW + nb
-        c = "0" if (first and sb == FX and (ka, kb) == ("al", "wh")) else acc(b)
+        c = "0" if (first and q == 0 and (ka, kb) == ("al", "wh")) else acc(b)
         if "nomfma" not in FLAGS:
             e(f"v_mfma_f32_32x32x16_bf16 {acc(b)}, {frag(sb, ka, mb)}, {frag(sb, kb, nb)}, {c}")
         spent = 0
-        if yq and si < BAR_SLOT:
-            _, k, i = yq.pop(0)
+        if q + 1 < NQ and rq[q + 1]:
+            k, i = rq[q + 1].pop(0)
+            nset, npre = (FY, "Y") if (q + 1) % 2 else (FX, "X")
             if "noread" not in FLAGS:
-                e(read_ins(FY, k, i, 1))
-            lg.issue(f"Y{k}{i}")
+                e(read_ins(nset, k, i, q + 1))
+            lg.issue(f"{npre}{k}{i}")
             spent += ISSUE
         if xq:
             for _ in range(2 if len(xq) > (NSLOT - 1 - si) else 1):
@@ -708,7 +731,7 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
                         e(read_ins(FX, k, i, 0))
                     lg.issue(f"X{k}{i}")
                     spent += ISSUE
-        if kind == "last" and sb == FY and (ka, kb) == ("ah", "wh"):
+        if kind == "last" and q == NQ - 1 and (ka, kb) == ("ah", "wh"):
             park_q.append((si + 3, b))          # three more MFMAs (>= 96 cycles) before the block's accumulators are read
         while park_q and park_q[0][0] <= si:
             _, pb = park_q.pop(0)
@@ -716,49 +739,43 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
                 e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
             spent += 16 * ISSUE
         fill(GAP - spent)
-    assert not yq and not xq, (yq, xq)
+    assert not xq and not any(rq.values()), (xq, rq)
     flush()
-    e(f"v_add_u32 {vr(RA1)}, {sr(S_RDELTA)}, {vr(RA1)}")
-    e(f"v_add_u32 {vr(RW1)}, {sr(S_RDELTA)}, {vr(RW1)}")
-    post = vm_issued[0] - (dma_last[0] or 0)
+    for q in range(1, NQ):
+        e(f"v_add_u32 {vr(RA + q)}, {sr(S_RDELTA)}, {vr(RA + q)}")
+        e(f"v_add_u32 {vr(RW + q)}, {sr(S_RDELTA)}, {vr(RW + q)}")
     if kind == "last":
         e("s_nop 15")
         while park_q:
             _, pb = park_q.pop(0)
             for r in range(16):
                 e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
-        last_setup(emit_vm)
-        post = vm_issued[0] - (dma_last[0] or 0)
-    return (vm_issued[0], post)
+        if not DMA_POST:
+            Q[:] = last_setup()
+            pos[0] = 0
+            flush()
+    return (vm_issued[0], vm_issued[0] - (dma_last[0] or 0))
 
 
-def last_setup(emit_vm):
-    """after parking: drain bases and bias of the parked tile (CUR), CUR <- NXT"""
+def last_setup():
+    """drain bases and bias (+ the residual loads of step 0) of the tile this body parks (CUR), CUR <- NXT: item list"""
+    L = []
     for base, arg, off in ((D_C, S_C, CUR), (D_R, S_R, CUR + 1), (D_H, S_CH, CUR + 2), (D_L, S_CL, CUR + 2)):
         wv = {CUR: W_C, CUR + 1: W_R, CUR + 2: W_P}[off]
         if "stsame" in FLAGS:                  # (timing experiment: every tile's result goes to the first tile's place)
-            e(f"s_mov_b32 {sr(ST)}, {sr(wv)}")
+            L.append(f"s_mov_b32 {sr(ST)}, {sr(wv)}")
         else:
-            e(f"s_add_u32 {sr(ST)}, {sr(off)}, {sr(wv)}")
-        e(f"s_add_u32 {sr(base)}, {sr(arg)}, {sr(ST)}")
-        e(f"s_addc_u32 {sr(base + 1)}, {sr(arg + 1)}, 0")
-    e(f"s_add_u32 {sr(ST)}, {sr(CUR + 3)}, {sr(W_B)}")
-    e(f"s_add_u32 {sr(ROWA)}, {sr(S_BIAS)}, {sr(ST)}")
-    e(f"s_addc_u32 {sr(ROWA + 1)}, {sr(S_BIAS + 1)}, 0")
-    e(f"v_lshlrev_b32 {vr(T0)}, 2, {vr(L31)}")
+            L.append(f"s_add_u32 {sr(ST)}, {sr(off)}, {sr(wv)}")
+        L += [f"s_add_u32 {sr(base)}, {sr(arg)}, {sr(ST)}", f"s_addc_u32 {sr(base + 1)}, {sr(arg + 1)}, 0"]
+    L += [f"s_add_u32 {sr(ST)}, {sr(CUR + 3)}, {sr(W_B)}", f"s_add_u32 {sr(ROWA)}, {sr(S_BIAS)}, {sr(ST)}",
+          f"s_addc_u32 {sr(ROWA + 1)}, {sr(S_BIAS + 1)}, 0", f"v_lshlrev_b32 {vr(T0)}, 2, {vr(L31)}"]
     for nb in range(NBW):
-        emit_vm(f"global_load_dword {vr(BIAS + nb)}, {vr(T0)}, {sr(ROWA, 2)} offset:{nb * 128}", "bias")
-    n = NBW
+        L.append(("vm", f"global_load_dword {vr(BIAS + nb)}, {vr(T0)}, {sr(ROWA, 2)} offset:{nb * 128}", "bias"))
     if EPI == "e3" and "nodrain" not in FLAGS:
-        for it in (Drain if WIDE else DrainNarrow).e3_loads(0):
-            if isinstance(it, str):
-                e(it)
-            else:
-                emit_vm(it[1], it[2])
-                n += 1
+        L += (Drain if WIDE else DrainNarrow).e3_loads(0)
     for i in range(4):
-        e(f"s_mov_b32 {sr(CUR + i)}, {sr(NXT + i)}")
-    return n
+        L.append(f"s_mov_b32 {sr(CUR + i)}, {sr(NXT + i)}")
+    return L
 
 
 # ------------------------------------------------------------------------------------------------ prologue / tail
@@ -776,41 +793,55 @@ def prologue():
     e(f"v_lshrrev_b32 {vr(HALF)}, 5, %[lane]")
     e("s_lshr_b32 s92, %[wave], 1")          # wm
     e("s_and_b32 s93, %[wave], 1")           # wn
-    # LDS read bases
-    e(f"v_lshrrev_b32 {vr(t0)}, 2, {vr(L31)}")
-    e(f"v_and_b32 {vr(t0)}, 3, {vr(t0)}")                                  # sw
-    e(f"s_mul_i32 s94, s92, {2048 * MBW}")
+    # LDS read bases: row (wave row 32 MBW wm + l31) x RBYTES + (chunk ^ swizzle) x 16, chunk = 2 q + half of sub-step q; the swizzle is
+    # (row >> 2) & 3 on 64-byte rows, (row >> 1) & 7 on 128-byte rows (conflict-free over the 16-lane groups of ds_read_b128)
+    e(f"v_lshrrev_b32 {vr(t0)}, {2 if KSUB == 1 else 1}, {vr(L31)}")
+    e(f"v_and_b32 {vr(t0)}, {3 if KSUB == 1 else 7}, {vr(t0)}")            # sw
+    e(f"s_mul_i32 s94, s92, {32 * MBW * RBYTES}")
     e("s_add_u32 s94, s94, %[ldsb]")
-    e(f"s_mul_i32 s95, s93, {2048 * NBW}")
+    e(f"s_mul_i32 s95, s93, {32 * NBW * RBYTES}")
     e("s_add_u32 s95, s95, %[ldsb]")
     e(f"s_add_u32 s95, s95, {2 * PA_B}")
-    e(f"v_lshlrev_b32 {vr(t1)}, 6, {vr(L31)}")
-    for s, (ra, rw) in enumerate(((RA0, RW0), (RA1, RW1))):
-        e(f"v_or_b32 {vr(t2)}, {2 * s}, {vr(HALF)}")
+    e(f"v_lshlrev_b32 {vr(t1)}, {6 if KSUB == 1 else 7}, {vr(L31)}")
+    for q in range(NQ):
+        e(f"v_or_b32 {vr(t2)}, {2 * q}, {vr(HALF)}")
         e(f"v_xor_b32 {vr(t2)}, {vr(t2)}, {vr(t0)}")
         e(f"v_lshl_add_u32 {vr(t2)}, {vr(t2)}, 4, {vr(t1)}")
-        e(f"v_add_u32 {vr(ra)}, s94, {vr(t2)}")
-        e(f"v_add_u32 {vr(rw)}, s95, {vr(t2)}")
-    # LDS-DMA lane offsets: row = wave * 16 MBW + 16 j + (lane >> 2), chunk lc = (lane & 3) ^ ((lane >> 4) & 3)
-    e(f"v_lshrrev_b32 {vr(t0)}, 4, %[lane]")
-    e(f"v_and_b32 {vr(t0)}, 3, {vr(t0)}")
-    e(f"v_and_b32 {vr(t1)}, 3, %[lane]")
-    e(f"v_xor_b32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
-    e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                              # lc * 16
-    e(f"v_lshrrev_b32 {vr(t1)}, 2, %[lane]")                               # rowl
-    if "p128" in FLAGS:                  # (timing experiment: pieces of 8 rows x 128 B - what a 64-deep K tile would fetch)
-        e(f"v_and_b32 {vr(t0)}, 7, %[lane]")
-        e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")
+        e(f"v_add_u32 {vr(RA + q)}, s94, {vr(t2)}")
+        e(f"v_add_u32 {vr(RW + q)}, s95, {vr(t2)}")
+    # LDS-DMA lane offsets.  64-byte rows: a piece is 16 rows x 64 B, lane -> (row lane >> 2, chunk (lane & 3) ^ ((lane >> 4) & 3)).
+    # 128-byte rows: 8 rows x 128 B = full L2 lines, lane -> (row lane >> 3, chunk (lane & 7) ^ ((row >> 1) & 7)); the pieces of a wave
+    # start at multiples of 8 rows and their count per wave is even, so (row >> 1) & 7 = (4 (j & 1) + (lane >> 4)) & 7 for piece j
+    if KSUB == 1:
+        e(f"v_lshrrev_b32 {vr(t0)}, 4, %[lane]")
+        e(f"v_and_b32 {vr(t0)}, 3, {vr(t0)}")
+        e(f"v_and_b32 {vr(t1)}, 3, %[lane]")
+        e(f"v_xor_b32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
+        e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                          # chunk * 16
+        e(f"v_lshrrev_b32 {vr(t1)}, 2, %[lane]")                           # row in the piece
+        if "p128" in FLAGS:              # (timing experiment: pieces of 8 rows x 128 B - what a 64-deep K tile would fetch)
+            e(f"v_and_b32 {vr(t0)}, 7, %[lane]")
+            e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")
+            e(f"v_lshrrev_b32 {vr(t1)}, 3, %[lane]")
+    else:
+        assert PA_N % 2 == 0 and PW_N % 2 == 0
+        e(f"v_lshrrev_b32 {vr(t0)}, 4, %[lane]")
+        e(f"v_and_b32 {vr(t1)}, 7, %[lane]")
+        e(f"v_xor_b32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
+        e(f"v_lshlrev_b32 {vr(t0)}, 4, {vr(t0)}")                          # chunk * 16 of the even pieces (odd pieces: ^ 64)
         e(f"v_lshrrev_b32 {vr(t1)}, 3, %[lane]")
-    for cnt, per, ld, dst in ((PA_N, 16 * MBW, S_LDA, DOA), (PW_N, 16 * NBW, S_LDW, DOW)):
-        e(f"s_mul_i32 s94, %[wave], {per}")
+    rows_pp = 8 if (KSUB == 2 or "p128" in FLAGS) else 16
+    for cnt, ld, dst in ((PA_N, S_LDA, DOA), (PW_N, S_LDW, DOW)):
+        e(f"s_mul_i32 s94, %[wave], {cnt * (16 // KSUB)}")
         e(f"v_add_u32 {vr(t2)}, s94, {vr(t1)}")
         e(f"s_lshl_b32 s94, {sr(ld)}, 1")
         e(f"v_mul_lo_u32 {vr(t2)}, {vr(t2)}, s94")
         e(f"v_add_u32 {vr(dst)}, {vr(t2)}, {vr(t0)}")
-        e(f"s_lshl_b32 s94, {sr(ld)}, {4 if 'p128' in FLAGS else 5}")                                  # 16 rows
+        e(f"s_mul_i32 s94, {sr(ld)}, {2 * rows_pp}")                       # one piece further down
         for j in range(1, cnt):
             e(f"v_add_u32 {vr(dst + j)}, s94, {vr(dst + j - 1)}")
+            if KSUB == 2:
+                e(f"v_xor_b32 {vr(dst + j)}, 64, {vr(dst + j)}")
     if WIDE:
         # store lane offsets (layout AFTER the quad transposes): lane -> row 4 half + (l31 & 3), columns (l31 & 28) .. + 3
         e(f"v_and_b32 {vr(t0)}, 3, {vr(L31)}")
@@ -869,8 +900,8 @@ def prologue():
         e(f"s_mov_b32 {sr(NXT + i)}, {sr(CUR + i)}")
     # K tiles 0 and 1
     e(f"s_mov_b32 {sr(S_DDST)}, %[ldsb]")
-    e(f"s_mul_i32 {sr(S_WDA)}, %[wave], {MBW * 1024}")
-    e(f"s_mul_i32 {sr(S_WDW)}, %[wave], {NBW * 1024}")
+    e(f"s_mul_i32 {sr(S_WDA)}, %[wave], {PA_N * 1024}")
+    e(f"s_mul_i32 {sr(S_WDW)}, %[wave], {PW_N * 1024}")
     for kt in range(LOOK):
         for s_ in dma_dst_setup():
             e(s_)
@@ -882,7 +913,7 @@ def prologue():
             e(s)
         if kt < LOOK - 1:
             for p in (P_AH, P_AL, P_WH, P_WL):
-                e(f"s_add_u32 {sr(p)}, {sr(p)}, 64")
+                e(f"s_add_u32 {sr(p)}, {sr(p)}, {64 * KSUB}")
                 e(f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0")
     e(f"s_mov_b32 {sr(S_KD)}, {LOOK - 1}")
     e(f"s_waitcnt vmcnt({(LOOK - 1) * NP})")
@@ -975,13 +1006,15 @@ def main():
     e3on = EPI == "e3" and "nodrain" not in FLAGS
     nst = lambda d: n_stores(d) if (e3on and "nostore" not in FLAGS) else 0   # stores of e3 step d (issued behind the loads of d + 1)
     pl = (NP, 0)                                         # a plain body: its DMA pieces only (the minimum any body issues)
-    last_info = (NP + NBW + (n_loads(0) if e3on else 0), NBW + (n_loads(0) if e3on else 0))
+    nset = NBW + (n_loads(0) if e3on else 0)             # set-up loads of `last` (bias, residual values of step 0)
+    last_info = (NP + nset, 0 if DMA_POST else nset)     # (DMA_POST: they are issued before its DMA pieces)
+    after = lambda d: (NP if DMA_POST else 0) + (nst(d - 1) if d else 0)   # VMEM ops a body issues behind the residual loads of step d
     e("L_drain:")
     infos = []
     for d in range(NDRAIN):
         h1 = infos[d - 1] if d >= 1 else last_info
         h2 = infos[d - 2] if d >= 2 else (last_info if d == 1 else pl)
-        infos.append(body("drain", d, (h1, h2), 0 if d == 0 else nst(d - 1)))
+        infos.append(body("drain", d, (h1, h2), after(d)))
         e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
     e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
     e("s_cbranch_scc0 L_last")
@@ -1004,6 +1037,7 @@ def main():
     nm = f"X4G_{CFG}_{EPI.upper()}"
     clob = [f'"v{i}"' for i in range(32, 256)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(8, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
     txt = (f"// GENERATED by tools/gen/gen_gemm_x4g.py {CFG} {EPI} - do not edit.\n"
+           f"#define X4G_{CFG}_LDS_BYTES {NSTAGE * STAGE}\n#define X4G_{CFG}_KTILE {32 * KSUB}\n#define X4G_{CFG}_MIN_NK {NDRAIN + 1}\n"
            f"// {len(out)} instructions; workgroup tile {TM} x {TN}, LDS {NSTAGE * STAGE} bytes ({NSTAGE} stages)\n"
            f"#define {nm}_BODY \\\n" + " \\\n".join('    "' + ln + '\\n\\t"' for ln in out) + "\n"
            f"#define {nm}_CLOBBERS " + ", ".join(clob) + "\n")
