@@ -59,6 +59,7 @@ ISSUE = int(os.environ.get("X4G_ISSUE", 4))
 _DEF_WIDE, _DEF_STMOD = {"e1": ("1", "nt"), "e2": ("0", ""), "e3": ("0", "nt")}[EPI]
 _stmod = os.environ.get("X4G_STMOD", _DEF_STMOD)
 STMOD = (" " + _stmod) if _stmod and _stmod != "none" else ""      # cache policy of the result stores (nt | sc1 | sc0 sc1 | none)
+STDEFER = os.environ.get("X4G_STDEFER", "0") == "1"
 GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
 
 # VGPR map (v0..v31 are left to the compiler)
@@ -632,7 +633,13 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
     if kind == "drain":
         if d == 0:
             Q.append(("waitvm_setup",))      # the bias (+ residual) loads of `last`
-        Q += drain_items(d)
+        items = drain_items(d)
+        if STDEFER and DMA_POST and WIDE:
+            # the result stores of this step are issued BEHIND this body's DMA pieces: the next barrier then waits for K tile t+2 with
+            # them still in flight (in-order VMEM completion: a store issued before the pieces would have to retire within one body)
+            Qdma += [it for it in items if not isinstance(it, str) and it[0] == "vm" and it[2] == "st"]
+            items = [it for it in items if isinstance(it, str) or not (it[0] == "vm" and it[2] == "st")]
+        Q += items
     pos = [0]
     debt = [0.0]
 

@@ -1,0 +1,3 @@
+for v in k_d0 k_nodrain k_nomfma k_nobar k_noread; do
+  echo "=== $v"; DS2_LIB=det-sam2_amd/lib/ab_$v.so timeout 300 python tools/x4g_check.py big 5 --nocheck --only 0,1,2,3 2>&1 | grep -v amdgpu.ids | sed -e 's/bit-identical //g' | cut -c1-330
+done
