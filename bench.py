@@ -63,7 +63,7 @@ def committed_pmc_traffic(kernel_key, B, nk, precision):
     source file).  None if no committed file matches this workload."""
     if B != 16 or nk != 28736 or precision != "bf16x3k":
         return None
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -71,7 +71,8 @@ def committed_pmc_traffic(kernel_key, B, nk, precision):
             d = json.load(f)
         if kernel_key in d:
             return {"bytes_per_launch": float(d[kernel_key]["traffic_bytes_per_launch"]), "source": f"profiles/{name}",
-                    "algorithmic_bytes": d[kernel_key].get("algorithmic_bytes")}
+                    # (the PMC file prices the MAIN kernel of the launch only - k_attention_x4a without its query pre-pass and merge)
+                    "algorithmic_bytes_of_that_kernel": d[kernel_key].get("algorithmic_bytes")}
         if kernel_key == "cross_attention" and "traffic_bytes_per_launch" in d:
             return {"bytes_per_launch": float(d["traffic_bytes_per_launch"]), "source": f"profiles/{name}"}
     return None
@@ -346,13 +347,22 @@ def bench_sharded(a, pred, cfg, world, rank, dev):
                        "round_time_split_s_by_rank": [{k: round(float(v), 4) for k, v in zip(names, x.tolist())} for x in sp_all],
                        "encoder_runs_per_round_all_ranks": float(tsum[2].item()), "new_frames_per_round": per_round},
             "stream_fps": per_round / dt,
-            "roofline": {"bound": "mfma", "kernel": "memory cross-attention (k_attention_w8), 1 launch/layer, per-frame Nk from the bank trace",
+            "roofline": {"bound": "mfma", "kernel": f"memory cross-attention ({cross_kernel_name(a.precision)}), 1 launch/layer, per-frame Nk from the bank trace",
                          "achieved": achieved, "peak": PEAK_TFLOPS[a.precision], "unit": "TFLOP/s",
                          "frac": None if achieved is None else achieved / PEAK_TFLOPS[a.precision], "traffic": None,
                          "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
                          "note": "rank 0; achieved = sum over tracked frames of 4 * 2*B*4096*Nk*(256+64) / summed HIP-event time"},
             "ms_per_step_by_stage": stage_ms,
         }
+        # SURVEY 8(d)'s path-level figure for the sharded stream: per tracked frame F_enc is amortised over the frames a rank ENCODES
+        # (every stream frame once per stream), the tracking part is priced at each frame's own Nk
+        if cfg.name in F_ENC_GFLOP and nks:
+            enc_runs = float(tsum[2].item())
+            pf_total = (F_ENC_GFLOP[cfg.name] * enc_runs + world * sum(B * (116.0 + 0.017039 * nk + 3.64 + 11.61) for nk in nks)) * 1e9
+            out["roofline_path"] = {"bound": "mfma", "achieved": pf_total / dt / 1e12, "peak": PEAK_TFLOPS[a.precision] * world, "unit": "TFLOP/s",
+                                    "frac": pf_total / dt / 1e12 / (PEAK_TFLOPS[a.precision] * world),
+                                    "note": "F_enc * encoder runs of all ranks + sum over tracked frames of B * (F_ma(Nk) + 3.64 + 11.61) GFLOP (rank 0's "
+                                            "Nk trace taken for every rank), over the round's max-over-ranks time; peak = n_gpus * the dense bf16 figure"}
         print(json.dumps(out))
 
 
@@ -486,6 +496,10 @@ def main():
                  "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": None if achieved is None else achieved / peak,
                  "traffic": None, "traffic_from_committed_pmc": committed_pmc_traffic("cross_attention", B, nk, a.precision),
                  "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
+                 "algorithmic_bytes_definition": "ONE definition for the launch: the one-kernel form - Q fp32 + K plane + V^T planes read once, "
+                                                 "output planes written once.  The launch's three kernels move more (Q re-written as fp16 "
+                                                 "fragments and read again, unnormalised O + (max, sum) written and re-read: 1.27 x, "
+                                                 "profiles/r04_pmc_traffic.json); traffic_from_committed_pmc is the main kernel alone",
                  "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
                  "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS,
                  "frac_of_sustained": None if achieved is None else achieved / SUSTAINED_MFMA_TFLOPS,
@@ -504,7 +518,7 @@ def main():
         if cand:
             name = max(cand, key=lambda k: cand[k]["ms_per_frame"])
             v = cand[name]
-            is_gemm = name.startswith("k_gemm_split")
+            is_gemm = name.startswith("k_gemm_split") or name.startswith("k_gemm_x4g")
             dom = {"bound": "mfma", "kernel": name, "achieved": v["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": v["tflops"] / peak,
                    "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS, "frac_of_sustained": v["tflops"] / SUSTAINED_MFMA_TFLOPS,
                    "traffic": None,

@@ -443,8 +443,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
 
 template <int D, int DV>
 int launch_t(const AttnArgs& a, hipStream_t st) {
-  static const bool w8_off = [] { const char* e = getenv("DS2_ATTN_HW8"); return e && atoi(e) == 0; }();
-  if (D <= 96 && a.Lq >= 256 && !w8_off) {
+  if (D <= 96 && a.Lq >= 256) {   // 8 waves x 256 queries (round 2: encoder 9.04 -> 8.82 ms/frame; the DS2_ATTN_HW8 switch is gone)
     dim3 grid(cdiv(a.Lq, 256), a.heads, a.batch);
     hipLaunchKernelGGL((k_attention_bf16x3<D, DV, (D <= 96 ? 8 : 4)>), grid, dim3(D <= 96 ? 512 : 256), 0, st, a);
   } else {

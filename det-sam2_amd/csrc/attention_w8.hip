@@ -815,11 +815,10 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   const bool klo = ds2_precision() != DS2_PREC_BF16X3K;   // bf16x3k: keys carry the hi plane only (k_lo may be null)
   DS2_REQUIRE(Lq % 256 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && Lk > 0 && (dv == 64 || dv == 128 || dv == 256),
               "attention_w8: Lq must be a multiple of 256, dv 64, 128 or 256");
-  static const bool qg1_env = [] { const char* e = getenv("DS2_ATTN_QG"); return e && atoi(e) == 1; }();
   // Few objects: with 256 queries per workgroup the grid is batch * Lq / 256 workgroups - 64 for 4 objects, a quarter of the chip.
   // Up to 128 of them the 128-query form (QG = 1) doubles the grid and still fits one round; per query both forms run the same
   // instruction sequence over the same tiles (bit-identical: tools/stage_hash_check.py against -DDS2_ATTN_QG1_SMALL=0).
-  const bool qg1 = qg1_env || (DS2_ATTN_QG1_SMALL && batch * (Lq / 256) <= 128);
+  const bool qg1 = DS2_ATTN_QG1_SMALL && batch * (Lq / 256) <= 128;
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,

@@ -92,7 +92,10 @@ __device__ __forceinline__ void wait_vm_lgkm() {   // s_waitcnt needs an immedia
   else static_assert(N == 8 || N == 12 || N == 16, "unexpected DMA count");
 }
 
-template <int ACT, bool X2>
+// LNF: the LayerNorm of the result rows in the epilogue is compiled in (MlpArgs::ln_w).  A template parameter since round 5: with the
+// LayerNorm code present EVERY instantiation - all at the full 512 registers - spilled 29 - 40 VGPRs to scratch;
+// without it none does, so only the one instantiation that uses the fusion (ReLU, two fp16 terms: the memory attention's FFN) carries it.
+template <int ACT, bool X2, bool LNF>
 __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   using FragT = typename std::conditional<X2, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -105,6 +108,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   for (int i = tid; i < a.H; i += 256) b1s[i] = a.b1 ? a.b1[i] : 0.f;
+  // LayerNorm weight / bias of the fused epilogue: staged in LDS, because read from global memory the compiler hoists the 64 per-lane
+  // 64-bit addresses (ln_w + n, ln_b + n for the 32 column groups) out of the row-block loop and spills them (29 - 40 VGPRs of scratch)
+  float* lns = b1s + a.H;   // [4][MD]: ln_w, ln_b, b2, gamma (the same holds for b2 / gamma of the plain epilogue)
+  if (LNF && a.ln_w) {
+    lns[tid] = a.ln_w[tid];
+    lns[MD + tid] = a.ln_b[tid];
+  }
+  lns[2 * MD + tid] = a.b2 ? a.b2[tid] : 0.f;
+  lns[3 * MD + tid] = a.gamma ? a.gamma[tid] : 1.f;
 
   const char* w1h = reinterpret_cast<const char*>(a.W1_hi);
   const char* w1l = reinterpret_cast<const char*>(a.W1_lo);
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- epilogue: lane (token, half) holds out[token][nb*32 + 8g + 4 half + e], e = 0..3: one float4 per (nb, g)
-    if (nparts > 1) {   // hidden split: the raw partial sums of this part; k_mlp256_merge finishes
+    if (!LNF && nparts > 1) {   // hidden split: the raw partial sums of this part; k_mlp256_merge finishes (never with LNF: launch_mlp256)
       if (tok < a.rows) {
         float* pp = a.part + ((size_t)hp * a.rows + tok) * MD;
 #pragma unroll
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
       }
       continue;
     }
-    const bool ln = a.ln_w != nullptr;
+    const bool ln = LNF && a.ln_w != nullptr;
     float rsum = 0.f;
 #pragma unroll
     for (int nb = 0; nb < MD / 32; ++nb) {
@@ -335,11 +347,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
         const int n = nb * 32 + 8 * g + 4 * half;
         float4 v = make_float4(out[nb][g * 4 + 0], out[nb][g * 4 + 1], out[nb][g * 4 + 2], out[nb][g * 4 + 3]);
         if (a.b2) {
-          const float4 b = *reinterpret_cast<const float4*>(a.b2 + n);
+          const float4 b = *reinterpret_cast<const float4*>(lns + 2 * MD + n);
           v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
         if (a.gamma) {
-          const float4 gm = *reinterpret_cast<const float4*>(a.gamma + n);
+          const float4 gm = *reinterpret_cast<const float4*>(lns + 3 * MD + n);
           v.x *= gm.x; v.y *= gm.y; v.z *= gm.z; v.w *= gm.w;
         }
         if (a.R && tok < a.rows) {
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = nb * 32 + 8 * g + 4 * half;
-            const float4 w4 = *reinterpret_cast<const float4*>(a.ln_w + n), b4 = *reinterpret_cast<const float4*>(a.ln_b + n);
+            const float4 w4 = *reinterpret_cast<const float4*>(lns + n), b4 = *reinterpret_cast<const float4*>(lns + MD + n);
             float4 y;
             y.x = (out[nb][g * 4 + 0] - mean) * rstd * w4.x + b4.x;
             y.y = (out[nb][g * 4 + 1] - mean) * rstd * w4.y + b4.y;
@@ -520,19 +532,24 @@ int launch_mlp256(const MlpArgs& a, hipStream_t st) {
     if (hs > 1 && a.part_bytes >= (size_t)hs * a.rows * MD * sizeof(float)) b.hsplit = hs;
   }
   const int grid = nrb < ncu ? nrb : ncu;
-  const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4;
+  const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4 + 4 * MD * 4;   // ring + b1 + (LayerNorm weight, bias, b2, gamma)
   void (*kern)(MlpArgs) = nullptr;
   const bool x2 = a.f16x2 != 0;
+  const bool lnf = a.ln_w != nullptr && b.hsplit == 1;   // (with the hidden split the merge kernel normalises)
+  DS2_REQUIRE(!lnf || a.act == DS2_ACT_RELU, "mlp256: the LayerNorm epilogue is built for the ReLU form only (memory attention FFN)");
   switch (a.act) {
-    case DS2_ACT_NONE: kern = x2 ? k_mlp256<DS2_ACT_NONE, true> : k_mlp256<DS2_ACT_NONE, false>; break;
-    case DS2_ACT_RELU: kern = x2 ? k_mlp256<DS2_ACT_RELU, true> : k_mlp256<DS2_ACT_RELU, false>; break;
-    case DS2_ACT_GELU: kern = x2 ? k_mlp256<DS2_ACT_GELU, true> : k_mlp256<DS2_ACT_GELU, false>; break;
+    case DS2_ACT_NONE: kern = x2 ? k_mlp256<DS2_ACT_NONE, true, false> : k_mlp256<DS2_ACT_NONE, false, false>; break;
+    case DS2_ACT_RELU:
+      kern = x2 ? (lnf ? k_mlp256<DS2_ACT_RELU, true, true> : k_mlp256<DS2_ACT_RELU, true, false>)
+                : (lnf ? k_mlp256<DS2_ACT_RELU, false, true> : k_mlp256<DS2_ACT_RELU, false, false>);
+      break;
+    case DS2_ACT_GELU: kern = x2 ? k_mlp256<DS2_ACT_GELU, true, false> : k_mlp256<DS2_ACT_GELU, false, false>; break;
     default: DS2_REQUIRE(false, "mlp256: unsupported activation %d", a.act);
   }
-  static bool attr_done[2][4] = {};
-  if (!attr_done[x2][a.act]) {
+  static bool attr_done[2][2][4] = {};
+  if (!attr_done[lnf][x2][a.act]) {
     DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[x2][a.act] = true;
+    attr_done[lnf][x2][a.act] = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid, b.hsplit), dim3(256), smem, st, b);
   DS2_CHECK_LAUNCH();

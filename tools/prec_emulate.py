@@ -87,6 +87,33 @@ def _scoped(mod, name, tag):
     setattr(mod, name, g)
 
 
+ENC_DIMS = [None]       # [e, 2e, 4e, 8e] of the model being run (set by the runners)
+
+
+def _enc_group(w):
+    """layer group of a Linear weight [N, K] inside forward_image: s12 (Hiera stages 1 - 2, every role) | s3qkv | s3proj | s3fc1 | s3fc2 |
+    s4 (stage 4, every role) | neck (everything else: FPN 1x1 convolutions run as Linear layers, patch embedding)"""
+    N, K = w.shape
+    d = ENC_DIMS[0]
+    role, dim = None, None
+    if N == 4 * K:
+        role, dim = "fc1", K
+    elif K == 4 * N:
+        role, dim = "fc2", N
+    elif N % 3 == 0 and N // 3 in (K, 2 * K):
+        role, dim = "qkv", K
+    elif N in (K, 2 * K):
+        role, dim = "proj", K
+    if role is None or dim not in d:
+        return "neck"
+    st = d.index(dim)
+    if st <= 1:
+        return "s12"
+    if st == 3 or (st == 2 and N == 2 * K and role == "proj") or (st == 2 and role == "qkv" and N // 3 == 2 * K):
+        return "s4"          # (the dimension change into stage 4 belongs to its first block)
+    return "s3" + role
+
+
 def emu_linear(x, w, b=None):
     global SCHEME
     rows = x.numel() // x.shape[-1]
@@ -99,6 +126,9 @@ def emu_linear(x, w, b=None):
         in_region = REGION[0] == "enc" and w.shape[1] == 4 * w.shape[0]
     if ONLY == "encfc1":
         in_region = REGION[0] == "enc" and w.shape[0] == 4 * w.shape[1]
+    if ONLY and ONLY.startswith("enc:"):          # one layer group of the image encoder: enc:<group>
+        in_region = REGION[0] == "enc" and (_enc_group(w) == ONLY[4:] or (ONLY[4:] == "s3" and _enc_group(w).startswith("s3"))
+                                            or (ONLY[4:] == "s34" and _enc_group(w)[:2] in ("s3", "s4")))
     if ONLY and not in_region and SCHEME != "bf16x3":
         keep, SCHEME = SCHEME, "bf16x3"
         try:
@@ -146,8 +176,14 @@ def _iou(a, b):
     return 1.0 if union == 0 else inter / union
 
 
+def _dims(cfg):
+    e = cfg.trunk.embed_dim
+    ENC_DIMS[0] = [e, 2 * e, 4 * e, 8 * e]
+
+
 def run_cfg1():
     cfg = resolve_config("sam2.1_hiera_t")
+    _dims(cfg)
     g = np.load(os.path.join(GOLD, "e2e_cfg1.npz"))
     vp = OracleVideoProcessor(synthetic_state_dict(cfg, 0), cfg, SyntheticDetector(1), skip_classes=set(), frame_buffer_size=8,
                               detect_interval=8, max_frame_num_to_track=8, max_inference_state_frames=-1)
@@ -165,10 +201,15 @@ def run_cfg1():
     return worst, dl
 
 
-def _compact(gname, nobj, kw, nframes, name="sam2.1_hiera_t"):
+def _compact(gname, nobj, kw, nframes, name="sam2.1_hiera_t", variant=None):
     cfg = resolve_config(name)
+    _dims(cfg)
     g = np.load(os.path.join(GOLD, gname))
-    vp = OracleVideoProcessor(synthetic_state_dict(cfg, 0), cfg, SyntheticDetector(nobj), **kw)
+    ws, ls, st = (0, 1.0, False)
+    if variant:
+        from oracle.make_goldens import HELDOUT
+        ws, ls, st = HELDOUT[variant]
+    vp = OracleVideoProcessor(synthetic_state_dict(cfg, ws, ls), cfg, SyntheticDetector(nobj), **kw)
     lows = []
     orig = vp.predictor.propagate_in_video
 
@@ -182,7 +223,7 @@ def _compact(gname, nobj, kw, nframes, name="sam2.1_hiera_t"):
     vp.predictor.propagate_in_video = capture
     with torch.inference_mode():
         for t in range(nframes):
-            vp.process_frame(t, synthetic_frame(t))
+            vp.process_frame(t, synthetic_frame(t, structured=st))
     worst, dl = 0.0, 0.0
     for i, (t, n, low) in enumerate(lows):
         ref = np.unpackbits(g[f"lowbits{i}"])[: low.size].reshape(low.shape).astype(bool)
@@ -197,9 +238,20 @@ def run_b16():
     return _compact("e2e_b16.npz", 16, B16_KW, 3)
 
 
+def run_ho_b16_lm():            # held-out: weight seed 1, structured frames, low-margin logits (the two most sensitive fixtures)
+    from oracle.make_goldens import B16_KW
+    return _compact("ho_b16_lm.npz", 16, B16_KW, 3, variant="lm")
+
+
+def run_ho_large_b16_s1():      # hiera_l x 16 objects x 9 frames at the bench's bank (10+ minutes of CPU)
+    from oracle.make_goldens import L16_FRAMES, L16_KW
+    return _compact("ho_large_b16_s1.npz", 16, L16_KW, L16_FRAMES, name="sam2.1_hiera_l", variant="s1")
+
+
 def run_large():
     from oracle.make_goldens import LARGE_KW
     cfg = resolve_config("sam2.1_hiera_l")
+    _dims(cfg)
     g = np.load(os.path.join(GOLD, "e2e_large.npz"))
     vp = OracleVideoProcessor(synthetic_state_dict(cfg, 0), cfg, SyntheticDetector(2), **LARGE_KW)
     with torch.inference_mode():
