@@ -389,7 +389,7 @@ int launch_tile(const GemmSplitArgs& g, int tile, hipStream_t st) {
 int launch_tile_impl(const GemmSplitArgs& g_in, int tile, hipStream_t st, const char** kname) {
   GemmSplitArgs g = g_in;
   {   // tile order (see GemmSplitArgs::group_m): wide-N GEMMs get 8-row groups (measured again in round 5 on the assembly kernel:
-      // 0 / 2 / 4 / 16 are all slower or equal, gpurun_out/r05_d_x4g.txt; the DS2_GEMM_GROUPM / DS2_GEMM_PF overrides of round 2 are gone)
+      // 0 / 2 / 4 / 16 are all slower or equal, profiles/r05_d_x4g.txt; the DS2_GEMM_GROUPM / DS2_GEMM_PF overrides of round 2 are gone)
     const int bn = (tile == 5 || tile == 10) ? 256 : 128;
     const int ntl = cdiv(g.C_hi ? (g.ldcp > g.N ? g.ldcp : g.N) : g.N, bn);
     g.group_m = ntl >= 8 ? 8 : 0;

@@ -35,7 +35,7 @@ MBW, NBW = int(CFG[0]), int(CFG[1])
 NB = MBW * NBW
 TM, TN = 64 * MBW, 64 * NBW
 KSUB = int(os.environ.get("X4G_KSUB", 2 if CFG == "23" else 1))   # 32-deep sub-tiles per LDS stage: the 128 x 192 tile stages 64-deep K
-RBYTES = 64 * KSUB                              # tiles, so that an LDS-DMA piece is 8 rows x 128 B = FULL L2 lines (gpurun_out/r05_l_dma.txt:
+RBYTES = 64 * KSUB                              # tiles, so that an LDS-DMA piece is 8 rows x 128 B = FULL L2 lines (profiles/r05_l_dma.txt:
 PA_B, PW_B = TM * RBYTES, TN * RBYTES             # the skeleton of the loop halves its time against 16 rows x 64 B); bytes of one plane of a stage
 STAGE = 2 * (PA_B + PW_B)
 if KSUB == 2:
@@ -52,7 +52,7 @@ STEPS_PER_MB = 8 // RP
 PA_N, PW_N = MBW * KSUB, NBW * KSUB           # LDS-DMA pieces (1 KiB) per plane, wave and body
 NP = 2 * ((0 if 'onlyw' in FLAGS else PA_N) + (0 if 'onlya' in FLAGS else PW_N))   # pieces per wave and body
 ISSUE = int(os.environ.get("X4G_ISSUE", 4))
-# form of the drain per epilogue, measured in one call (gpurun_out/r05_f_stores.txt; X4G_WIDE / X4G_STMOD override for A/B builds):
+# form of the drain per epilogue, measured in one call (profiles/r05_f_stores.txt; X4G_WIDE / X4G_STMOD override for A/B builds):
 #   e1 (fp32, 453 MB at the qkv shape): quad transposes + 16-byte non-temporal stores 384 us, plain 403, dword stores 440 (pp256: 405)
 #   e2 (GELU + planes): the lane-pair exchange + dword stores 521 us, transposes + 8-byte stores 555 (the extra VALU work costs more)
 #   e3 (residual): dword loads / stores 176 - 178 us, transposes 186
