@@ -251,6 +251,166 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
   }
 }
 
+
+// ---- round 5: the key projection's epilogue WITHOUT the LDS round trip and WITHOUT global RoPE-table loads.
+// tools/k64_trace_bench.py on the bench workload (profiles/r05_k64_trace_before.txt): of a wave's ~35 k cycles per 32-row tile the
+// MFMAs take 5 k, the four 64-column slabs 30 k - each slab's 8 RoPE-table loads sit BEHIND the previous slab's 8 plane stores in the
+// in-order VMEM queue (one vmcnt), so every slab waits for the previous slab's stores to retire.  Here the only VMEM traffic of a tile
+// is the next tile's A fragments (issued right behind the MFMAs, i.e. OLDER than every store of the tile) and the plane stores:
+//   * the axial RoPE table in its compact form (64 x-rows + 64 y-rows x 64 complex pairs = 64 KiB, GemmSplitArgs::rope_w) sits in LDS
+//     next to the weights, rows XOR-swizzled by (row & 3) so that the four rows a lane quad reads do not collide;
+//   * the accumulators go from "lane = column, registers = rows" to "lane i of a quad = row i, 4 consecutive columns" by a 4 x 4
+//     transpose inside every lane quad (two DPP butterfly stages, as in gemm_x4g): the two complex pairs of a lane are its own, the
+//     rotation needs no neighbour, and a store instruction writes 8 rows x 64 B (fp16) with nothing parked in LDS.
+// Same arithmetic, same order per element: bit-identical to k_gemm_split_k64<8, true, *> (tests/test_hip_stages.py: the memory attention
+// at bench size is unchanged to the bit; DS2_GEMM_K64T=0 keeps the slab epilogue for A/B runs).
+template <int CTL>
+__device__ __forceinline__ float dpp_quad(float x) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], bool b1, bool b2) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {          // lane ^ 2: register pairs (0, 2), (1, 3)
+    const float a = v[j], b = v[j + 2];
+    const float y = dpp_quad<0x4E>(b2 ? a : b);
+    v[j] = b2 ? y : a;
+    v[j + 2] = b2 ? b : y;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j += 2) {       // lane ^ 1: register pairs (0, 1), (2, 3)
+    const float a = v[j], b = v[j + 1];
+    const float y = dpp_quad<0xB1>(b1 ? a : b);
+    v[j] = b1 ? y : a;
+    v[j + 1] = b1 ? b : y;
+  }
+}
+
+constexpr int ROPE_LDS = 65536;   // [x | y part][64 rows][32 chunks of 16 B = 2 complex pairs]
+
+template <bool F16H>
+__global__ __launch_bounds__(512, 1) void k_gemm_split_k64t(GemmSplitArgs g, int tiles_per_wave) {
+  constexpr int NT = 8, NCOL = 256, WPL = NCOL * WROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WPL + ROPE_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  for (int i = tid; i < NCOL * 8 * 2; i += 512) {   // weights -> LDS once (the image of k_gemm_split_k64)
+    const int p = i / (NCOL * 8), r = (i / 8) % NCOL, c = i & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>((p ? g.W_lo : g.W_hi) + (size_t)r * g.ldw + c * 8);
+    *reinterpret_cast<uint4*>(lds + p * WPL + r * WROWB + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+  }
+  unsigned char* rope = lds + 2 * WPL;
+  for (int i = tid; i < 2 * 64 * 32; i += 512) {    // compact axial table: pairs < 64 depend on x = pos % w, the others on y = pos / w
+    const int part = i >> 11, r = (i >> 5) & 63, c = i & 31;
+    const int pos = part ? r * g.rope_w : r;
+    const float4 v = *reinterpret_cast<const float4*>(g.rope_cis + ((size_t)pos * 128 + part * 64 + 2 * c) * 2);
+    *reinterpret_cast<float4*>(rope + part * 32768 + r * 512 + ((c ^ (r & 3)) << 4)) = v;
+  }
+  __syncthreads();
+
+  const int gw = blockIdx.x * 8 + wave, nw = gridDim.x * 8;
+  const int ntiles = (g.M + 31) / 32;
+  const int qi = l31 & 3, qq = l31 >> 2;
+  const bool b1 = (lane & 1) != 0, b2 = (lane & 2) != 0;
+  float bias[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias[t] = g.bias ? g.bias[t * 32 + l31] : 0.f;
+
+  auto load_a = [&](int tile, AFrags& F) {
+    int row = tile * 32 + l31;
+    row = row < g.M ? row : g.M - 1;
+    const unsigned short* ph = g.A_hi + (size_t)row * g.lda + half * 8;
+    const unsigned short* pl = g.A_lo + (size_t)row * g.lda + half * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      F.h[s] = *reinterpret_cast<const bf16x8*>(ph + s * 16);
+      F.l[s] = *reinterpret_cast<const bf16x8*>(pl + s * 16);
+    }
+  };
+  AFrags F;
+  load_a(gw < ntiles ? gw : ntiles - 1, F);
+  const int wsw = (l31 >> 1) & 7;
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int tile_raw = gw + it * nw;
+    const int tile = tile_raw < ntiles ? tile_raw : ntiles - 1;
+    const bool live = tile_raw < ntiles;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int coff = (((s * 2 + half) ^ wsw) << 4);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned char* wp = lds + (t * 32 + l31) * WROWB + coff;
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + WPL);
+        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2A || (g.drop_terms & 1)), acc[t], F.l[s], bh);
+        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2W || (g.drop_terms & 2)), acc[t], F.h[s], bl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bh, acc[t], 0, 0, 0);
+      }
+    }
+    {   // the next row tile's fragments: behind the MFMAs, ahead of every store of this tile
+      const int tn_raw = gw + (it + 1) * nw;
+      load_a(tn_raw < ntiles ? tn_raw : ntiles - 1, F);
+    }
+    const int m0 = tile * 32;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int m = m0 + 8 * gq + 4 * half + qi;          // this lane's output row of the group
+      const bool row_ok = live && m < g.M;
+      const int mm = m < g.M ? m : g.M - 1;
+      const int tpos = mm % g.rope_L;
+      const bool rot = tpos < g.rope_n;                   // (object-pointer tokens are not rotated)
+      const int pos = rot ? tpos % g.rope_grid : 0;
+      const int px = pos % g.rope_w, py = pos / g.rope_w;
+      const unsigned char* rx = rope + px * 512;
+      const unsigned char* ry = rope + 32768 + py * 512;
+      unsigned short* const orow = g.C_hi + (size_t)mm * g.ldcp + 4 * qq;
+      unsigned short* const lrow = F16H ? nullptr : g.C_lo + (size_t)mm * g.ldcp + 4 * qq;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = acc[t][4 * gq + k] + bias[t];
+        quad_transpose4(v, b1, b2);
+        {   // apply_rotary_enc (position_encoding.py:196-220) on the complex pairs (n, n+1), (n+2, n+3), n = 32 t + 4 q
+#pragma clang fp contract(off)
+          const int c = (t & 3) * 8 + qq;                 // 16-byte chunk of the part's row: pairs 16 (t & 3) + 2 q, + 1
+          const unsigned char* rp = t < 4 ? rx + ((c ^ (px & 3)) << 4) : ry + ((c ^ (py & 3)) << 4);
+          const float4 cs = *reinterpret_cast<const float4*>(rp);
+          // (the contraction hipcc chose for `v0 c.x - v1 c.y`, `v0 c.y + v1 c.x` in the slab epilogue - read off its v_pk_mul / v_pk_fma
+          //  pair: the products with c.y are rounded, the ones with c.x fused)
+          const float a0 = __builtin_fmaf(v[0], cs.x, -(v[1] * cs.y)), a1 = __builtin_fmaf(v[1], cs.x, v[0] * cs.y);
+          const float a2 = __builtin_fmaf(v[2], cs.z, -(v[3] * cs.w)), a3 = __builtin_fmaf(v[3], cs.z, v[2] * cs.w);
+          v[0] = rot ? a0 : v[0]; v[1] = rot ? a1 : v[1]; v[2] = rot ? a2 : v[2]; v[3] = rot ? a3 : v[3];
+        }
+        if (row_ok) {
+          if constexpr (F16H) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            uint2 h;
+            h.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ds2_sat_f16(v[0]), ds2_sat_f16(v[1])}), f16x2));
+            h.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{ds2_sat_f16(v[2]), ds2_sat_f16(v[3])}), f16x2));
+            *reinterpret_cast<uint2*>(orow + t * 32) = h;
+          } else {
+            uint2 h, l;
+            h.x = cvt_pk_bf16(v[0], v[1]);
+            h.y = cvt_pk_bf16(v[2], v[3]);
+            l.x = cvt_pk_bf16(v[0] - bf_lo(h.x), v[1] - bf_hi(h.x));
+            l.y = cvt_pk_bf16(v[2] - bf_lo(h.y), v[3] - bf_hi(h.y));
+            *reinterpret_cast<uint2*>(orow + t * 32) = h;
+            if (g.C_lo) *reinterpret_cast<uint2*>(lrow + t * 32) = l;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (unit by unit: left alone, hipcc hoists the 32 table reads of a tile and spills 200 registers)
+      }
+    }
+  }
+}
+
 }  // namespace
 
 #ifdef DS2_K64_TRACE
@@ -273,7 +433,15 @@ int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st) {
   const int tiles_per_wave = (ntiles + blocks * 8 - 1) / (blocks * 8);
   const bool planes = g.act == DS2_ACT_NONE && !g.gamma && !g.R && !g.C && g.C_hi;
   DS2_REQUIRE(!g.c_hi_f16 || (planes && !g.C_lo), "gemm_split_k64: fp16 hi plane needs the plane-only epilogue without a lo plane");
-  if (g.c_hi_f16 && ncols == 256)
+  // the key projection (256 columns, planes only, axial RoPE with the compact table): the register-transposed epilogue
+  const char* kt_e = getenv("DS2_GEMM_K64T");   // (read per call: the tests compare both forms in one process)
+  const bool k64t = !(kt_e && atoi(kt_e) == 0) && planes && ncols == 256 && g.N == 256 && g.ldcp == 256 && g.rope_cis && g.rope_w == 64 &&
+                    g.rope_grid == 4096 && g.rope_L > 0 && (g.c_hi_f16 || g.C_lo) && !g.drop_terms;
+  if (k64t && g.c_hi_f16)
+    hipLaunchKernelGGL((k_gemm_split_k64t<true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else if (k64t)
+    hipLaunchKernelGGL((k_gemm_split_k64t<false>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
+  else if (g.c_hi_f16 && ncols == 256)
     hipLaunchKernelGGL((k_gemm_split_k64<8, true, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
   else if (g.c_hi_f16)
     hipLaunchKernelGGL((k_gemm_split_k64<4, true, true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);

@@ -308,3 +308,31 @@ def test_model_view_shares_weights_and_gives_identical_results():
         import ctypes as C
         a = np.zeros(4, np.float32)
         _capi.check(view.lib.ds2_model_set_param(view.h, b"x", a.ctypes.data_as(C.c_void_p), a.nbytes), "ds2_model_set_param")
+
+
+@pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
+@pytest.mark.parametrize("B,NF,NP", [(16, 7, 16), (4, 2, 3), (3, 1, 1)])
+def test_key_projection_epilogues_agree(prec, B, NF, NP, monkeypatch):
+    """Round 5: the key projection's register-transposed epilogue (k_gemm_split_k64t: RoPE table in LDS, 4 x 4 lane-quad transposes,
+    no LDS slab, no table loads behind the stores) against the slab epilogue it replaces (DS2_GEMM_K64T=0) - the memory attention's
+    output must agree BIT FOR BIT (full bank, a ragged row count: 4 x 8204 and 3 x 4100 rows are not multiples of 32)."""
+    from det_sam2_amd.hip_model import HipSam2
+    cfg = resolve_config("sam2.1_hiera_t")
+    hm = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=16)
+    hm.set_precision(prec)
+    d = hm.device
+    g = torch.Generator().manual_seed(5 + NP)
+    curr = torch.randn(4096, 256, generator=g).to(d)
+    feats = [(torch.randn(B, 4096, 64, generator=g).to(torch.bfloat16).to(d), 6 - i) for i in range(NF)]
+    ptrs = [(torch.randn(B, 256, generator=g).to(d), float(i) / 15.0) for i in range(NP)]
+    mem_d, pos_d = hm.bank_assemble(B, feats, ptrs)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DS2_GEMM_K64T", mode)
+        hm.profile_enable(True, gemm_shapes=True)
+        for t in hm.profile_tags():
+            hm.profile_read(t)
+        outs[mode] = hm.memory_attention(B, curr, mem_d, pos_d, 4 * NP).clone()
+        torch.cuda.synchronize()
+        hm.profile_enable(False)
+    assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
