@@ -503,6 +503,84 @@ class SAM2VideoPredictor:
                 "maskmem_pos_enc": None, "pred_masks": out["pred_masks"][s], "obj_ptr": out["obj_ptr"][s],
                 "object_score_logits": out["object_score_logits"][s]}
 
+    # ------------------------------------------------------------------ prompt / object removal
+    def _frame_masks_after_edit(self, st, frame_idx):
+        """video-resolution masks of every object on one frame after its prompts changed (no memory encoding)."""
+        is_cond = any(frame_idx in tmp["cond_frame_outputs"] for tmp in st["temp_output_dict_per_obj"].values())
+        cons = self._consolidate(st, frame_idx, is_cond, False)
+        return self._video_res(st, cons["pred_masks"])
+
+    @torch.inference_mode()
+    def clear_all_prompts_in_frame(self, inference_state, frame_idx, obj_id, need_output=True):
+        """clear_all_prompts_in_frame (sam2_video_predictor.py:1061-1131): forget the points / mask of one object on one
+        frame.  A frame left without any object's input stops being a conditioning frame: its consolidated output is
+        demoted to a non-conditioning one, and when no conditioning frame remains all tracking results are dropped."""
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        st["mask_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+            st["temp_output_dict_per_obj"][obj_idx][key].pop(frame_idx, None)
+        has_input = any(frame_idx in st["point_inputs_per_obj"][i] or frame_idx in st["mask_inputs_per_obj"][i]
+                        for i in range(self._get_obj_num(st)))
+        if not has_input:
+            od, cfi = st["output_dict"], st["consolidated_frame_inds"]
+            cfi["cond_frame_outputs"].discard(frame_idx)
+            cfi["non_cond_frame_outputs"].discard(frame_idx)
+            out = od["cond_frame_outputs"].pop(frame_idx, None)
+            if out is not None:
+                od["non_cond_frame_outputs"][frame_idx] = out
+                st["frames_already_tracked"].pop(frame_idx, None)
+            for o in st["output_dict_per_obj"].values():
+                obj_out = o["cond_frame_outputs"].pop(frame_idx, None)
+                if obj_out is not None:
+                    o["non_cond_frame_outputs"][frame_idx] = obj_out
+            if len(od["cond_frame_outputs"]) == 0:
+                self._reset_tracking_results(st)
+        if not need_output:
+            return None
+        return frame_idx, st["obj_ids"], self._frame_masks_after_edit(st, frame_idx)
+
+    @torch.inference_mode()
+    def remove_object(self, inference_state, obj_id, strict=False, need_output=True):
+        """remove_object (sam2_video_predictor.py:1438-1549): take one object out of the tracking state.  Its prompts are
+        cleared first (which may demote conditioning frames), the object table is renumbered, and its row is cut out of
+        every stored batch entry (memory features, low-res masks, pointers, objectness).  Returns (obj_ids,
+        [(frame_idx, video_res_masks)] for the frames the object had prompts on)."""
+        st = inference_state
+        rm = st["obj_id_to_idx"].get(obj_id)
+        updated = []
+        if rm is None:
+            if strict:
+                raise RuntimeError(f"Cannot remove object id {obj_id} as it doesn't exist. "
+                                   f"All existing object ids: {st['obj_ids']}.")
+            return st["obj_ids"], updated
+        if len(st["obj_id_to_idx"]) == 1:
+            self.reset_state(st)
+            return st["obj_ids"], updated
+        input_frames = set(st["point_inputs_per_obj"][rm]) | set(st["mask_inputs_per_obj"][rm])
+        for t in input_frames:
+            self.clear_all_prompts_in_frame(st, t, obj_id, need_output=False)
+        n_old = len(st["obj_ids"])
+        keep = [i for i in range(n_old) if i != rm]
+        ids = [st["obj_ids"][i] for i in keep]
+        st["obj_id_to_idx"] = {o: i for i, o in enumerate(ids)}
+        st["obj_idx_to_id"] = dict(enumerate(ids))
+        st["obj_ids"] = ids
+        for name in ("point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj", "temp_output_dict_per_obj"):
+            vals = [st[name].pop(i) for i in range(n_old)]
+            st[name].update((new, vals[old]) for new, old in enumerate(keep))
+        sel = torch.tensor(keep, dtype=torch.long)
+        for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+            for t, out in st["output_dict"][key].items():
+                for f in ("maskmem_features", "pred_masks", "obj_ptr", "object_score_logits"):
+                    if out[f] is not None:
+                        out[f] = out[f].index_select(0, sel.to(out[f].device))
+                self._add_output_per_object(st, t, out, key)
+        if need_output:
+            updated = [(t, self._frame_masks_after_edit(st, t)) for t in input_frames]
+        return st["obj_ids"], updated
+
     # ------------------------------------------------------------------ propagate (A9, A10, A11)
     @torch.inference_mode()
     def propagate_in_video_preflight(self, inference_state):
@@ -694,13 +772,24 @@ class SAM2VideoPredictor:
 
     @torch.inference_mode()
     def reset_state(self, inference_state):
-        """reset_state (sam2_video_predictor.py:1134-1172)."""
+        """reset_state (sam2_video_predictor.py:1134-1145): tracking results AND the object table."""
         st = inference_state
+        self._reset_tracking_results(st)
         for k in ("point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj", "temp_output_dict_per_obj"):
             st[k].clear()
         st["obj_id_to_idx"].clear()
         st["obj_idx_to_id"].clear()
         st["obj_ids"].clear()
+
+    def _reset_tracking_results(self, st):
+        """_reset_tracking_results (sam2_video_predictor.py:1147-1172): every prompt and output, the object table stays."""
+        for name in ("point_inputs_per_obj", "mask_inputs_per_obj"):
+            for v in st[name].values():
+                v.clear()
+        for name in ("output_dict_per_obj", "temp_output_dict_per_obj"):
+            for v in st[name].values():
+                v["cond_frame_outputs"].clear()
+                v["non_cond_frame_outputs"].clear()
         st["output_dict"]["cond_frame_outputs"].clear()
         st["output_dict"]["non_cond_frame_outputs"].clear()
         st["consolidated_frame_inds"]["cond_frame_outputs"].clear()

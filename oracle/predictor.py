@@ -423,6 +423,89 @@ class OraclePredictor:
                 o["maskmem_pos_enc"] = [x[s] for x in out["maskmem_pos_enc"]]
             od[key][frame_idx] = o
 
+    # ------------------------------------------------------------------ prompt / object removal
+    def reset_tracking_results(self, st):
+        """_reset_tracking_results (sam2_video_predictor.py:1147-1172)."""
+        for k in ("point_inputs_per_obj", "mask_inputs_per_obj"):
+            for v in st[k].values():
+                v.clear()
+        for k in ("output_dict_per_obj", "temp_output_dict_per_obj"):
+            for v in st[k].values():
+                v["cond_frame_outputs"].clear()
+                v["non_cond_frame_outputs"].clear()
+        for k in ("output_dict", "consolidated_frame_inds"):
+            st[k]["cond_frame_outputs"].clear()
+            st[k]["non_cond_frame_outputs"].clear()
+        st["tracking_has_started"] = False
+        st["frames_already_tracked"].clear()
+
+    def _masks_after_edit(self, st, frame_idx):
+        is_cond = any(frame_idx in t["cond_frame_outputs"] for t in st["temp_output_dict_per_obj"].values())
+        cons = self.consolidate(st, frame_idx, is_cond, False, at_video_res=True)
+        return self.video_res(st, cons["pred_masks_video_res"])
+
+    def clear_all_prompts_in_frame(self, st, frame_idx, obj_id, need_output=True):
+        """clear_all_prompts_in_frame (sam2_video_predictor.py:1061-1131)."""
+        i = self.obj_id_to_idx(st, obj_id)
+        st["point_inputs_per_obj"][i].pop(frame_idx, None)
+        st["mask_inputs_per_obj"][i].pop(frame_idx, None)
+        st["temp_output_dict_per_obj"][i]["cond_frame_outputs"].pop(frame_idx, None)
+        st["temp_output_dict_per_obj"][i]["non_cond_frame_outputs"].pop(frame_idx, None)
+        B = len(st["obj_idx_to_id"])
+        if not any(frame_idx in st["point_inputs_per_obj"][j] or frame_idx in st["mask_inputs_per_obj"][j] for j in range(B)):
+            od, cfi = st["output_dict"], st["consolidated_frame_inds"]
+            cfi["cond_frame_outputs"].discard(frame_idx)
+            cfi["non_cond_frame_outputs"].discard(frame_idx)
+            out = od["cond_frame_outputs"].pop(frame_idx, None)
+            if out is not None:                                    # :1095-1099 demoted to a non-conditioning frame
+                od["non_cond_frame_outputs"][frame_idx] = out
+                st["frames_already_tracked"].pop(frame_idx, None)
+            for j in range(B):
+                o = st["output_dict_per_obj"][j]
+                oo = o["cond_frame_outputs"].pop(frame_idx, None)
+                if oo is not None:
+                    o["non_cond_frame_outputs"][frame_idx] = oo
+            if not od["cond_frame_outputs"]:                       # :1108-1110
+                self.reset_tracking_results(st)
+        if need_output:
+            return frame_idx, st["obj_ids"], self._masks_after_edit(st, frame_idx)
+
+    def remove_object(self, st, obj_id, strict=False, need_output=True):
+        """remove_object (sam2_video_predictor.py:1438-1549)."""
+        rm = st["obj_id_to_idx"].get(obj_id)
+        if rm is None:
+            if strict:
+                raise RuntimeError(f"object id {obj_id} does not exist; existing ids: {st['obj_ids']}")
+            return st["obj_ids"], []
+        if len(st["obj_id_to_idx"]) == 1:                          # :1456-1459
+            self.reset_tracking_results(st)
+            for k in ("obj_id_to_idx", "obj_idx_to_id", "obj_ids", "point_inputs_per_obj", "mask_inputs_per_obj",
+                      "output_dict_per_obj", "temp_output_dict_per_obj"):
+                st[k].clear()
+            return st["obj_ids"], []
+        frames = set(st["point_inputs_per_obj"][rm]) | set(st["mask_inputs_per_obj"][rm])
+        for t in frames:                                           # step 0 :1466-1476
+            self.clear_all_prompts_in_frame(st, t, obj_id, need_output=False)
+        old = list(range(len(st["obj_ids"])))
+        remain = [i for i in old if i != rm]
+        ids = [st["obj_ids"][i] for i in remain]                   # step 1 :1480-1491
+        st["obj_id_to_idx"] = {o: n for n, o in enumerate(ids)}
+        st["obj_idx_to_id"] = {n: o for n, o in enumerate(ids)}
+        st["obj_ids"] = ids
+        for k in ("point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj", "temp_output_dict_per_obj"):
+            moved = {remain.index(i): st[k].pop(i) for i in old if i != rm}    # step 2 :1493-1505
+            st[k].pop(rm, None)
+            st[k].update(moved)
+        for key in ("cond_frame_outputs", "non_cond_frame_outputs"):           # step 3 :1507-1527
+            for t, out in st["output_dict"][key].items():
+                out["maskmem_features"] = out["maskmem_features"][remain]
+                out["maskmem_pos_enc"] = self.maskmem_pos_enc(st, [x[remain] for x in out["maskmem_pos_enc"]])
+                for f in ("pred_masks", "obj_ptr", "object_score_logits"):
+                    out[f] = out[f][remain]
+                self.add_output_per_object(st, t, out, key)
+        updated = [(t, self._masks_after_edit(st, t)) for t in frames] if need_output else []   # step 4 :1531-1547
+        return st["obj_ids"], updated
+
     # ------------------------------------------------------------------ propagate (A9, A10)
     def preflight(self, st):
         """propagate_in_video_preflight (sam2_video_predictor.py:807-893)."""

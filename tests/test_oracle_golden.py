@@ -454,6 +454,54 @@ def test_e2e_correction_prompts_match_reference_golden(tiny, golden_dir):
             assert 1.0 - _iou((logits > 0).numpy()[o], ref[o]) <= 1e-3, (t, o)
 
 
+def test_e2e_prompt_and_object_removal_match_reference_golden(tiny, golden_dir):
+    """clear_all_prompts_in_frame / remove_object (sam2_video_predictor.py:1061-1131, :1438-1549) - golden e2e_remove."""
+    from det_sam2_amd.synth import synthetic_box
+    from oracle.make_goldens import correction_prompts, removal_click
+    cfg, sd = tiny
+    g = np.load(os.path.join(golden_dir, "e2e_remove.npz"))
+    op = OraclePredictor(sd, cfg)
+
+    def worst(vr, packed, n):
+        ref = np.unpackbits(packed).reshape(n, 1, 1024, 1024).astype(bool)
+        return max(1.0 - _iou((vr > 0).numpy()[o], ref[o]) for o in range(n))
+
+    with torch.inference_mode():
+        st = op.init_state([synthetic_frame(t) for t in range(6)])
+        for o in range(3):
+            op.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0))
+        op.add_new_points_or_box(st, 3, 1, *removal_click())
+        first = list(op.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6))
+        assert [y[0] for y in first] == list(g["first_frames"])
+        assert sorted(st["output_dict"]["cond_frame_outputs"]) == list(g["first_cond"])
+        for i, (t, ids, lg) in enumerate(first):
+            assert worst(lg, g["first_bits"][i], 3) <= 1e-3, t
+        c0 = correction_prompts()[0]
+        _, _, vr = op.add_new_points_or_box(st, 4, 0, points=c0[3], labels=c0[4])
+        assert worst(vr, g["click_bits"], 3) <= 1e-3
+        t, ids, vr = op.clear_all_prompts_in_frame(st, 4, 0)
+        assert t == 4 and list(ids) == [0, 1, 2] and worst(vr, g["clear_bits"], 3) <= 1e-3
+        ids, updated = op.remove_object(st, 1)
+        assert list(ids) == list(g["ids_after"]) and sorted(t for t, _ in updated) == sorted(g["updated_frames"])
+        for t, vr in updated:
+            assert worst(vr, g["updated_bits"][list(g["updated_frames"]).index(t)], 2) <= 1e-3, t
+        od = st["output_dict"]
+        assert sorted(od["cond_frame_outputs"]) == list(g["cond_after"])
+        assert sorted(od["non_cond_frame_outputs"]) == list(g["noncond_after"])
+        assert sorted(st["frames_already_tracked"]) == list(g["tracked_after"])
+        assert sorted(st["consolidated_frame_inds"]["cond_frame_outputs"]) == list(g["consolidated_cond_after"])
+        assert np.abs(od["non_cond_frame_outputs"][3]["pred_masks"].numpy() - g["low3_after"]).max() <= 5e-4
+        assert op.remove_object(st, 77) == (st["obj_ids"], [])
+        with pytest.raises(RuntimeError):
+            op.remove_object(st, 77, strict=True)
+        ys = list(op.propagate_in_video(st, start_frame_idx=0, max_frame_num_to_track=6))
+    assert [y[0] for y in ys] == list(g["frames"])
+    for i, (t, ids, logits) in enumerate(ys):
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        assert np.abs(od[key][t]["pred_masks"].numpy() - g["low"][i]).max() <= 5e-4
+        assert worst(logits, g["bits"][i], 2) <= 1e-3, t
+
+
 # ---------------------------------------------------------------------------------------------- round 4: measured shape
 # e2e_large_b16 / e2e_bplus (+ held-out s1): the reference's own output at the benchmark's shape (hiera_l x 16 objects, bank of
 # 1 conditioning + 6 non-conditioning frames) and for BASELINE config 3's model (hiera_b+, preloaded bank of P = 1).

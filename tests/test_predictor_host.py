@@ -105,3 +105,65 @@ def test_run_from_a_frame_folder_equals_run_from_memory(tmp_path):
     assert VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(frame_dir=str(empty)) is None
     with pytest.raises(NotImplementedError, match="OpenCV"):
         VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(video_path="x.mp4")
+
+
+def test_remove_object_equals_never_having_added_it():
+    """remove_object / clear_all_prompts_in_frame (sam2_video_predictor.py:1438-1549, :1061-1131): after the removal the
+    state is the one of a run that never had the object - the stand-in stages treat batch rows independently, so every
+    stored tensor and every later mask is equal bit for bit.  Reference arithmetic: golden e2e_remove (oracle + GPU tests)."""
+    def start(objs):
+        p = fake_predictor()
+        st = p.init_state(_frames(6))
+        for o in objs:
+            p.add_new_points_or_box(st, 0, o, box=synthetic_box(o, 0, size=64))
+        return p, st
+
+    a, sa = start([0, 1, 2])
+    a.add_new_points_or_box(sa, 3, 1, points=np.array([[30.0, 30.0]], np.float32), labels=np.array([1], np.int32))
+    list(a.propagate_in_video(sa, start_frame_idx=0, max_frame_num_to_track=6))
+    assert sorted(sa["output_dict"]["cond_frame_outputs"]) == [0, 3]
+    # a correction click that is taken back: the frame shows the tracked masks again, nothing stays in the temp dict
+    before = a._video_res(sa, sa["output_dict"]["non_cond_frame_outputs"][4]["pred_masks"])
+    a.add_new_points_or_box(sa, 4, 0, points=np.array([[10.0, 12.0]], np.float32), labels=np.array([0], np.int32))
+    t, ids, vr = a.clear_all_prompts_in_frame(sa, 4, 0)
+    assert (t, list(ids)) == (4, [0, 1, 2]) and torch.equal(vr, before)
+    assert not sa["temp_output_dict_per_obj"][0]["non_cond_frame_outputs"] and 4 not in sa["point_inputs_per_obj"][0]
+    ids, updated = a.remove_object(sa, 1)
+    assert list(ids) == [0, 2] and sorted(t for t, _ in updated) == [0, 3]
+    assert all(m.shape == (2, 1, 64, 64) for _, m in updated)
+    assert sa["obj_id_to_idx"] == {0: 0, 2: 1} and sa["obj_idx_to_id"] == {0: 0, 1: 2}
+    od = sa["output_dict"]
+    assert sorted(od["cond_frame_outputs"]) == [0] and sorted(od["non_cond_frame_outputs"]) == [1, 2, 3, 4, 5]   # 3 demoted
+    assert 3 not in sa["frames_already_tracked"] and 3 not in sa["consolidated_frame_inds"]["cond_frame_outputs"]
+    for name in ("point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj", "temp_output_dict_per_obj"):
+        assert sorted(sa[name]) == [0, 1]
+    assert a.remove_object(sa, 77) == ([0, 2], [])
+    with pytest.raises(RuntimeError, match="77"):
+        a.remove_object(sa, 77, strict=True)
+
+    b, sb = start([0, 2])
+    list(b.propagate_in_video(sb, start_frame_idx=0, max_frame_num_to_track=6))
+    for f in ("maskmem_features", "pred_masks", "obj_ptr", "object_score_logits"):       # the shared conditioning frame
+        assert torch.equal(od["cond_frame_outputs"][0][f], sb["output_dict"]["cond_frame_outputs"][0][f]), f
+    for key in ("cond_frame_outputs", "non_cond_frame_outputs"):                          # per-object views are re-cut
+        for t, out in od[key].items():
+            assert out["pred_masks"].shape[0] == 2 and out["maskmem_features"].shape[0] == 2
+            for i in range(2):
+                assert torch.equal(sa["output_dict_per_obj"][i][key][t]["obj_ptr"], out["obj_ptr"][i:i + 1])
+    # propagation after the removal: every frame but 0 is tracked again with 2 objects and a bank that no longer holds
+    # object 1's conditioning frame 3 - the run equals run B frame by frame
+    n0 = _tracked(a)
+    ya = {t: m.clone() for t, _, m in a.propagate_in_video(sa, start_frame_idx=0, max_frame_num_to_track=6)}
+    yb = {t: m.clone() for t, _, m in b.propagate_in_video(sb, start_frame_idx=0, max_frame_num_to_track=6)}
+    assert _tracked(a) == n0 + 5 and 3 in sa["frames_already_tracked"]
+    for t in range(6):
+        assert ya[t].shape == (2, 1, 64, 64) and torch.equal(ya[t], yb[t]), t
+
+    # the last object: remove_object == reset_state; clearing the only prompt of the only conditioning frame resets tracking
+    c, sc = start([5])
+    assert c.remove_object(sc, 5) == ([], [])
+    assert not sc["obj_id_to_idx"] and not sc["output_dict"]["cond_frame_outputs"]
+    d, sd = start([5])
+    list(d.propagate_in_video(sd, start_frame_idx=0, max_frame_num_to_track=3))
+    assert d.clear_all_prompts_in_frame(sd, 0, 5, need_output=False) is None
+    assert not sd["tracking_has_started"] and not sd["output_dict"]["non_cond_frame_outputs"] and sd["obj_ids"] == [5]
