@@ -34,10 +34,33 @@
 #include "common.h"
 #include "kernels.h"
 
-// ablation builds for profiling only (tools/ab.py build NAME -DDS2_MLP_ABL=n; results are WRONG for n != 0):
-// 1 = no bias / activation (split only), 2 = no workgroup barrier per step, 3 = no prefetch DMA inside the loop
+// 1 (default): the hidden-dimension loop of the ReLU / two-fp16-term instantiations (the memory attention's FFN) is the generated
+// inline-assembly statement of tools/gen/gen_mlp256_x4m.py (fragment reads 4 units ahead with counted waits, DMA 6 tiles ahead, one
+// barrier per 16 KiB tile, activation as fillers); 0: the C++ loop for every instantiation.  Same arithmetic in the same order per
+// element: tools/mlp_layout_check.py compares the two builds bit for bit.
+#ifndef DS2_MLP_X4M
+#define DS2_MLP_X4M 1
+#endif
+#if DS2_MLP_X4M
+#ifdef X4M_INC_FILE
+#include X4M_INC_FILE      // (tools/x4m_variant.sh: ablation / parameter variants of the generated body)
+#else
+#include "mlp256_x4m_body.inc"
+#endif
+#endif
+
+// ablation builds for profiling only (tools/ab.py build NAME -DDS2_MLP_ABL=mask; results are WRONG for mask != 0), bits:
+// 1 = no bias / activation (split only), 2 = no workgroup barrier per step, 4 = no prefetch DMA inside the loop, 8 = the lo-plane weight
+// fragments are not read (half the LDS fragment reads), 16 = no weight fragment reads at all, 32 = the in-loop DMA is issued but never
+// waited for (vmcnt), 64 = no main loop (prologue + epilogue only)
 #ifndef DS2_MLP_ABL
 #define DS2_MLP_ABL 0
+#endif
+// 1 (default, round 5): the weight tiles sit in LDS as rows of 128 bytes (64 k resp. 64 hidden units) and a DMA piece is 8 rows x 128 B -
+// every piece requests FULL L2 lines.  0: rows of 64 bytes, pieces of 16 rows x 64 B = half lines (rounds 3 - 4).  The L2 -> LDS path is bound
+// by line requests (DESIGN.md "GEMM, round 5"); the ablation without the in-loop DMA runs 22 % faster.  Same MFMA order per element: bit-identical.
+#ifndef DS2_MLP_LINE128
+#define DS2_MLP_LINE128 1
 #endif
 
 namespace {
@@ -128,6 +151,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   const int c_begin = hp * (nchunk_all / nparts), c_end = c_begin + nchunk_all / nparts;
   // DMA: a piece = 16 rows x 64 B of one plane (1 KiB, one wave instruction); lane -> (row = lane >> 2, physical 16-byte
   // chunk = lane & 3) fetching the logical chunk (lane & 3) ^ ((lane >> 4) & 3)
+#if DS2_MLP_LINE128
+  // DMA: a piece = 8 rows x 128 B of one plane (1 KiB, one wave instruction); lane -> (row = lane >> 3, physical 16-byte chunk = lane & 7)
+  // fetching the logical chunk (lane & 7) ^ ((tile row >> 1) & 7); the reader applies the same XOR
+  const int drow = lane >> 3;
+  const int sw = (l31 >> 1) & 7;
+  unsigned offA[2], offB[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {   // W1 piece pc = 2 wave + j: tile rows 8 pc .. 8 pc + 7 (hidden units), 64 k per row
+    const int row = (wave * 2 + j) * 8 + drow;
+    offA[j] = ((unsigned)row * (unsigned)a.ldw1 + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {   // W2 piece pc = 4 wave + j: tile rows 8 pc .. (output columns n of this half), 64 hidden units per row
+    const int row = (wave * 4 + j) * 8 + drow;
+    offB[j] = ((unsigned)row * (unsigned)a.ldw2 + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
+  }
+  const unsigned strideB = 128u * (unsigned)a.ldw2 * 2u;            // bytes between the two n-halves of W2
+#else
   const int drow = lane >> 2;
   const int dlc = (lane & 3) ^ ((lane >> 4) & 3);
   const int sw = (l31 >> 2) & 3;   // reader side of the same involution
@@ -140,6 +181,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) offB[j] = ((unsigned)((wave * 4 + j) * 16 + drow) * (unsigned)a.ldw2 + dlc * 8) * 2u;
+  const unsigned strideB = 0;
+#endif
   const unsigned strideA = (unsigned)MHC * (unsigned)a.ldw1 * 2u;   // bytes between chunks of W1 (64 hidden rows)
 
   // tile at position P6 (0..5) of chunk `c` into the ring slot of pair position PP (slot = PP % MNS)
@@ -153,7 +196,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
         __builtin_amdgcn_global_load_lds(w1l + (offA[j] + o_), (lds_ptr)(base_ + MLO + (wave * 2 + j) * 1024), 16, 0, 0); \
       }                                                                                                                   \
     } else {                                                                                                              \
-      const unsigned o_ = ((unsigned)(c) * MHC + ((P6) - MTA) * 32u) * 2u;                                                \
+      const unsigned o_ = DS2_MLP_LINE128 ? (unsigned)(c) * MHC * 2u + ((P6) - MTA) * strideB                             \
+                                          : ((unsigned)(c) * MHC + ((P6) - MTA) * 32u) * 2u;                              \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                     \
         __builtin_amdgcn_global_load_lds(w2h + (offB[j] + o_), (lds_ptr)(base_ + (wave * 4 + j) * 1024), 16, 0, 0);       \
         __builtin_amdgcn_global_load_lds(w2l + (offB[j] + o_), (lds_ptr)(base_ + MLO + (wave * 4 + j) * 1024), 16, 0, 0); \
@@ -162,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   }
   // prefetch issued at pair position PP: the tile MNS - 1 positions ahead (in this pair, or in the next one)
 #define MLP_PREFETCH(PP)                                                                                                  \
-  if constexpr (DS2_MLP_ABL == 3) {} else if constexpr ((PP) + MNS - 1 < MT_PAIR) MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, c2 + ((PP) + MNS - 1) / MT_PER_CHUNK, (PP) + MNS - 1) \
+  if constexpr ((DS2_MLP_ABL & 4) != 0) {} else if constexpr ((PP) + MNS - 1 < MT_PAIR) MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, c2 + ((PP) + MNS - 1) / MT_PER_CHUNK, (PP) + MNS - 1) \
   else MLP_DMA(((PP) + MNS - 1) % MT_PER_CHUNK, cn2 + ((PP) + MNS - 1 - MT_PAIR) / MT_PER_CHUNK, (PP) + MNS - 1)
   // order of a step's instructions (one wave per SIMD: nobody else hides the LDS latency): the DMA issue first, then the
   // fragment pairs (hi, lo) in groups of two = 6 MFMAs.  Three register sets: groups g and g + 1 are resident, group g + 2
@@ -181,11 +225,39 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   // wave's fragment reads are retired, then everybody meets
 #define MLP_STEP_END(PP)                                                         \
   __builtin_amdgcn_sched_barrier(0);                                             \
-  if constexpr (DS2_MLP_ABL == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            \
+  if constexpr ((DS2_MLP_ABL & 36) != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* 6: DMA issued, never waited for */ \
   else wait_vm_lgkm<tile_dma((PP) + 2) + tile_dma((PP) + 3)>();                  \
-  if constexpr (DS2_MLP_ABL != 2) __builtin_amdgcn_s_barrier();                  \
+  if constexpr ((DS2_MLP_ABL & 2) == 0) __builtin_amdgcn_s_barrier();                  \
   __builtin_amdgcn_sched_barrier(0);
 
+#if DS2_MLP_X4M
+  constexpr bool X4M = ACT == DS2_ACT_RELU && X2 && DS2_MLP_ABL == 0;
+#else
+  constexpr bool X4M = false;
+#endif
+  // operands of the assembly loop: tiles of 64 rows x 128 B (a wave issues pieces 2 wave, 2 wave + 1 of both planes), fragment reads at
+  // row l31, 16-byte chunk (2 k + half) ^ ((l31 >> 1) & 7) - the k-step enters as an XOR of 32 k on the byte address
+  unsigned m_rd0 = 0, m_offa[2] = {0, 0}, m_offb[2] = {0, 0}, m_baddr = 0, m_ldsb = 0, m_stridea = 0, m_strideb = 0, m_nch = 0;
+  unsigned long long m_w1h = 0, m_w1l = 0, m_w2h = 0, m_w2l = 0;
+  if constexpr (X4M) {
+    m_ldsb = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char*)lds));
+    m_rd0 = m_ldsb + (unsigned)l31 * 128u + (unsigned)((half ^ ((l31 >> 1) & 7)) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 8 + (lane >> 3);
+      const unsigned ch = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 8);
+      m_offa[j] = ((unsigned)row * (unsigned)a.ldw1 + ch) * 2u;
+      m_offb[j] = ((unsigned)row * (unsigned)a.ldw2 + ch) * 2u;
+    }
+    m_baddr = m_ldsb + (unsigned)(MNS * MSLOT) + (unsigned)(c_begin * MHC + 4 * half) * 4u;
+    m_stridea = (unsigned)MHC * (unsigned)a.ldw1 * 2u;
+    m_strideb = 64u * (unsigned)a.ldw2 * 2u;
+    m_nch = (unsigned)(c_end - c_begin);
+    m_w1h = reinterpret_cast<unsigned long long>(w1h) + (unsigned long long)c_begin * m_stridea;
+    m_w1l = reinterpret_cast<unsigned long long>(w1l) + (unsigned long long)c_begin * m_stridea;
+    m_w2h = reinterpret_cast<unsigned long long>(w2h) + (unsigned long long)c_begin * (MHC * 2u);
+    m_w2l = reinterpret_cast<unsigned long long>(w2l) + (unsigned long long)c_begin * (MHC * 2u);
+  }
   const int nrb = (a.rows + MBR - 1) / MBR;
   for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
     const int tok = rb * MBR + wave * 32 + l31;
@@ -217,6 +289,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) out[i][e] = 0.f;
 
+#if DS2_MLP_X4M
+    if constexpr (X4M) {
+      // the whole hidden loop of this row block, ring prologue included (mlp256_x4m_body.inc); every wave leaves it with its DMA still
+      // in flight (the wrapped-around tail) - drained below like the C++ loop's
+      asm volatile(X4M_BODY
+                   : [o0] "+a"(out[0]), [o1] "+a"(out[1]), [o2] "+a"(out[2]), [o3] "+a"(out[3]), [o4] "+a"(out[4]), [o5] "+a"(out[5]),
+                     [o6] "+a"(out[6]), [o7] "+a"(out[7])
+                   : [x0] "v"(xh[0]), [x1] "v"(xh[1]), [x2] "v"(xh[2]), [x3] "v"(xh[3]), [x4] "v"(xh[4]), [x5] "v"(xh[5]), [x6] "v"(xh[6]),
+                     [x7] "v"(xh[7]), [x8] "v"(xh[8]), [x9] "v"(xh[9]), [x10] "v"(xh[10]), [x11] "v"(xh[11]), [x12] "v"(xh[12]),
+                     [x13] "v"(xh[13]), [x14] "v"(xh[14]), [x15] "v"(xh[15]), [rd0] "v"(m_rd0), [offa0] "v"(m_offa[0]), [offa1] "v"(m_offa[1]),
+                     [offb0] "v"(m_offb[0]), [offb1] "v"(m_offb[1]), [baddr] "v"(m_baddr), [w1h] "s"(m_w1h), [w1l] "s"(m_w1l), [w2h] "s"(m_w2h),
+                     [w2l] "s"(m_w2l), [stridea] "s"(m_stridea), [strideb] "s"(m_strideb), [ldsb] "s"(m_ldsb), [wave] "s"(wave), [nch] "s"(m_nch)
+                   : X4M_CLOBBERS);
+    } else
+#endif
+    {
     // ---- ring prologue: tiles 0..2 of chunk 0 (the X loads above are ordinary loads: drained with them)
     MLP_DMA(0, c_begin, 0)
     MLP_DMA(1, c_begin, 1)
@@ -225,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     __builtin_amdgcn_s_barrier();        // (also publishes b1s on the first row block)
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int c2 = c_begin; c2 < c_end; c2 += 2) {
+    for (int c2 = c_begin; c2 < ((DS2_MLP_ABL & 64) ? c_begin : c_end); c2 += 2) {
       const int cn2 = (c2 + 2 < c_end) ? c2 + 2 : c_begin;   // (the tail prefetches wrap around: uniform DMA accounting)
       // phase A step at pair position PP (tile T = PP % 6 of chunk c2 + PP / 6): W1 tile, 64 hidden x 64 k
 #define MLP_A(PP)                                                                                                         \
@@ -235,9 +323,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     FragT wh_[4][MHC / 32], wl_[4][MHC / 32];                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
       _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
-        const unsigned char* r_ = base_ + (ks >> 1) * 4096 + (hb * 32 + l31) * 64 + ((((ks & 1) * 2 + half) ^ sw) << 4);  \
-        wh_[ks][hb] = *reinterpret_cast<const FragT*>(r_);                                                                \
-        wl_[ks][hb] = *reinterpret_cast<const FragT*>(r_ + MLO);                                                          \
+        const unsigned char* r_ = DS2_MLP_LINE128 ? base_ + (hb * 32 + l31) * 128 + (((ks * 2 + half) ^ sw) << 4)        \
+            : base_ + (ks >> 1) * 4096 + (hb * 32 + l31) * 64 + ((((ks & 1) * 2 + half) ^ sw) << 4);                      \
+        if constexpr ((DS2_MLP_ABL & 16) != 0) wh_[ks][hb] = xh[ks]; else wh_[ks][hb] = *reinterpret_cast<const FragT*>(r_);     \
+        if constexpr ((DS2_MLP_ABL & 24) != 0) wl_[ks][hb] = wh_[ks][hb]; else wl_[ks][hb] = *reinterpret_cast<const FragT*>(r_ + MLO); \
       }                                                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
       _Pragma("unroll") for (int hb = 0; hb < MHC / 32; ++hb) {                                                           \
@@ -248,7 +337,34 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     MLP_INTERLEAVE(8)                                                                                                     \
     MLP_STEP_END(PP)                                                                                                      \
   }
-      // phase B step at pair position PP: W2 tile (256 n x 32 permuted hidden units = hidden block Q = PP % 6 - 4)
+      // phase B step at pair position PP.  DS2_MLP_LINE128: W2 tile = output columns [128 Q, 128 Q + 128) x the chunk's 64 (permuted) hidden
+      // units, Q = PP % 6 - 4; its 16 fragment pairs are (k-step t = 0..3, column block nb = 0..3), t outermost - an output element
+      // still sums its hidden units in ascending order.  Otherwise: 256 n x 32 hidden units (hidden block Q), pairs (t = 0..1, nb = 0..7).
+#if DS2_MLP_LINE128
+#define MLP_B(PP)                                                                                                         \
+  {                                                                                                                       \
+    MLP_PREFETCH(PP)                                                                                                      \
+    const unsigned char* base_ = lds + ((PP) % MNS) * MSLOT;                                                              \
+    constexpr int Q_ = (PP) % MT_PER_CHUNK - MTA;                                                                         \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                                                    \
+      FragT wh_[8], wl_[8];                                                                                               \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                     \
+        const int t = t2 * 2 + (i >> 2), nb = i & 3;                                                                      \
+        const unsigned char* r_ = base_ + (nb * 32 + l31) * 128 + (((t * 2 + half) ^ sw) << 4);                           \
+        if constexpr ((DS2_MLP_ABL & 16) != 0) wh_[i] = xh[i]; else wh_[i] = *reinterpret_cast<const FragT*>(r_);                \
+        if constexpr ((DS2_MLP_ABL & 24) != 0) wl_[i] = wh_[i]; else wl_[i] = *reinterpret_cast<const FragT*>(r_ + MLO);         \
+      }                                                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                     \
+        const int t = t2 * 2 + (i >> 2), nb = Q_ * 4 + (i & 3);                                                           \
+        out[nb] = mfma16(wl_[i], fh[t >> 1][t & 1], out[nb]);                                                             \
+        if constexpr (!X2) out[nb] = mfma16(wh_[i], fl[t >> 1][t & 1], out[nb]);                                          \
+        out[nb] = mfma16(wh_[i], fh[t >> 1][t & 1], out[nb]);                                                             \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    MLP_INTERLEAVE(16)                                                                                                    \
+    MLP_STEP_END(PP)                                                                                                      \
+  }
+#else
 #define MLP_B(PP)                                                                                                         \
   {                                                                                                                       \
     MLP_PREFETCH(PP)                                                                                                      \
@@ -258,8 +374,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
       FragT wh_[MD / 32], wl_[MD / 32];                                                                                   \
       _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
         const unsigned char* r_ = base_ + (nb * 32 + l31) * 64 + (((t * 2 + half) ^ sw) << 4);                            \
-        wh_[nb] = *reinterpret_cast<const FragT*>(r_);                                                                    \
-        wl_[nb] = *reinterpret_cast<const FragT*>(r_ + MLO);                                                              \
+        if constexpr ((DS2_MLP_ABL & 16) != 0) wh_[nb] = xh[nb]; else wh_[nb] = *reinterpret_cast<const FragT*>(r_);             \
+        if constexpr ((DS2_MLP_ABL & 24) != 0) wl_[nb] = wh_[nb]; else wl_[nb] = *reinterpret_cast<const FragT*>(r_ + MLO);      \
       }                                                                                                                   \
       _Pragma("unroll") for (int nb = 0; nb < MD / 32; ++nb) {                                                            \
         out[nb] = mfma16(wl_[nb], fh[Q_][t], out[nb]);                                                                    \
@@ -270,6 +386,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     MLP_INTERLEAVE(16)                                                                                                    \
     MLP_STEP_END(PP)                                                                                                      \
   }
+#endif
       // bias + activation + split of chunk c: hid[hb] registers 8t .. 8t+7 (g = 2t, 2t+1) -> k-step t of hidden block hb.
       // b1 comes from LDS by inline asm: a plain LDS read here makes hipcc drain the DMA ring (s_waitcnt vmcnt(0)).
 #define MLP_ACT(c)                                                                                                        \
@@ -286,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
         float v[8];                                                                                                       \
         _Pragma("unroll") for (int gg = 0; gg < 2; ++gg)                                                                  \
           _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                   \
-            v[gg * 4 + e] = DS2_MLP_ABL == 1 ? hid[hb][(2 * t + gg) * 4 + e]                                              \
+            v[gg * 4 + e] = (DS2_MLP_ABL & 1) ? hid[hb][(2 * t + gg) * 4 + e]                                              \
                                              : ds2_act(hid[hb][(2 * t + gg) * 4 + e] + bb[hb][2 * t + gg][e], ACT);       \
         uint4 h, l;                                                                                                       \
         if constexpr (X2) {                                                                                               \
@@ -319,6 +436,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
       MLP_A(6) MLP_A(7) MLP_A(8) MLP_A(9)
       MLP_ACT(c2 + 1)
       MLP_B(10) MLP_B(11)
+    }
     }
     // ---- the ring still holds the (wrapped-around) prefetches: drain them before the ordinary loads / stores of the
     //      epilogue and before the next row block restarts the ring

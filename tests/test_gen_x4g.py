@@ -18,3 +18,25 @@ def test_committed_body_is_the_generators_output(tmp_path, cfg, epi):
                    capture_output=True)
     committed = open(os.path.join(ROOT, "det-sam2_amd", "csrc", f"gemm_x4g_body_{cfg}_{epi}.inc")).read()
     assert out.read_text() == committed
+
+
+def test_committed_mlp_loop_is_the_generators_output(tmp_path):
+    """det-sam2_amd/csrc/mlp256_x4m_body.inc (the hidden loop of the fused MLP's ReLU / two-fp16-term form) = tools/gen/gen_mlp256_x4m.py
+    today; the generator simulates the in-order LDS queue for every counted wait and checks that the queue at the end of the loop body
+    equals the one at its start."""
+    out = tmp_path / "body.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("X4M_")}
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_mlp256_x4m.py"), str(out)], check=True, env=env, capture_output=True)
+    assert out.read_text() == open(os.path.join(ROOT, "det-sam2_amd", "csrc", "mlp256_x4m_body.inc")).read()
+    body = out.read_text()
+    assert body.count("v_mfma_f32_32x32x16_f16") == 128 and body.count("s_barrier") == 9      # 64 units x 2; 8 steps + the prologue
+
+
+@pytest.mark.parametrize("env_extra", [{"X4M_D": "4"}, {"X4M_D": "7"}, {"X4M_ILV": "1", "X4M_D": "4"}, {"X4M_WAIT1": "0", "X4M_NONOP": "0", "X4M_MED3": "0"}])
+def test_mlp_loop_generator_variants_are_consistent(tmp_path, env_extra):
+    """the schedule knobs (read-ahead depth, interleaved unit pairs, the first version's instruction mix) all pass the generator's own
+    checks: queue state cyclic, hazard lint, 128 MFMAs"""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("X4M_")}
+    env.update(env_extra)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_mlp256_x4m.py"), str(tmp_path / "v.inc")], check=True, env=env,
+                   capture_output=True)

@@ -43,7 +43,7 @@ def run(names, rounds, env_mode=False):
                 d = json.loads(o.stdout.strip().splitlines()[-1])
                 gm = d.get("roofline_gemm") or {}
                 print(f"{n:12s} fps {d['value']:.2f} cross {d['roofline']['avg_launch_ms']:.3f} ms  gemm {gm.get('family_ms_per_frame', 0):.3f} ms/frame "
-                      f"(top {gm.get('shape')} {gm.get('achieved', 0):.0f} TF)  {d['ms_per_step_by_stage']}", flush=True)
+                      f"(top {gm.get('shape')} {gm.get('achieved', 0):.0f} TF)  k_mlp256 {((d.get('by_kernel') or {}).get('k_mlp256') or {}).get('avg_launch_ms', 0):.4f} ms  {d['ms_per_step_by_stage']}", flush=True)
             except Exception:
                 print(n, "FAILED", o.stderr[-400:])
 
