@@ -61,6 +61,7 @@ def test_gemm(ops, M, N, K, act, use_r, r_mod, use_g):
     (300, 256, 0, True, False),          # ragged last row block (300 = 2 x 128 + 44)
     (1000, 1024, 2, True, True),         # CXBlock shape: GELU, layer scale, residual
     (40000, 2048, 1, True, False),       # memory-attention FFN shape, more row blocks than CUs (persistent loop)
+    (4096, 2048, 1, True, False),        # few rows: hidden dimension split over workgroups (4 chunks per part) + merge kernel
 ])
 @pytest.mark.parametrize("f16x2", [False, True])
 def test_fused_mlp(rows, H, act, use_r, use_g, f16x2, monkeypatch):
