@@ -162,6 +162,52 @@ size_t attention_x4a_ws_bytes(int batch, int Lq, int Lk) {
   return (rows / 64) * (32 * 1024) + (size_t)x4a_nsplit(batch, Lq, Lk) * (rows * DV * sizeof(float) + rows * 2 * sizeof(float)) + 1024;
 }
 
+// the same tiles from the bank's bf16 frame entries (kernels.h BankArgs; the fp32 memory tensor is never built): one thread per
+// (object, entry, tile of 32 tokens, dv).  A bf16 value converts to fp32 exactly, so the fp16 values equal k_vt_pack32's on `memory`.
+__global__ __launch_bounds__(256) void k_bank_vt32(BankArgs a, unsigned short* __restrict__ vt) {
+  const int tpe = a.tokens / 32;                       // tiles per entry
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)a.B * a.n_mem * tpe * DV) return;
+  const int dv = (int)(i % DV);
+  size_t r = i / DV;
+  const int tl = (int)(r % tpe); r /= tpe;
+  const int e = (int)(r % a.n_mem), b = (int)(r / a.n_mem);
+  const unsigned short* src = a.feats[e] + ((size_t)b * a.tokens + (size_t)tl * 32) * 64 + dv;
+  unsigned h[16];
+#pragma unroll
+  for (int key = 0; key < 32; key += 2) {
+    const float x0 = __uint_as_float((unsigned)src[(size_t)key * 64] << 16), x1 = __uint_as_float((unsigned)src[(size_t)(key + 1) * 64] << 16);
+    h[vt_pos32(key) >> 1] = cvt_pk_f16(ds2_sat_f16(x0), ds2_sat_f16(x1));
+  }
+  const int ntile = (a.Nk + 31) / 32;
+  uint4* o = reinterpret_cast<uint4*>(vt + (((size_t)b * ntile + (size_t)(a.e0 + e) * tpe + tl) * DV + dv) * 32);
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) o[q4] = make_uint4(h[4 * q4], h[4 * q4 + 1], h[4 * q4 + 2], h[4 * q4 + 3]);
+}
+int launch_bank_vt32(const BankArgs& a, void* vt32, hipStream_t st) {
+  DS2_REQUIRE(a.n_mem >= 0 && a.n_mem <= DS2_MAX_MEM_ENTRIES && a.tokens % 32 == 0, "bank_vt32: bad entry table (n_mem=%d)", a.n_mem);
+  if (a.n_mem > 0) {
+    const size_t n = (size_t)a.B * a.n_mem * (a.tokens / 32) * DV;
+    hipLaunchKernelGGL(k_bank_vt32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, reinterpret_cast<unsigned short*>(vt32));
+    DS2_CHECK_LAUNCH();
+  }
+  return DS2_OK;
+}
+const unsigned char* attention_x4a_vt_slot_table() {   // vt_pos32 as a device table (per device, built once; k_bank_ptr_planes)
+  static const unsigned char* tab[64] = {};          // (a race between two host threads costs a second 32-byte allocation)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!tab[dev]) {
+    unsigned char h[32];
+    for (int k = 0; k < 32; ++k) h[k] = (unsigned char)vt_pos32(k);
+    unsigned char* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), 32) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h, 32, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    tab[dev] = d;
+  }
+  return tab[dev];
+}
+
 int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
   const size_t n = (size_t)batch * ((L + 31) / 32) * DV;
   hipLaunchKernelGGL(k_vt_pack32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L, reinterpret_cast<unsigned short*>(vt));

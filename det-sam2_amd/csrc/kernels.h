@@ -85,6 +85,12 @@ struct BankArgs {
 };
 int launch_bank_assemble(const BankArgs& a, hipStream_t st);
 int launch_bank_ptr(const BankArgs& a, const float* dim_t /*[128]*/, hipStream_t st);
+// the bank straight to the cross-attention's operands (kin planes [B*Nk][64] bf16 hi / lo; V^T tiles of the assembly attention)
+int launch_bank_kin(const BankArgs& a, void* hi, void* lo, hipStream_t st);
+int launch_bank_vt32(const BankArgs& a, void* vt32, hipStream_t st);                       // (attention_x4a.hip: frame tokens)
+int launch_bank_ptr_planes(const BankArgs& a, const float* dim_t, void* hi, void* lo, void* vt32, int ntile,
+                           const unsigned char* vt_slot /*device [32]: key & 31 -> slot*/, hipStream_t st);
+const unsigned char* attention_x4a_vt_slot_table();                                        // device table of vt_pos32
 
 // outputs
 int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits /*nullable*/,

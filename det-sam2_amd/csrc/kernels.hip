@@ -1001,6 +1001,66 @@ __global__ __launch_bounds__(64) void k_bank_ptr(BankArgs a, const float* dim_t)
     }
 }
 
+// The bank straight to the operands of the memory cross-attention (mode bf16x3k with the assembly attention, model.hip
+// memory_attention_impl): the key input kin = memory + memory_pos as bf16 operand planes of the k_proj GEMM - the fp32 `memory` and
+// `memory_pos` [B, Nk, 64] tensors (2 x 118 MB at 16 objects and 7 frames) are never written nor read back.  Same expressions as
+// k_bank_mem followed by k_add_bcast_split: pos = pe + tp, then m + pos, then the bf16 split (bit-identical planes).
+__global__ void k_bank_kin(BankArgs a, uint2* hi, uint2* lo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over B * n_mem * tokens * 16 (4-column granules)
+  const size_t per_e = (size_t)a.tokens * 16;
+  if (i >= (size_t)a.B * a.n_mem * per_e) return;
+  const int c4 = (int)(i % 16);
+  size_t r = i / 16;
+  const int t = (int)(r % a.tokens); r /= a.tokens;
+  const int e = (int)(r % a.n_mem), b = (int)(r / a.n_mem);
+  const ushort4 h4 = *reinterpret_cast<const ushort4*>(a.feats[e] + ((size_t)b * a.tokens + t) * 64 + c4 * 4);
+  const float4 m = make_float4(bf16_bits_to_f32(h4.x), bf16_bits_to_f32(h4.y), bf16_bits_to_f32(h4.z), bf16_bits_to_f32(h4.w));
+  const float4 pe = *reinterpret_cast<const float4*>(a.maskmem_pos + (size_t)t * 64 + c4 * 4);
+  const float4 tp = *reinterpret_cast<const float4*>(a.tpos_enc + (size_t)a.tpos_row[e] * 64 + c4 * 4);
+  const float4 pos = make_float4(pe.x + tp.x, pe.y + tp.y, pe.z + tp.z, pe.w + tp.w);
+  const float4 v = make_float4(m.x + 1.0f * pos.x, m.y + 1.0f * pos.y, m.z + 1.0f * pos.z, m.w + 1.0f * pos.w);
+  uint2 h, l;
+  h.x = ln_cvt_pk_bf16(v.x, v.y);
+  h.y = ln_cvt_pk_bf16(v.z, v.w);
+  l.x = ln_cvt_pk_bf16(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+  l.y = ln_cvt_pk_bf16(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+  const size_t o = ((size_t)b * a.Nk + (size_t)(a.e0 + e) * a.tokens + t) * 16 + c4;
+  hi[o] = h;
+  lo[o] = l;
+}
+// pointer tokens of the same form: kin planes rows + their slots in the V^T tiles of the assembly attention (vt32: [b][tile][dv 64][slot
+// 32] fp16, slot = vt_slot[key & 31]; the tiles were zeroed by the caller - keys past the bank's end are zero as k_vt_pack32 leaves them)
+__global__ __launch_bounds__(64) void k_bank_ptr_planes(BankArgs a, const float* dim_t, unsigned short* hi, unsigned short* lo,
+                                                        unsigned short* vt, int ntile, const unsigned char* vt_slot) {
+  __shared__ float pe[256];
+  const int e = blockIdx.x, c = threadIdx.x;
+  const float pos = a.ptr_pos[e];
+  for (int k = c; k < 128; k += 64) {
+    const float v = pos / dim_t[k];
+    pe[k] = sinf(v);
+    pe[128 + k] = cosf(v);
+  }
+  __syncthreads();
+  float tp = 0.f;
+  for (int k = 0; k < 256; ++k) tp += pe[k] * a.tpos_w[c * 256 + k];
+  tp += a.tpos_b[c];
+  for (int b = 0; b < a.B; ++b)
+    for (int j = 0; j < 4; ++j) {
+      const float m = a.ptrs[e][(size_t)b * 256 + j * 64 + c];
+      const int row = a.n_mem_total * a.tokens + (a.p0 + e) * 4 + j;
+      const float v = m + 1.0f * tp;
+      const unsigned h = ln_cvt_pk_bf16(v, 0.f) & 0xffffu;
+      const unsigned l = ln_cvt_pk_bf16(v - __uint_as_float(h << 16), 0.f) & 0xffffu;
+      const size_t o = ((size_t)b * a.Nk + row) * 64 + c;
+      hi[o] = (unsigned short)h;
+      lo[o] = (unsigned short)l;
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      const unsigned f = __builtin_bit_cast(unsigned, __builtin_convertvector((f2{ds2_sat_f16(m), 0.f}), h2)) & 0xffffu;
+      vt[(((size_t)b * ntile + row / 32) * 64 + c) * 32 + vt_slot[row & 31]] = (unsigned short)f;
+    }
+}
+
 // ------------------------------------------------------------------ output (A15): bilinear 256^2 -> video
 // resolution (sam2_video_predictor.py:618-642) fused with `> 0` and bit-packing (det_sam2_RT.py:396-399);
 // packing order = numpy.packbits (MSB first).  One thread per 8 output pixels.
@@ -1397,6 +1457,25 @@ int launch_bank_assemble(const BankArgs& a, hipStream_t st) {
 int launch_bank_ptr(const BankArgs& a, const float* dim_t, hipStream_t st) {
   if (a.n_ptr > 0) {
     hipLaunchKernelGGL(k_bank_ptr, dim3(a.n_ptr), dim3(64), 0, st, a, dim_t);
+    DS2_CHECK_LAUNCH();
+  }
+  return DS2_OK;
+}
+int launch_bank_kin(const BankArgs& a, void* hi, void* lo, hipStream_t st) {
+  DS2_REQUIRE(a.n_mem >= 0 && a.n_mem <= DS2_MAX_MEM_ENTRIES, "bank_kin: too many entries (n_mem=%d)", a.n_mem);
+  if (a.n_mem > 0) {
+    hipLaunchKernelGGL(k_bank_kin, grid1((size_t)a.B * a.n_mem * a.tokens * 16), dim3(256), 0, st, a, reinterpret_cast<uint2*>(hi),
+                       reinterpret_cast<uint2*>(lo));
+    DS2_CHECK_LAUNCH();
+  }
+  return DS2_OK;
+}
+int launch_bank_ptr_planes(const BankArgs& a, const float* dim_t, void* hi, void* lo, void* vt32, int ntile, const unsigned char* vt_slot,
+                           hipStream_t st) {
+  DS2_REQUIRE(a.n_ptr >= 0 && a.n_ptr <= DS2_MAX_PTR_ENTRIES, "bank_ptr_planes: too many entries (n_ptr=%d)", a.n_ptr);
+  if (a.n_ptr > 0) {
+    hipLaunchKernelGGL(k_bank_ptr_planes, dim3(a.n_ptr), dim3(64), 0, st, a, dim_t, reinterpret_cast<unsigned short*>(hi),
+                       reinterpret_cast<unsigned short*>(lo), reinterpret_cast<unsigned short*>(vt32), ntile, vt_slot);
     DS2_CHECK_LAUNCH();
   }
   return DS2_OK;

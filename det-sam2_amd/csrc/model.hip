@@ -1024,48 +1024,67 @@ extern "C" int ds2_image_encoder(ds2_model* m, const uint16_t* frame_f16, float*
 }
 
 // ------------------------------------------------------------------------------------------------ A11
-extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const void* const* feats, const int32_t* tpos_row,
-                                 int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
-                                 float* memory_pos, void* stream) {
-  DS2_REQUIRE(m && m->finalized && B > 0 && memory && memory_pos, "ds2_bank_assemble: bad argument");
-  ModelScope _dg(m);
-  DS2_REQUIRE(n_mem >= 0 && n_ptr >= 0 && (n_mem == 0 || (feats && tpos_row)) && (n_ptr == 0 || (ptrs && ptr_pos)),
-              "ds2_bank_assemble: bad entry tables (n_mem=%d, n_ptr=%d)", n_mem, n_ptr);
-  hipStream_t st = (hipStream_t)stream;
-  for (int e = 0; e < n_mem; ++e) {
-    DS2_REQUIRE(feats[e], "ds2_bank_assemble: null feature pointer");
-    DS2_REQUIRE(tpos_row[e] >= 0 && tpos_row[e] < m->cfg.num_maskmem, "ds2_bank_assemble: bad tpos_row");
+namespace {
+struct BankSrc {   // the entry tables of ds2_bank_assemble (HOST arrays of device pointers)
+  int n_mem; const void* const* feats; const int32_t* tpos_row;
+  int n_ptr; const float* const* ptrs; const float* ptr_pos;
+};
+int bank_check(ds2_model* m, const BankSrc& s, const char* who) {
+  DS2_REQUIRE(s.n_mem >= 0 && s.n_ptr >= 0 && (s.n_mem == 0 || (s.feats && s.tpos_row)) && (s.n_ptr == 0 || (s.ptrs && s.ptr_pos)),
+              "%s: bad entry tables (n_mem=%d, n_ptr=%d)", who, s.n_mem, s.n_ptr);
+  for (int e = 0; e < s.n_mem; ++e) {
+    DS2_REQUIRE(s.feats[e], "%s: null feature pointer", who);
+    DS2_REQUIRE(s.tpos_row[e] >= 0 && s.tpos_row[e] < m->cfg.num_maskmem, "%s: bad tpos_row", who);
   }
+  for (int i = 0; i < s.n_ptr; ++i) DS2_REQUIRE(s.ptrs[i], "%s: null pointer entry", who);
+  return DS2_OK;
+}
+// the entry tables travel in the kernel arguments, DS2_MAX_*_ENTRIES at a time (no limit on the bank size); fm(a) / fp(a) launch for one batch
+template <class FM, class FP>
+int bank_for_each(ds2_model* m, int B, const BankSrc& s, float* memory, float* memory_pos, FM fm, FP fp) {
   BankArgs a{};
   a.B = B; a.tokens = TOK;
-  a.Nk = n_mem * TOK + 4 * n_ptr; a.n_mem_total = n_mem;
+  a.Nk = s.n_mem * TOK + 4 * s.n_ptr; a.n_mem_total = s.n_mem;
   a.maskmem_pos = m->P("#maskmem_pos");
   a.tpos_enc = m->P("maskmem_tpos_enc");
   a.tpos_w = m->P("obj_ptr_tpos_proj.weight");
   a.tpos_b = m->P("obj_ptr_tpos_proj.bias");
   a.mem = memory; a.mem_pos = memory_pos;
   CHECK_PARAMS();
-  // the entry tables travel in the kernel arguments, DS2_MAX_*_ENTRIES at a time (no limit on the bank size)
-  for (int e0 = 0; e0 < n_mem; e0 += DS2_MAX_MEM_ENTRIES) {
-    a.e0 = e0; a.n_mem = n_mem - e0 < DS2_MAX_MEM_ENTRIES ? n_mem - e0 : DS2_MAX_MEM_ENTRIES; a.n_ptr = 0;
+  for (int e0 = 0; e0 < s.n_mem; e0 += DS2_MAX_MEM_ENTRIES) {
+    a.e0 = e0; a.n_mem = s.n_mem - e0 < DS2_MAX_MEM_ENTRIES ? s.n_mem - e0 : DS2_MAX_MEM_ENTRIES; a.n_ptr = 0;
     for (int e = 0; e < a.n_mem; ++e) {
-      a.feats[e] = reinterpret_cast<const uint16_t*>(feats[e0 + e]);
-      a.tpos_row[e] = tpos_row[e0 + e];
+      a.feats[e] = reinterpret_cast<const uint16_t*>(s.feats[e0 + e]);
+      a.tpos_row[e] = s.tpos_row[e0 + e];
     }
-    TRY(launch_bank_assemble(a, st));
+    TRY(fm(a));
   }
-  for (int p0 = 0; p0 < n_ptr; p0 += DS2_MAX_PTR_ENTRIES) {
-    a.p0 = p0; a.n_ptr = n_ptr - p0 < DS2_MAX_PTR_ENTRIES ? n_ptr - p0 : DS2_MAX_PTR_ENTRIES; a.n_mem = 0;
-    for (int i = 0; i < a.n_ptr; ++i) { a.ptrs[i] = ptrs[p0 + i]; a.ptr_pos[i] = ptr_pos[p0 + i]; }
-    TRY(launch_bank_ptr(a, m->P("#ptr_dim_t"), st));
+  for (int p0 = 0; p0 < s.n_ptr; p0 += DS2_MAX_PTR_ENTRIES) {
+    a.p0 = p0; a.n_ptr = s.n_ptr - p0 < DS2_MAX_PTR_ENTRIES ? s.n_ptr - p0 : DS2_MAX_PTR_ENTRIES; a.n_mem = 0;
+    for (int i = 0; i < a.n_ptr; ++i) { a.ptrs[i] = s.ptrs[p0 + i]; a.ptr_pos[i] = s.ptr_pos[p0 + i]; }
+    TRY(fp(a));
   }
   return DS2_OK;
+}
+int bank_to_fp32(ds2_model* m, int B, const BankSrc& s, float* memory, float* memory_pos, hipStream_t st) {
+  return bank_for_each(m, B, s, memory, memory_pos, [&](const BankArgs& a) { return launch_bank_assemble(a, st); },
+                       [&](const BankArgs& a) { return launch_bank_ptr(a, m->P("#ptr_dim_t"), st); });
+}
+}  // namespace
+extern "C" int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const void* const* feats, const int32_t* tpos_row,
+                                 int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* memory,
+                                 float* memory_pos, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && memory && memory_pos, "ds2_bank_assemble: bad argument");
+  ModelScope _dg(m);
+  const BankSrc s{n_mem, feats, tpos_row, n_ptr, ptrs, ptr_pos};
+  TRY(bank_check(m, s, "ds2_bank_assemble"));
+  return bank_to_fp32(m, B, s, memory, memory_pos, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ A12
 static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, bool curr_shared, const float* curr_pos,
                                  bool pos_shared, const float* memory, const float* memory_pos, int32_t Nk, int32_t n_ptr_tok,
-                                 float* out, void* stream);
+                                 float* out, void* stream, const BankSrc* bank = nullptr);
 extern "C" int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, const float* memory, const float* memory_pos,
                                     int32_t Nk, int32_t n_ptr_tok, float* out, void* stream) {
   return memory_attention_impl(m, B, curr, true, nullptr, true, memory, memory_pos, Nk, n_ptr_tok, out, stream);
@@ -1075,10 +1094,20 @@ extern "C" int ds2_memory_attention_ex(ds2_model* m, int32_t B, const float* cur
                                        int32_t n_ptr_tok, float* out, void* stream) {
   return memory_attention_impl(m, B, curr, curr_shared != 0, curr_pos, pos_shared != 0, memory, memory_pos, Nk, n_ptr_tok, out, stream);
 }
+// bank != nullptr (ds2_bank_memory_attention): memory / memory_pos are NOT given - the bank's entries are turned into the cross-attention's
+// operands directly (kin planes, V^T tiles) when the assembly attention runs, else assembled as fp32 tensors in the workspace first
+extern "C" int ds2_bank_memory_attention(ds2_model* m, int32_t B, const float* curr, int32_t n_mem, const void* const* feats,
+                                         const int32_t* tpos_row, int32_t n_ptr, const float* const* ptrs, const float* ptr_pos,
+                                         float* out, void* stream) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && curr && out, "ds2_bank_memory_attention: bad argument");
+  const BankSrc s{n_mem, feats, tpos_row, n_ptr, ptrs, ptr_pos};
+  TRY(bank_check(m, s, "ds2_bank_memory_attention"));
+  return memory_attention_impl(m, B, curr, true, nullptr, true, nullptr, nullptr, n_mem * TOK + 4 * n_ptr, 4 * n_ptr, out, stream, &s);
+}
 static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, bool curr_shared, const float* curr_pos,
                                  bool pos_shared, const float* memory, const float* memory_pos, int32_t Nk, int32_t n_ptr_tok,
-                                 float* out, void* stream) {
-  DS2_REQUIRE(m && m->finalized && B > 0 && curr && memory && memory_pos && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
+                                 float* out, void* stream, const BankSrc* bank) {
+  DS2_REQUIRE(m && m->finalized && B > 0 && curr && (bank || (memory && memory_pos)) && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
               "ds2_memory_attention: bad argument");
   ModelScope _dg(m);
   GemmDropScope _gds("DS2_EXP_MA_DROP");
@@ -1106,8 +1135,18 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const bool x4a = split && k_f16 && attention_x4a_enabled() && attention_x4a_supported(B, TOK, Nk, 64, true);
   const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK, Nk) : 0;
   const size_t x4a_bytes = x4a ? x4a_ws_bytes + (size_t)B * nt_c * 4096 + 4096 : 0;
-  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (split ? (size_t)rows * 2048 + 4096 : 0) + mlp256_part_bytes(rows, F) + (4u << 20);
+  const char* bd_env = bank ? getenv("DS2_BANK_DIRECT") : nullptr;   // (read per call: 0 = the fp32 tensors in every mode, for A/B runs)
+  const bool bank_direct = bank && x4a && !(bd_env && atoi(bd_env) == 0);       // entries -> kin planes + V^T tiles, no fp32 memory / memory_pos
+  const size_t bank_fp32_bytes = (bank && !bank_direct) ? (size_t)2 * B * Nk * 64 * 4 + 512 : 0;
+  const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (split ? (size_t)rows * 2048 + 4096 : 0) + mlp256_part_bytes(rows, F) + bank_fp32_bytes + (4u << 20);
   TRY(m->require(need, st));
+  if (bank && !bank_direct) {   // every other mode: the fp32 tensors as ds2_bank_assemble builds them, in the workspace
+    float* mf = reinterpret_cast<float*>(m->alloc_bytes((size_t)B * Nk * 64 * 4));
+    float* pf = reinterpret_cast<float*>(m->alloc_bytes((size_t)B * Nk * 64 * 4));
+    if (!mf || !pf) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
+    TRY(bank_to_fp32(m, B, *bank, mf, pf, st));
+    memory = mf; memory_pos = pf;
+  }
   const float* cis = m->P("#rope_cis");
   ALLOC(x, (size_t)rows * 256);
   ALLOC(x1, (size_t)TOK * 256);
@@ -1141,7 +1180,15 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       vt32 = m->alloc_bytes((size_t)B * nt_c * 4096);
       x4a_ws = m->alloc_bytes(x4a_ws_bytes);
       if (!vt32 || !x4a_ws) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
-      TRY(launch_vt_pack32(memory, 64, B, Nk, vt32, st));
+      if (bank_direct) {   // frame tokens here; the pointer tokens' slots together with their kin rows below (tiles zeroed first)
+        TRY(bank_for_each(m, B, *bank, nullptr, nullptr, [&](const BankArgs& a) { return launch_bank_vt32(a, vt32, st); },
+                          [&](const BankArgs&) { return (int)DS2_OK; }));
+        const int t0 = (Nk - n_ptr_tok) / 32;
+        if (nt_c > t0)
+          DS2_CHECK_HIP(hipMemset2DAsync(reinterpret_cast<char*>(vt32) + (size_t)t0 * 4096, (size_t)nt_c * 4096, 0, (size_t)(nt_c - t0) * 4096, B, st));
+      } else {
+        TRY(launch_vt_pack32(memory, 64, B, Nk, vt32, st));
+      }
     } else {
       TRY(launch_vt_split16(memory, 64, B, Nk, vt_c, 64, st, Nk - n_ptr_tok, vlo_flag, k_f16));   // (bf16x3k: fp16 planes)
     }
@@ -1161,7 +1208,15 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   if (split) {   // emitted directly as the k_proj GEMM's operand planes
     ds2_model::ActPlanes kp;
     TRY(new_act_planes(m, kin, B * Nk, 64, &kp, st));
-    TRY(launch_add_bcast_split(memory, 64, memory_pos, 64, 0, 1.0f, kp.hi, kp.lo, kp.ld, B * Nk, 64, st));
+    if (bank_direct) {
+      DS2_REQUIRE(kp.ld == 64, "memory_attention: key-input planes with row pitch %d", kp.ld);
+      const unsigned char* slots = attention_x4a_vt_slot_table();
+      DS2_REQUIRE(slots, "memory_attention: no V^T slot table");
+      TRY(bank_for_each(m, B, *bank, nullptr, nullptr, [&](const BankArgs& a) { return launch_bank_kin(a, kp.hi, kp.lo, st); },
+                        [&](const BankArgs& a) { return launch_bank_ptr_planes(a, m->P("#ptr_dim_t"), kp.hi, kp.lo, vt32, nt_c, slots, st); }));
+    } else {
+      TRY(launch_add_bcast_split(memory, 64, memory_pos, 64, 0, 1.0f, kp.hi, kp.lo, kp.ld, B * Nk, 64, st));
+    }
   } else {
     TRY(launch_add_bcast(memory, 64, memory_pos, 64, 0, 1.0f, kin, 64, B * Nk, 64, st));
   }

@@ -71,36 +71,60 @@ std::tuple<Tensor, Tensor, Tensor> image_encoder(int64_t model, const Tensor& fr
   return {f0, f1, f2};
 }
 
-// A11: tensor part of _prepare_memory_conditioned_features (sam2_base.py:565-648)
-std::tuple<Tensor, Tensor> bank_assemble(int64_t model, int64_t B, at::TensorList feats, at::IntArrayRef tpos_rows,
-                                         at::TensorList ptrs, at::ArrayRef<double> ptr_pos) {
-  TORCH_CHECK(feats.size() == tpos_rows.size() && ptrs.size() == ptr_pos.size(), "det_sam2::bank_assemble: table lengths differ");
-  TORCH_CHECK(feats.size() + ptrs.size() > 0, "det_sam2::bank_assemble: empty bank");
-  const Tensor& any = feats.size() ? feats[0] : ptrs[0];
-  c10::hip::HIPGuardMasqueradingAsCUDA g(any.device());
+// the entry tables of a bank as the C-ABI takes them (host arrays of device pointers)
+struct BankTables {
   std::vector<const void*> fp;
   std::vector<int32_t> rows;
+  std::vector<const float*> pp;
+  std::vector<float> pos;
+};
+static BankTables bank_tables(int64_t B, at::TensorList feats, at::IntArrayRef tpos_rows, at::TensorList ptrs, at::ArrayRef<double> ptr_pos,
+                              const char* who) {
+  TORCH_CHECK(feats.size() == tpos_rows.size() && ptrs.size() == ptr_pos.size(), "det_sam2::", who, ": table lengths differ");
+  TORCH_CHECK(feats.size() + ptrs.size() > 0, "det_sam2::", who, ": empty bank");
+  BankTables t;
   for (size_t i = 0; i < feats.size(); ++i) {
     want(feats[i], at::kBFloat16, "feats[i]");
     TORCH_CHECK(feats[i].dim() == 3 && feats[i].size(0) == B && feats[i].size(1) == TOK && feats[i].size(2) == 64,
-                "det_sam2::bank_assemble: feats[i] must be bf16 [B,4096,64]");
-    fp.push_back(feats[i].data_ptr());
-    rows.push_back((int32_t)tpos_rows[i]);
+                "det_sam2::", who, ": feats[i] must be bf16 [B,4096,64]");
+    t.fp.push_back(feats[i].data_ptr());
+    t.rows.push_back((int32_t)tpos_rows[i]);
   }
-  std::vector<const float*> pp;
-  std::vector<float> pos;
   for (size_t i = 0; i < ptrs.size(); ++i) {
     want(ptrs[i], at::kFloat, "ptrs[i]");
-    TORCH_CHECK(ptrs[i].dim() == 2 && ptrs[i].size(0) == B && ptrs[i].size(1) == 256, "det_sam2::bank_assemble: ptrs[i] must be fp32 [B,256]");
-    pp.push_back(ptrs[i].data_ptr<float>());
-    pos.push_back((float)ptr_pos[i]);
+    TORCH_CHECK(ptrs[i].dim() == 2 && ptrs[i].size(0) == B && ptrs[i].size(1) == 256, "det_sam2::", who, ": ptrs[i] must be fp32 [B,256]");
+    t.pp.push_back(ptrs[i].data_ptr<float>());
+    t.pos.push_back((float)ptr_pos[i]);
   }
+  return t;
+}
+
+// A11: tensor part of _prepare_memory_conditioned_features (sam2_base.py:565-648)
+std::tuple<Tensor, Tensor> bank_assemble(int64_t model, int64_t B, at::TensorList feats, at::IntArrayRef tpos_rows,
+                                         at::TensorList ptrs, at::ArrayRef<double> ptr_pos) {
+  BankTables t = bank_tables(B, feats, tpos_rows, ptrs, ptr_pos, "bank_assemble");
+  const Tensor& any = feats.size() ? feats[0] : ptrs[0];
+  c10::hip::HIPGuardMasqueradingAsCUDA g(any.device());
   const int64_t nk = (int64_t)feats.size() * TOK + 4 * (int64_t)ptrs.size();
   auto o = any.options().dtype(at::kFloat);
   Tensor mem = at::empty({B, nk, 64}, o), mpos = at::empty({B, nk, 64}, o);
-  check(ds2_bank_assemble(model_of(model), (int32_t)B, (int32_t)fp.size(), fp.data(), rows.data(), (int32_t)pp.size(), pp.data(),
-                          pos.data(), mem.data_ptr<float>(), mpos.data_ptr<float>(), stream_of(any)), "bank_assemble");
+  check(ds2_bank_assemble(model_of(model), (int32_t)B, (int32_t)t.fp.size(), t.fp.data(), t.rows.data(), (int32_t)t.pp.size(), t.pp.data(),
+                          t.pos.data(), mem.data_ptr<float>(), mpos.data_ptr<float>(), stream_of(any)), "bank_assemble");
   return {mem, mpos};
+}
+
+// A11 + A12 in one call (the tracking loop): the bank's entries -> memory-conditioned features [B,4096,256]; curr [4096,256] shared
+Tensor bank_memory_attention(int64_t model, int64_t B, const Tensor& curr, at::TensorList feats, at::IntArrayRef tpos_rows,
+                             at::TensorList ptrs, at::ArrayRef<double> ptr_pos) {
+  want(curr, at::kFloat, "curr");
+  TORCH_CHECK(curr.dim() == 2 && curr.size(0) == TOK && curr.size(1) == 256, "det_sam2::bank_memory_attention: curr must be [4096,256]");
+  BankTables t = bank_tables(B, feats, tpos_rows, ptrs, ptr_pos, "bank_memory_attention");
+  c10::hip::HIPGuardMasqueradingAsCUDA g(curr.device());
+  Tensor out = at::empty({B, TOK, 256}, curr.options());
+  check(ds2_bank_memory_attention(model_of(model), (int32_t)B, curr.data_ptr<float>(), (int32_t)t.fp.size(), t.fp.data(), t.rows.data(),
+                                  (int32_t)t.pp.size(), t.pp.data(), t.pos.data(), out.data_ptr<float>(), stream_of(curr)),
+        "bank_memory_attention");
+  return out;
 }
 
 // A12: MemoryAttention.forward (memory_attention.py:119-176).  curr [4096,256] shared by the B objects or [B,4096,256];
@@ -358,6 +382,7 @@ TORCH_LIBRARY(det_sam2, m) {
   m.def("ingest_frames(int model, Tensor frames_u8) -> Tensor");
   m.def("image_encoder(int model, Tensor frames) -> (Tensor, Tensor, Tensor)");
   m.def("bank_assemble(int model, int B, Tensor[] feats, int[] tpos_rows, Tensor[] ptrs, float[] ptr_pos) -> (Tensor, Tensor)");
+  m.def("bank_memory_attention(int model, int B, Tensor curr, Tensor[] feats, int[] tpos_rows, Tensor[] ptrs, float[] ptr_pos) -> Tensor");
   m.def("memory_attention(int model, int B, Tensor curr, Tensor? curr_pos, Tensor memory, Tensor memory_pos, int num_obj_ptr_tokens) -> Tensor");
   m.def("sam_heads(int model, int B, Tensor pix_feat, bool pix_bcast, bool add_no_mem_embed, Tensor fpn0, Tensor fpn1, "
         "Tensor? point_coords, Tensor? point_labels, Tensor? mask_inputs, bool multimask) -> (Tensor, Tensor, Tensor, Tensor)");
@@ -380,6 +405,7 @@ TORCH_LIBRARY_IMPL(det_sam2, CUDA, m) {
   m.impl("ingest_frames", &ingest_frames);
   m.impl("image_encoder", &image_encoder);
   m.impl("bank_assemble", &bank_assemble);
+  m.impl("bank_memory_attention", &bank_memory_attention);
   m.impl("memory_attention", &memory_attention);
   m.impl("sam_heads", &sam_heads);
   m.impl("prompt_encoder", &prompt_encoder);

@@ -233,6 +233,12 @@ class HipSam2(HipOps):
         return self.ops.bank_assemble(self._h, B, [t for t, _ in mem_entries], [int(r) for _, r in mem_entries],
                                       [t for t, _ in ptr_entries], [float(p) for _, p in ptr_entries])
 
+    def bank_attention(self, B, curr, mem_entries, ptr_entries):
+        """bank_assemble + memory_attention in one call (the tracking loop; A11 + A12): same result bit for bit; in mode bf16x3k the bank's
+        entries become the cross-attention's operands directly - the fp32 memory / memory_pos tensors are never written."""
+        return self.ops.bank_memory_attention(self._h, B, curr, [t for t, _ in mem_entries], [int(r) for _, r in mem_entries],
+                                              [t for t, _ in ptr_entries], [float(p) for _, p in ptr_entries])
+
     def memory_attention(self, B, curr, memory, memory_pos, num_obj_ptr_tokens):
         """curr [4096,256] shared; memory/memory_pos [B,Nk,64] -> [B,4096,256] (A12)."""
         return self.ops.memory_attention(self._h, B, curr, None, memory, memory_pos, num_obj_ptr_tokens)

@@ -403,8 +403,7 @@ class SAM2VideoPredictor:
             # _run_single_frame_inference(output_dict=<this object's slice>, batch_size=1, is_init_cond_frame=False):
             # memory-conditioned features from the object's own bank entries, then the SAM heads with the prompt
             mem_entries, ptr_entries = self._bank_for_frame(st, frame_idx, 1, reverse, od=obj_out)
-            memory, memory_pos = self.hip.bank_assemble(1, mem_entries, ptr_entries)
-            pix = self.hip.memory_attention(1, f2, memory, memory_pos, 4 * len(ptr_entries))
+            pix = self._memory_conditioned(1, f2, mem_entries, ptr_entries)
             low, ptr, obj, _ = self.hip.sam_heads(1, pix, f0, f1, pin["point_coords"], pin["point_labels"], multimask,
                                                   mask_inputs=prev_logits)
         low = self._fill_holes(low)
@@ -672,6 +671,15 @@ class SAM2VideoPredictor:
             self.trace.append(tr)
         return mem_entries, ptr_entries
 
+    def _memory_conditioned(self, B, f2, mem_entries, ptr_entries):
+        """_prepare_memory_conditioned_features' tensor part (sam2_base.py:565-690): bank -> memory attention.  One fused call when the
+        stage interface has it (the fp32 memory / memory_pos tensors are then never materialised), else the two stages."""
+        fused = getattr(self.hip, "bank_attention", None)
+        if fused is not None and mem_entries:
+            return fused(B, f2, mem_entries, ptr_entries)
+        memory, memory_pos = self.hip.bank_assemble(B, mem_entries, ptr_entries)
+        return self.hip.memory_attention(B, f2, memory, memory_pos, 4 * len(ptr_entries))
+
     def _fill_holes(self, low):
         """fill_holes_in_mask_scores on the low-res logits [B,256,256] (sam2_video_predictor.py:1343-1346)."""
         if self.fill_hole_area <= 0:
@@ -684,8 +692,7 @@ class SAM2VideoPredictor:
         no prompts, run_mem_encoder=True)  (sam2_video_predictor.py:1280-1365; sam2_base.py:857-919)."""
         f0, f1, f2 = self._get_image_feature(st, frame_idx)
         mem_entries, ptr_entries = self._bank_for_frame(st, frame_idx, B, reverse)
-        memory, memory_pos = self.hip.bank_assemble(B, mem_entries, ptr_entries)
-        pix = self.hip.memory_attention(B, f2, memory, memory_pos, 4 * len(ptr_entries))
+        pix = self._memory_conditioned(B, f2, mem_entries, ptr_entries)
         low, ptr, obj, _ = self.hip.sam_heads(B, pix, f0, f1, None, None, multimask=True)   # num_pts=0 => multimask
         mem = self.hip.memory_encoder(B, f2, low, obj, binarize=False)
         low = self._fill_holes(low)   # after the memory encoder, as in _run_single_frame_inference (:1343-1346)

@@ -110,6 +110,15 @@ int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const void* const*
 int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, const float* memory, const float* memory_pos,
                          int32_t Nk, int32_t num_obj_ptr_tokens, float* out, void* stream);
 
+/* ---- A11 + A12 in one call, the tracking loop's form (sam2_base.py:500-690: _prepare_memory_conditioned_features builds the bank and
+ * hands it to memory_attention): the entry tables of ds2_bank_assemble, curr as for ds2_memory_attention, out [B,4096,256].  Equal bit
+ * for bit to ds2_bank_assemble followed by ds2_memory_attention; in mode bf16x3k with the assembly cross-attention the bank's entries
+ * become the attention's operands directly (key-input planes, V^T tiles) and the fp32 memory / memory_pos [B,Nk,64] tensors are never
+ * written (DS2_BANK_DIRECT=0: assembled in the workspace first, as in every other mode). */
+int ds2_bank_memory_attention(ds2_model* m, int32_t B, const float* curr, int32_t n_mem, const void* const* feats,
+                              const int32_t* tpos_row, int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* out,
+                              void* stream);
+
 /* ---- A7+A8: SAM2Base._forward_sam_heads (sam2_base.py:254-397) = PromptEncoder.forward
  * (sam/prompt_encoder.py:134-171) + MaskDecoder.forward (sam/mask_decoder.py:105-161) + mask selection,
  * objectness gate, object pointer.  pix_feat: [B,4096,256], or [4096,256] shared when pix_bcast != 0

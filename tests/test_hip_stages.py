@@ -113,6 +113,12 @@ def test_memory_attention_and_bank(prec):
     e = rel_err(out, ref.transpose(0, 1))
     record("memory_attention", prec=prec, e_mem=e_mem, e_pos=e_pos, err=e)
     assert e_mem == 0.0 and e_pos < 1e-5 and e < TOL[prec], (e_mem, e_pos, e)
+    # ds2_bank_memory_attention (the tracking loop's one call): bit for bit the two stages, in every mode (3 pointers = 12 tokens: the
+    # pointer keys fill a part of the last V^T tile)
+    fused = hm.bank_attention(B, curr.to(d), [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)],
+                              [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)])
+    torch.cuda.synchronize()
+    assert torch.equal(fused, out), float((fused - out).abs().max())
 
 
 def test_bank_assemble_beyond_40_entries():
@@ -185,6 +191,15 @@ def test_memory_attention_at_bench_size(B, NF, NP, x4a, monkeypatch):
         again = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP)
         torch.cuda.synchronize()
         assert torch.equal(again, out), float((again - out).abs().max())
+    # the one-call form of the tracking loop: with the assembly attention the bank's entries become kin planes / V^T tiles directly
+    # (no fp32 memory / memory_pos), with DS2_BANK_DIRECT=0 or the 8-wave kernel through fp32 tensors in the workspace - same bits
+    entries = [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)]
+    pentries = [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)]
+    for direct in ("1", "0"):
+        monkeypatch.setenv("DS2_BANK_DIRECT", direct)
+        fused = hm.bank_attention(B, curr.to(d), entries, pentries)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, out), (direct, float((fused - out).abs().max()))
 
 
 @pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True), ("click", True), ("clicks", False), ("clicks12", False)])
