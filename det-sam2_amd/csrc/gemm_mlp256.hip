@@ -118,7 +118,7 @@ __device__ __forceinline__ void wait_vm_lgkm() {   // s_waitcnt needs an immedia
 // LNF: the LayerNorm of the result rows in the epilogue is compiled in (MlpArgs::ln_w).  A template parameter since round 5: with the
 // LayerNorm code present EVERY instantiation - all at the full 512 registers - spilled 29 - 40 VGPRs to scratch;
 // without it none does, so only the one instantiation that uses the fusion (ReLU, two fp16 terms: the memory attention's FFN) carries it.
-template <int ACT, bool X2, bool LNF>
+template <int ACT, bool X2, bool LNF, bool LNI = false>
 __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   using FragT = typename std::conditional<X2, f16x8, bf16x8>::type;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   }
   lns[2 * MD + tid] = a.b2 ? a.b2[tid] : 0.f;
   lns[3 * MD + tid] = a.gamma ? a.gamma[tid] : 1.f;
+  if constexpr (LNI) {      // weight / bias of the input LayerNorm: [4 MD, 6 MD)
+    lns[4 * MD + tid] = a.lni_w[tid];
+    lns[5 * MD + tid] = a.lni_b[tid];
+  }
 
   const char* w1h = reinterpret_cast<const char*>(a.W1_hi);
   const char* w1l = reinterpret_cast<const char*>(a.W1_lo);
@@ -264,7 +268,71 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     const int tokc = tok < a.rows ? tok : a.rows - 1;   // clamp: rows beyond the end are computed but never stored
     // ---- X fragments of this wave's 32 tokens: B operand (token = lane & 31, k = 16 s + 8 half .. + 7), both planes
     FragT xh[MD / 16], xl[X2 ? 1 : MD / 16];
-    {
+    if constexpr (LNI) {
+      static_assert(!LNI || X2, "the input LayerNorm is built for the two-fp16-term form");
+      if (rb == (int)blockIdx.x) __syncthreads();   // (the staged LayerNorm weight / bias: first row block only)
+      // this lane's half of the token's row: columns 16 s + 8 half + j, j = 0..7 - the float4 groups 4 s + 2 half + jj of k_layernorm_vec
+      const float* px = a.X_f32 + (size_t)tokc * a.ldxf + half * 8;
+      float4 v[MD / 16][2];
+#pragma unroll
+      for (int s = 0; s < MD / 16; ++s) {
+        v[s][0] = *reinterpret_cast<const float4*>(px + s * 16);
+        v[s][1] = *reinterpret_cast<const float4*>(px + s * 16 + 4);
+      }
+      // wave_sum's butterfly (xor 32, 16, 8, 4, 2, 1 over the 64 float4 groups of the row) as a tree: group index L = 4 s + 2 half + jj, so
+      // xor 32 / 16 / 8 / 4 pair s with s ^ 8 / 4 / 2 / 1 (in this lane), xor 2 is the other half (lane ^ 32), xor 1 is jj
+      auto both = [](float x) {          // x + (the same quantity of lane ^ 32): the pair holds both, addition commutes
+        const unsigned u = __float_as_uint(x);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      };
+      auto tree = [&](float (&p)[MD / 16][2]) {
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1)
+#pragma unroll
+          for (int s = 0; s < d; ++s) {
+            p[s][0] = p[s][0] + p[s + d][0];
+            p[s][1] = p[s][1] + p[s + d][1];
+          }
+        const float t0 = both(p[0][0]), t1 = both(p[0][1]);
+        return t0 + t1;
+      };
+      float ps[MD / 16][2];
+#pragma unroll
+      for (int s = 0; s < MD / 16; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) ps[s][jj] = (v[s][jj].x + v[s][jj].y) + (v[s][jj].z + v[s][jj].w);
+      const float mean = tree(ps) / (float)MD;
+#pragma unroll
+      for (int s = 0; s < MD / 16; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const float d0 = v[s][jj].x - mean, d1 = v[s][jj].y - mean, d2 = v[s][jj].z - mean, d3 = v[s][jj].w - mean;
+          ps[s][jj] = 0.f + ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        }
+      const float rstd = 1.f / sqrtf(tree(ps) / (float)MD + a.lni_eps);
+#pragma unroll
+      for (int s = 0; s < MD / 16; ++s) {
+        unsigned r[4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int c = 16 * s + 8 * half + 4 * jj;
+          const float4 w4 = *reinterpret_cast<const float4*>(lns + 4 * MD + c), b4 = *reinterpret_cast<const float4*>(lns + 5 * MD + c);
+          float4 o;
+          o.x = (v[s][jj].x - mean) * rstd * w4.x + b4.x;
+          o.y = (v[s][jj].y - mean) * rstd * w4.y + b4.y;
+          o.z = (v[s][jj].z - mean) * rstd * w4.z + b4.z;
+          o.w = (v[s][jj].w - mean) * rstd * w4.w + b4.w;
+          // the planes a LayerNorm pass would store (k_layernorm_vec), then their sum rounded to the one fp16 plane as below
+          const unsigned h0 = cvt_pk_bf16(o.x, o.y), h1 = cvt_pk_bf16(o.z, o.w);
+          const unsigned l0 = cvt_pk_bf16(o.x - bf_lo(h0), o.y - bf_hi(h0)), l1 = cvt_pk_bf16(o.z - bf_lo(h1), o.w - bf_hi(h1));
+          r[2 * jj] = cvt_pk_f16(bf_lo(h0) + bf_lo(l0), bf_hi(h0) + bf_hi(l0));
+          r[2 * jj + 1] = cvt_pk_f16(bf_lo(h1) + bf_lo(l1), bf_hi(h1) + bf_hi(l1));
+        }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        xh[s] = __builtin_bit_cast(FragT, (u32x4{r[0], r[1], r[2], r[3]}));
+      }
+    } else {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4* ph = reinterpret_cast<const u32x4*>(a.X_hi + (size_t)tokc * a.ldx + half * 8);
       const u32x4* pl = reinterpret_cast<const u32x4*>(a.X_lo + (size_t)tokc * a.ldx + half * 8);
@@ -640,7 +708,10 @@ size_t mlp256_part_bytes(int rows, int H) {
 
 int launch_mlp256(const MlpArgs& a, hipStream_t st) {
   DS2_REQUIRE(mlp256_supported(a), "mlp256: unsupported shape rows=%d D=%d H=%d", a.rows, a.D, a.H);
-  DS2_REQUIRE(a.X_hi && a.X_lo && a.W1_hi && a.W1_lo && a.W2_hi && a.W2_lo && a.out, "mlp256: null operand");
+  const bool lni = a.lni_w != nullptr;
+  DS2_REQUIRE(((a.X_hi && a.X_lo) || lni) && a.W1_hi && a.W1_lo && a.W2_hi && a.W2_lo && a.out, "mlp256: null operand");
+  DS2_REQUIRE(!lni || (a.X_f32 && a.lni_b && a.ldxf % 4 == 0 && a.f16x2 && (a.act == DS2_ACT_RELU || a.act == DS2_ACT_GELU)),
+              "mlp256: the input LayerNorm is built for the two-fp16-term ReLU / GELU forms (memory attention FFN, memory encoder CXBlock)");
   const int ncu = mlp256_ncu();
   const int nrb = cdiv(a.rows, MBR);
   MlpArgs b = a;
@@ -650,7 +721,7 @@ int launch_mlp256(const MlpArgs& a, hipStream_t st) {
     if (hs > 1 && a.part_bytes >= (size_t)hs * a.rows * MD * sizeof(float)) b.hsplit = hs;
   }
   const int grid = nrb < ncu ? nrb : ncu;
-  const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4 + 4 * MD * 4;   // ring + b1 + (LayerNorm weight, bias, b2, gamma)
+  const size_t smem = (size_t)MNS * MSLOT + (size_t)a.H * 4 + 6 * MD * 4;   // ring + b1 + (LayerNorm weight, bias, b2, gamma; input LayerNorm weight, bias)
   void (*kern)(MlpArgs) = nullptr;
   const bool x2 = a.f16x2 != 0;
   const bool lnf = a.ln_w != nullptr && b.hsplit == 1;   // (with the hidden split the merge kernel normalises)
@@ -658,16 +729,19 @@ int launch_mlp256(const MlpArgs& a, hipStream_t st) {
   switch (a.act) {
     case DS2_ACT_NONE: kern = x2 ? k_mlp256<DS2_ACT_NONE, true, false> : k_mlp256<DS2_ACT_NONE, false, false>; break;
     case DS2_ACT_RELU:
-      kern = x2 ? (lnf ? k_mlp256<DS2_ACT_RELU, true, true> : k_mlp256<DS2_ACT_RELU, true, false>)
+      kern = x2 ? (lni ? (lnf ? k_mlp256<DS2_ACT_RELU, true, true, true> : k_mlp256<DS2_ACT_RELU, true, false, true>)
+                       : (lnf ? k_mlp256<DS2_ACT_RELU, true, true> : k_mlp256<DS2_ACT_RELU, true, false>))
                 : (lnf ? k_mlp256<DS2_ACT_RELU, false, true> : k_mlp256<DS2_ACT_RELU, false, false>);
       break;
-    case DS2_ACT_GELU: kern = x2 ? k_mlp256<DS2_ACT_GELU, true, false> : k_mlp256<DS2_ACT_GELU, false, false>; break;
+    case DS2_ACT_GELU:
+      kern = x2 ? (lni ? k_mlp256<DS2_ACT_GELU, true, false, true> : k_mlp256<DS2_ACT_GELU, true, false>) : k_mlp256<DS2_ACT_GELU, false, false>;
+      break;
     default: DS2_REQUIRE(false, "mlp256: unsupported activation %d", a.act);
   }
-  static bool attr_done[2][2][4] = {};
-  if (!attr_done[lnf][x2][a.act]) {
+  static bool attr_done[2][2][2][4] = {};
+  if (!attr_done[lni][lnf][x2][a.act]) {
     DS2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[lnf][x2][a.act] = true;
+    attr_done[lni][lnf][x2][a.act] = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid, b.hsplit), dim3(256), smem, st, b);
   DS2_CHECK_LAUNCH();

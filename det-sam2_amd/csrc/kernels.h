@@ -182,6 +182,11 @@ struct MlpArgs {
   // row block; each writes its raw partial result to part [hsplit][rows][256] and k_mlp256_merge adds them up and applies the
   // epilogue (bias, gamma, residual, LayerNorm, planes).  Set by launch_mlp256 when `part` (scratch) is provided.
   float* part; size_t part_bytes; int hsplit;
+  // fused LayerNorm of the INPUT rows (round 5: norm3 of the memory attention): when lni_w is set, X is read as fp32 rows X_f32 [rows, ldxf]
+  // (X_hi / X_lo unused) and normalised in the kernel's prologue - the statistics in k_layernorm_vec's association order, the result
+  // split into bf16 planes in registers and rounded to the fp16 plane exactly as the planes of a separate LayerNorm pass would be
+  // (bit-identical); two-fp16-term ReLU / GELU forms
+  const float* X_f32; int ldxf; const float *lni_w, *lni_b; float lni_eps;
 };
 bool mlp256_supported(const MlpArgs& a);
 int launch_mlp256_permute_w2(const float* w2, int ldw, int n_rows, int H, float* out, hipStream_t st);

@@ -455,7 +455,8 @@ static bool mlp_fused_enabled() {
 // A's operand planes must be registered (its producer emitted them) or are split here.
 static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H, const float* A, int lda, const float* W1,
                      const float* b1, const float* W2, const float* b2, const float* gamma, const float* R, int ldr, float* out,
-                     int ldo, int act, bool planes_too = false, bool f16x2 = false, const LnFuse* lnf = nullptr) {
+                     int ldo, int act, bool planes_too = false, bool f16x2 = false, const LnFuse* lnf = nullptr,
+                     const LnFuse* lni = nullptr) {   // lni: LayerNorm of the INPUT rows in the kernel's prologue (A = the un-normalised fp32 rows)
   if (!ds2_split_mode() || !mlp_fused_enabled() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
   MlpArgs a{};
   a.f16x2 = f16x2 ? 1 : 0;
@@ -509,11 +510,15 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     lk2.unlock();
   }
   const unsigned short *xh = nullptr, *xl = nullptr;
-  if (m) {
+  if (lni) {
+    DS2_REQUIRE(f16x2 && (act == DS2_ACT_RELU || act == DS2_ACT_GELU) && lni->w && lni->b && lda % 4 == 0,
+                "mlp_fused: input LayerNorm needs the two-fp16-term ReLU / GELU form");
+    a.X_f32 = A; a.ldxf = lda; a.lni_w = lni->w; a.lni_b = lni->b; a.lni_eps = lni->eps;
+  } else if (m) {
     auto ia = m->act_planes.find(A);
     if (ia != m->act_planes.end() && ia->second.ld == 256) { xh = ia->second.hi; xl = ia->second.lo; }
   }
-  if (!xh) {
+  if (!xh && !lni) {
     TRY(ctx.require((size_t)rows * 256 * 4 + 512, st));
     unsigned short* sh = reinterpret_cast<unsigned short*>(ctx.scratch);
     unsigned short* sl = sh + (size_t)rows * 256;
@@ -549,12 +554,13 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
 // planes_too: `out` feeds a GEMM next - the fused kernel writes its operand planes alongside the fp32 result
 static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::string& p2, int rows, int H, const float* A,
                 float* hbuf, float* out, int act, const float* R, const float* gamma, bool planes_too = false, bool f16x2 = false,
-                const LnFuse* lnf = nullptr, bool* ln_done = nullptr) {
+                const LnFuse* lnf = nullptr, bool* ln_done = nullptr, const LnFuse* lni = nullptr) {
   m->act_planes.erase(out);   // (`out` is rewritten: planes registered for its previous contents are stale)
   const int rc = mlp_fused(m, m->gctx, st, rows, H, A, 256, m->P(p1 + ".weight"), m->P(p1 + ".bias"), m->P(p2 + ".weight"),
-                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too, f16x2, lnf);
+                           m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too, f16x2, lnf, lni);
   if (ln_done) *ln_done = lnf && rc == DS2_OK;
   if (rc != DS2_ERR_UNSUPPORTED) return rc;
+  DS2_REQUIRE(!lni, "mlp2: the fused kernel cannot take this shape and the input was left un-normalised for it");
   TRY(linear(m, st, p1, rows, H, 256, A, 256, hbuf, H, act, nullptr, 0, 0, nullptr, true));
   return linear(m, st, p2, rows, 256, H, hbuf, H, out, 256, DS2_ACT_NONE, R, 256, 0, gamma);
 }
@@ -1331,14 +1337,21 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
                  true));   // only consumer: out_proj GEMM
       TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     }
-    // -- FFN
-    TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
+    // -- FFN.  norm3 runs in the fused MLP's prologue when that kernel takes the layer in its two-fp16-term form (DS2_MA_LN3_FUSE=0: as
+    //    its own pass writing the operand planes; same bits either way)
+    MlpArgs probe{};
+    probe.rows = rows; probe.D = 256; probe.H = F; probe.ldx = 256; probe.ldw1 = 256; probe.ldw2 = F; probe.ldo = 256; probe.ldr = 256;
+    const char* l3e = getenv("DS2_MA_LN3_FUSE");
+    const bool ln3_in = split && mlp_fused_enabled() && f16x2_enabled() && mlp256_supported(probe) && !(l3e && atoi(l3e) == 0) &&
+                        m->P(p + ".norm3.weight") && m->P(p + ".norm3.bias");
+    const LnFuse lni{m->P(p + ".norm3.weight"), m->P(p + ".norm3.bias"), 1e-5f, nullptr, nullptr};
+    if (!ln3_in) TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
     const bool last = l + 1 == m->cfg.mem_attn_layers;
     const std::string pn = last ? std::string("memory_attention.norm") : "memory_attention.layers." + std::to_string(l + 1) + ".norm1";
     const LnFuse lnf{m->P(pn + ".weight"), m->P(pn + ".bias"), 1e-5f, last ? out : nullptr, last ? nullptr : &n1p[(l + 1) & 1]};
     bool ln_done = false;
-    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, t, h, x, DS2_ACT_RELU, x, nullptr, false, f16x2_enabled(),
-             (fuse_ln && lnf.w && lnf.b) ? &lnf : nullptr, &ln_done));
+    TRY(mlp2(m, st, p + ".linear1", p + ".linear2", rows, F, ln3_in ? x : t, h, x, DS2_ACT_RELU, x, nullptr, false, f16x2_enabled(),
+             (fuse_ln && lnf.w && lnf.b) ? &lnf : nullptr, &ln_done, ln3_in ? &lni : nullptr));
     n1_ready = ln_done && !last;
     final_done = ln_done && last;
     m->release(layer_mark);
@@ -1855,9 +1868,17 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   for (int l = 0; l < 2; ++l) {
     const std::string p = me + ".fuser.layers." + std::to_string(l);
     TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
-    TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
-    TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma"),
-             DS2_ME_X_PLANES && l == 1, f16x2_enabled()));   // the last block's result feeds out_proj
+    // the CXBlock's LayerNorm in the fused MLP's prologue when that kernel takes the block in its two-fp16-term form (DS2_ME_LN_FUSE=0: as its
+    // own pass; same bits either way)
+    MlpArgs probe{};
+    probe.rows = rows; probe.D = 256; probe.H = 1024; probe.ldx = 256; probe.ldw1 = 256; probe.ldw2 = 1024; probe.ldo = 256; probe.ldr = 256;
+    const char* lfe = getenv("DS2_ME_LN_FUSE");
+    const bool ln_in = ds2_split_mode() && mlp_fused_enabled() && f16x2_enabled() && mlp256_supported(probe) && !(lfe && atoi(lfe) == 0) &&
+                       m->P(p + ".norm.weight") && m->P(p + ".norm.bias");
+    const LnFuse lni{m->P(p + ".norm.weight"), m->P(p + ".norm.bias"), 1e-6f, nullptr, nullptr};
+    if (!ln_in) TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
+    TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, ln_in ? d : t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma"),
+             DS2_ME_X_PLANES && l == 1, f16x2_enabled(), nullptr, nullptr, ln_in ? &lni : nullptr));   // the last block's result feeds out_proj
   }
   if (out_f32) {      // MemoryEncoder.forward's own output (no no_obj_embed_spatial, no bf16 storage rounding)
     TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, out_f32, 64));
