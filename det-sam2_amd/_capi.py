@@ -43,6 +43,7 @@ SIGNATURES = {
     "ds2_bank_assemble": (C.c_int, [c_vp, i32, i32, C.POINTER(c_vp), C.POINTER(i32), i32, C.POINTER(c_vp),
                                     C.POINTER(C.c_float), c_vp, c_vp, c_vp]),
     "ds2_memory_attention": (C.c_int, [c_vp, i32, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp]),
+    "ds2_op_query_fragments": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp]),
     "ds2_bank_memory_attention": (C.c_int, [c_vp, i32, c_vp, i32, C.POINTER(c_vp), C.POINTER(i32), i32, C.POINTER(c_vp),
                                             C.POINTER(C.c_float), c_vp, c_vp]),
     "ds2_sam_heads": (C.c_int, [c_vp, i32, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, i32, i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

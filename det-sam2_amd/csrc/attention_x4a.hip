@@ -208,6 +208,20 @@ const unsigned char* attention_x4a_vt_slot_table() {   // vt_pos32 as a device t
   return tab[dev];
 }
 
+// the query pass alone (ds2_op_query_fragments: the reference form of gemm_qproj.hip's output)
+int launch_x4a_qprep(const float* q, int ldq, int batch, int Lq, bool q_shared, float scale, const float* cis, int rope_grid, void* qfrag,
+                     hipStream_t st) {
+  DS2_REQUIRE(q && qfrag && ldq % 4 == 0 && batch > 0 && Lq > 0 && Lq % 64 == 0, "x4a_qprep: bad argument");
+  int rope_w = 0;
+  for (int x = 1; x * x <= rope_grid; ++x)
+    if (x * x == rope_grid) rope_w = x;
+  const size_t nq = ((size_t)batch * Lq / 64) * 32 * 64;
+  hipLaunchKernelGGL(k_x4a_qprep, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, q, ldq, batch, Lq, q_shared ? 0 : Lq,
+                     scale * 1.44269504088896340736f, cis, rope_grid, rope_w, reinterpret_cast<uint4*>(qfrag));
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+
 int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStream_t st) {
   const size_t n = (size_t)batch * ((L + 31) / 32) * DV;
   hipLaunchKernelGGL(k_vt_pack32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, ldv, batch, L, reinterpret_cast<unsigned short*>(vt));
@@ -221,7 +235,8 @@ int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void*
                          hipStream_t st, void* o_hi, void* o_lo, int ldop, const float* q_rope_cis, int q_rope_grid, bool q_shared,
                          void* ws, size_t ws_bytes) {
   DS2_REQUIRE(attention_x4a_supported(batch, Lq, Lk, DV, o_hi && o_lo), "attention_x4a: unsupported shape");
-  DS2_REQUIRE(ldq % 4 == 0 && ldop % 4 == 0 && q && k_f16 && vt32 && ws && ws_bytes >= attention_x4a_ws_bytes(batch, Lq, Lk),
+  // q == nullptr: the Q fragments at the start of `ws` are already there (launch_qproj_x4a, gemm_qproj.hip)
+  DS2_REQUIRE(ldq % 4 == 0 && ldop % 4 == 0 && k_f16 && vt32 && ws && ws_bytes >= attention_x4a_ws_bytes(batch, Lq, Lk),
               "attention_x4a: bad argument / scratch too small");
   const size_t rows = (size_t)batch * Lq;
   char* w = reinterpret_cast<char*>(ws);
@@ -234,9 +249,11 @@ int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void*
     if (x * x == q_rope_grid) rope_w = x;
   DS2_REQUIRE(!q_rope_cis || q_rope_grid > 0, "attention_x4a: rope grid");
   const size_t nq = (rows / 64) * 32 * 64;
-  hipLaunchKernelGGL(k_x4a_qprep, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, q, ldq, batch, Lq, q_shared ? 0 : Lq,
-                     scale * 1.44269504088896340736f, q_rope_cis, q_rope_grid, rope_w, reinterpret_cast<uint4*>(qfrag));
-  DS2_CHECK_LAUNCH();
+  if (q) {
+    hipLaunchKernelGGL(k_x4a_qprep, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, q, ldq, batch, Lq, q_shared ? 0 : Lq,
+                       scale * 1.44269504088896340736f, q_rope_cis, q_rope_grid, rope_w, reinterpret_cast<uint4*>(qfrag));
+    DS2_CHECK_LAUNCH();
+  }
   X4AArgs a{reinterpret_cast<const char*>(k_f16), reinterpret_cast<const char*>(vt32), qfrag, part_o, part_ml, batch, Lq, Lk, nsplit};
   hipLaunchKernelGGL(k_attention_x4a, dim3(batch * (Lq / 256), nsplit), dim3(256), 0, st, a);
   DS2_CHECK_LAUNCH();

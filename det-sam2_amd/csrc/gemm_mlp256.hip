@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const float d0 = v[s][jj].x - mean, d1 = v[s][jj].y - mean, d2 = v[s][jj].z - mean, d3 = v[s][jj].w - mean;
-          ps[s][jj] = 0.f + ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+          ps[s][jj] = 0.f + (__builtin_fmaf(d0, d0, d1 * d1) + __builtin_fmaf(d2, d2, d3 * d3));   // (k_layernorm_vec's contraction, spelled out)
         }
       const float rstd = 1.f / sqrtf(tree(ps) / (float)MD + a.lni_eps);
 #pragma unroll

@@ -91,6 +91,13 @@ int launch_bank_vt32(const BankArgs& a, void* vt32, hipStream_t st);            
 int launch_bank_ptr_planes(const BankArgs& a, const float* dim_t, void* hi, void* lo, void* vt32, int ntile,
                            const unsigned char* vt_slot /*device [32]: key & 31 -> slot*/, hipStream_t st);
 const unsigned char* attention_x4a_vt_slot_table();                                        // device table of vt_pos32
+// norm2 + q_proj + RoPE + scale + fp16 pack of the memory cross-attention's queries in one kernel, straight into the assembly attention's
+// Q fragments (gemm_qproj.hip); nrep > 1: rows = Lq shared queries written for nrep objects
+int launch_x4a_qprep(const float* q, int ldq, int batch, int Lq, bool q_shared, float scale, const float* cis, int rope_grid, void* qfrag,
+                     hipStream_t st);
+bool qproj_x4a_supported(int rows, int ldx, int ldw);
+int launch_qproj_x4a(const float* x, int ldx, int rows, const float* ln_w, const float* ln_b, float ln_eps, const void* w_hi, const void* w_lo,
+                     int ldw, const float* bias, const float* cis, int rope_grid, float scale, void* qfrag, int nrep, hipStream_t st);
 
 // outputs
 int launch_mask_output(const float* low, int B, int hin, int Hv, int Wv, float* logits /*nullable*/,

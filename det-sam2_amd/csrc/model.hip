@@ -1102,6 +1102,34 @@ extern "C" int ds2_memory_attention_ex(ds2_model* m, int32_t B, const float* cur
 }
 // bank != nullptr (ds2_bank_memory_attention): memory / memory_pos are NOT given - the bank's entries are turned into the cross-attention's
 // operands directly (kin planes, V^T tiles) when the assembly attention runs, else assembled as fp32 tensors in the workspace first
+// the queries of the memory cross-attention of one layer as the assembly attention's Q fragments, by the fused kernel (fused != 0:
+// gemm_qproj.hip) or by the three kernels it replaces (LayerNorm pass -> GEMM -> query pass): unit test of the former against the latter
+extern "C" int ds2_op_query_fragments(ds2_model* m, int32_t layer, const float* x, int32_t rows, int32_t fused, void* qfrag, void* stream) {
+  DS2_REQUIRE(m && m->finalized && x && qfrag && rows > 0 && rows % 64 == 0 && layer >= 0 && layer < m->cfg.mem_attn_layers,
+              "ds2_op_query_fragments: bad argument");
+  ModelScope _dg(m);
+  hipStream_t st = (hipStream_t)stream;
+  const std::string p = "memory_attention.layers." + std::to_string(layer);
+  const float* cis = m->P("#rope_cis");
+  const float* qw = m->P(p + ".cross_attn_image.q_proj.weight");
+  const float sc = 1.0f / 16.0f;
+  CHECK_PARAMS();
+  if (fused) {
+    DS2_REQUIRE(ds2_split_mode() && qproj_x4a_supported(rows, 256, 256), "ds2_op_query_fragments: the fused kernel needs a split mode");
+    GemmPlanes qwp;
+    TRY(weight_planes(m->gctx, qw, 256, 256, &qwp, st));
+    return launch_qproj_x4a(x, 256, rows, m->P(p + ".norm2.weight"), m->P(p + ".norm2.bias"), 1e-5f, qwp.hi, qwp.lo, qwp.ld,
+                            m->P(p + ".cross_attn_image.q_proj.bias"), cis, TOK, sc, qfrag, 1, st);
+  }
+  TRY(m->require((size_t)rows * 256 * 4 * 4 + (8u << 20), st));
+  ALLOC(t, (size_t)rows * 256);
+  ALLOC(q, (size_t)rows * 256);
+  TRY(layernorm(m, st, p + ".norm2", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
+  TRY(linear(m, st, p + ".cross_attn_image.q_proj", rows, 256, 256, t, 256, q, 256));
+  m->act_planes.erase(t);
+  return launch_x4a_qprep(q, 256, 1, rows, false, sc, cis, TOK, qfrag, st);
+}
+
 extern "C" int ds2_bank_memory_attention(ds2_model* m, int32_t B, const float* curr, int32_t n_mem, const void* const* feats,
                                          const int32_t* tpos_row, int32_t n_ptr, const float* const* ptrs, const float* ptr_pos,
                                          float* out, void* stream) {
@@ -1295,8 +1323,21 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     //    softmax(QK^T) (M Wv^T + bv) = (softmax(QK^T) M) Wv^T + bv, so P.V runs in the 64-d memory space.
     m->act_planes.erase(a);   // self-attention planes are consumed; `a` is re-used below
     const int qrows = q_once ? TOK : rows;
-    TRY(layernorm(m, st, p + ".norm2", q_once ? x1 : x, t, qrows, 256, 1e-5f, DS2_ACT_NONE, true));
-    TRY(linear(m, st, p + ".cross_attn_image.q_proj", qrows, 256, 256, t, 256, q, 256));
+    // norm2 -> q_proj -> RoPE -> scale -> fp16 Q fragments of the assembly attention as ONE kernel (gemm_qproj.hip; DS2_MA_QFUSE=0: the
+    // LayerNorm pass, the GEMM and the attention's query pass; same bits either way)
+    const char* qfe = getenv("DS2_MA_QFUSE");
+    const float* qw = m->P(p + ".cross_attn_image.q_proj.weight");
+    const bool qfuse = x4a && qw && !(qfe && atoi(qfe) == 0) && qproj_x4a_supported(qrows, 256, 256) &&
+                       m->P(p + ".norm2.weight") && m->P(p + ".norm2.bias");
+    if (qfuse) {
+      GemmPlanes qwp;
+      TRY(weight_planes(m->gctx, qw, 256, 256, &qwp, st));
+      TRY(launch_qproj_x4a(q_once ? x1 : x, 256, qrows, m->P(p + ".norm2.weight"), m->P(p + ".norm2.bias"), 1e-5f, qwp.hi, qwp.lo, qwp.ld,
+                           m->P(p + ".cross_attn_image.q_proj.bias"), cis, TOK, sc, x4a_ws, q_once ? B : 1, st));
+    } else {
+      TRY(layernorm(m, st, p + ".norm2", q_once ? x1 : x, t, qrows, 256, 1e-5f, DS2_ACT_NONE, true));
+      TRY(linear(m, st, p + ".cross_attn_image.q_proj", qrows, 256, 256, t, 256, q, 256));
+    }
     if (!split) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     if (split) {
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
@@ -1313,7 +1354,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       ds2_model::ActPlanes cp;
       TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
       if (x4a)
-        TRY(launch_attention_x4a(q, 256, khi, vt32, B, TOK, Nk, sc, st, cp.hi, cp.lo, cp.ld, cis, TOK, q_once, x4a_ws, x4a_ws_bytes));
+        TRY(launch_attention_x4a(qfuse ? nullptr : q, 256, khi, vt32, B, TOK, Nk, sc, st, cp.hi, cp.lo, cp.ld, cis, TOK, q_once, x4a_ws, x4a_ws_bytes));
       else
         TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
                                 Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once, ksplit_ws, ksplit_bytes));

@@ -233,6 +233,14 @@ class HipSam2(HipOps):
         return self.ops.bank_assemble(self._h, B, [t for t, _ in mem_entries], [int(r) for _, r in mem_entries],
                                       [t for t, _ in ptr_entries], [float(p) for _, p in ptr_entries])
 
+    def op_query_fragments(self, layer, x, fused):
+        """test hook (ds2_op_query_fragments): x fp32 [rows,256] -> the layer's cross-attention queries as fp16 Q fragments [rows*256] int16."""
+        import torch
+        out = torch.empty(x.shape[0] * 256, dtype=torch.int16, device=x.device)
+        _capi.check(self.lib.ds2_op_query_fragments(self.h, int(layer), C.c_void_p(x.data_ptr()), x.shape[0], int(bool(fused)),
+                                                    C.c_void_p(out.data_ptr()), self._stream()), "ds2_op_query_fragments")
+        return out
+
     def bank_attention(self, B, curr, mem_entries, ptr_entries):
         """bank_assemble + memory_attention in one call (the tracking loop; A11 + A12): same result bit for bit; in mode bf16x3k the bank's
         entries become the cross-attention's operands directly - the fp32 memory / memory_pos tensors are never written."""

@@ -119,6 +119,11 @@ int ds2_bank_memory_attention(ds2_model* m, int32_t B, const float* curr, int32_
                               const int32_t* tpos_row, int32_t n_ptr, const float* const* ptrs, const float* ptr_pos, float* out,
                               void* stream);
 
+/* test hook: the cross-attention queries of memory-attention layer `layer` for fp32 rows x [rows,256] (rows % 64 == 0) in the assembly
+ * attention's fragment order (rows/64 * 32 KiB): norm2 -> q_proj -> RoPE (row index modulo 4096) -> scale -> fp16, by the fused kernel
+ * (fused != 0, gemm_qproj.hip) or by the three kernels it replaces. */
+int ds2_op_query_fragments(ds2_model* m, int32_t layer, const float* x, int32_t rows, int32_t fused, void* qfrag, void* stream);
+
 /* ---- A7+A8: SAM2Base._forward_sam_heads (sam2_base.py:254-397) = PromptEncoder.forward
  * (sam/prompt_encoder.py:134-171) + MaskDecoder.forward (sam/mask_decoder.py:105-161) + mask selection,
  * objectness gate, object pointer.  pix_feat: [B,4096,256], or [4096,256] shared when pix_bcast != 0

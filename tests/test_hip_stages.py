@@ -351,3 +351,21 @@ def test_key_projection_epilogues_agree(prec, B, NF, NP, monkeypatch):
         torch.cuda.synchronize()
         hm.profile_enable(False)
     assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
+
+
+@pytest.mark.parametrize("rows", [4096, 8192 + 64])
+def test_fused_query_kernel_equals_the_three_kernels_it_replaces(rows):
+    """gemm_qproj.hip (norm2 -> q_proj -> RoPE -> scale -> fp16 Q fragments of the assembly cross-attention in one kernel;
+    memory_attention.py:74-87, sam/transformer.py:312-363) against k_layernorm_vec -> bf16x3 GEMM -> k_x4a_qprep through the test hook
+    ds2_op_query_fragments: every fp16 value of every layer's fragments, bit for bit (the LayerNorm statistics are summed in the separate
+    kernel's association order, the MFMA terms in the tile kernels' order, the rotation in the query pass's contraction).  4096 rows: the
+    shared queries of layer 0; 8256: a ragged last 128-row block."""
+    cfg, sd, hm = model("sam2.1_hiera_t", "bf16x3k")
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, 256, generator=g) * 2 + 0.3).to(hm.device)
+    for layer in range(cfg.mem_attn_layers if hasattr(cfg, "mem_attn_layers") else 4):
+        ref = hm.op_query_fragments(layer, x, False)
+        got = hm.op_query_fragments(layer, x, True)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), (layer, int((got != ref).sum()))
+    assert ref.view(torch.float16).float().abs().max() > 0.1          # (not a comparison of zeros)
