@@ -226,13 +226,18 @@ def kernel_probe(pred, gen, st, last_tracked, table_path=None):
            "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": top["tflops"] / peak, "avg_launch_ms": top["avg_us"] * 1e-3,
            "calls_per_frame": top["calls_per_frame"], "family_ms_per_frame": total, "family_tflops": flops / (total * 1e-3) / 1e12,
            "family_frac": flops / (total * 1e-3) / 1e12 / peak,
-           # the fused two-layer MLP launches (k_mlp256: memory-attention FFN, CXBlock) are GEMM work that left the per-shape table
-           "family_incl_fused_mlp_ms_per_frame": total + sum(v["ms"] for n_, v in kern.items() if n_.startswith("k_mlp256")) / GEMM_PROBE,
-           "family_incl_fused_mlp_tflops": (flops * GEMM_PROBE + sum(v["flops"] for n_, v in kern.items() if n_.startswith("k_mlp256"))) /
-                                           ((total * GEMM_PROBE + sum(v["ms"] for n_, v in kern.items() if n_.startswith("k_mlp256"))) * 1e-3) / 1e12,
+           # the fused launches are GEMM work that left the per-shape table: k_mlp256 (memory-attention FFN, CXBlock; with the LayerNorm in
+           # front of it since round 5), k_qkv_self (in_proj + key / value operand passes), k_qproj_x4a (norm2 + q_proj + query pass)
+           "family_incl_fused_mlp_ms_per_frame": total + sum(v["ms"] for n_, v in kern.items() if n_.startswith(FUSED_GEMM_KERNELS)) / GEMM_PROBE,
+           "family_incl_fused_mlp_tflops": (flops * GEMM_PROBE + sum(v["flops"] for n_, v in kern.items() if n_.startswith(FUSED_GEMM_KERNELS))) /
+                                           ((total * GEMM_PROBE + sum(v["ms"] for n_, v in kern.items() if n_.startswith(FUSED_GEMM_KERNELS))) * 1e-3) / 1e12,
+           "family_incl_fused_kernels": list(FUSED_GEMM_KERNELS),
            "note": "HIP-event bracket per GEMM (incl. its operand-split pre-pass when the producer did not emit planes), "
                    f"{GEMM_PROBE} frames after the timed region with the async encoder off; algorithmic FLOPs 2*M*N*K"}
     return fam, by_kernel
+
+
+FUSED_GEMM_KERNELS = ("k_mlp256", "k_qkv_self", "k_qproj_x4a")
 
 
 def stream_fps(pred, B, n_frames):

@@ -95,6 +95,10 @@ const unsigned char* attention_x4a_vt_slot_table();                             
 // Q fragments (gemm_qproj.hip); nrep > 1: rows = Lq shared queries written for nrep objects
 int launch_x4a_qprep(const float* q, int ldq, int batch, int Lq, bool q_shared, float scale, const float* cis, int rope_grid, void* qfrag,
                      hipStream_t st);
+// in_proj of the memory self-attention + key rotation / fp16 plane + V^T tiles in one kernel (gemm_qkvs.hip)
+bool qkv_self_supported(int rows, int ldx, int ldw, int tokens_per_image);
+int launch_qkv_self(const void* x_hi, const void* x_lo, int ldx, int rows, const void* w_hi, const void* w_lo, int ldw, const float* bias,
+                    const float* cis, int rope_grid, float* q, int ldq, void* k_f16, void* vt, hipStream_t st);
 bool qproj_x4a_supported(int rows, int ldx, int ldw);
 int launch_qproj_x4a(const float* x, int ldx, int rows, const float* ln_w, const float* ln_b, float ln_eps, const void* w_hi, const void* w_lo,
                      int ldw, const float* bias, const float* cis, int rope_grid, float scale, void* qfrag, int nrep, hipStream_t st);

@@ -1279,22 +1279,39 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     const float* xin = once ? x1 : x;
     if (n1_ready) m->act_planes[t] = n1p[l & 1];   // emitted by the previous layer's MLP epilogue
     else TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
-    TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
+    // in_proj + the key rotation / fp16 plane + the V^T tiles as ONE kernel (gemm_qkvs.hip; DS2_MA_QKVFUSE=0: the GEMM, k_rope_split and
+    // k_vt_split16; same bits either way).  Mode bf16x3k only: single fp16 planes, the values' lo plane is not read
+    const char* qkve = getenv("DS2_MA_QKVFUSE");
+    auto tpl = m->act_planes.find(t);
+    const bool qkvf = split && k_f16 && !klo_planes && !(qkve && atoi(qkve) == 0) && tpl != m->act_planes.end() && tpl->second.ld == 256 &&
+                      m->P("@ma_qkv_w." + ls) && qkv_self_supported(Bs * TOK, 256, 256, TOK);
+    const int ldq_s = qkvf ? 256 : 768;
+    if (qkvf) {
+      GemmPlanes wp;
+      TRY(weight_planes(m->gctx, m->P("@ma_qkv_w." + ls), 768, 256, &wp, st));
+      char ptag[96] = "";
+      if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_qkv_self %d %d %d", Bs * TOK, 768, 256);
+      ProfScope _gp(ptag, st, g_prof_gemm);
+      TRY(launch_qkv_self(tpl->second.hi, tpl->second.lo, tpl->second.ld, Bs * TOK, wp.hi, wp.lo, wp.ld, m->P("@ma_qkv_b." + ls), cis, TOK,
+                          qkv, 256, khi_s, vt_s, st));
+    } else {
+      TRY(gemm(st, Bs * TOK, 768, 256, t, 256, m->P("@ma_qkv_w." + ls), 256, m->P("@ma_qkv_b." + ls), qkv, 768, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
+    }
     if (!split) TRY(launch_rope(qkv, 768, cis, Bs, TOK, TOK, TOK, st));   // (the bf16x3 kernel rotates q while loading it)
     if (split) {
-      TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st, k_f16));
+      if (!qkvf) TRY(launch_rope_split(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, khi_s, klo_planes ? klo_s : nullptr, st, k_f16));
       ProfScope _p("kernel.self_attention", st);
       ds2_model::ActPlanes sa_p{};
       float* xs = once ? x1 : x;               // the residual stream this self-attention updates
       if (!m->ma_fold_vo) TRY(new_act_planes(m, a, Bs * TOK, 256, &sa_p, st));   // consumer: out_proj GEMM
-      TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st, 0, nullptr, k_f16));   // all 256 value columns in one pass
+      if (!qkvf) TRY(launch_vt_split16(qkv + 512, 768, Bs, TOK, vt_s, 256, st, 0, nullptr, k_f16));   // all 256 value columns in one pass
       // (measured and not kept: norm2 of the written rows emitted as q_proj's operand planes in this kernel's epilogue - the epilogue's
       // 8-byte plane stores cost the kernel 16 us per launch, what the separate LayerNorm pass costs less its launch: +-0)
       if (m->ma_fold_vo)   // values already carry out_proj: the kernel adds its result to the residual stream in place
-        TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, xs, 256, Bs, TOK, TOK, sc, 256, st, nullptr,
+        TRY(launch_attention_w8(qkv, ldq_s, khi_s, klo_planes ? klo_s : nullptr, vt_s, xs, 256, Bs, TOK, TOK, sc, 256, st, nullptr,
                                 nullptr, 0, 0, nullptr, cis, TOK, xs, 256, false, ksplit_ws, ksplit_bytes));
       else
-        TRY(launch_attention_w8(qkv, 768, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
+        TRY(launch_attention_w8(qkv, ldq_s, khi_s, klo_planes ? klo_s : nullptr, vt_s, nullptr, 256, Bs, TOK, TOK, sc, 256, st, sa_p.hi,
                                 sa_p.lo, sa_p.ld, 0, nullptr, cis, TOK, nullptr, 0, false, ksplit_ws, ksplit_bytes));
     } else {
       TRY(launch_rope(qkv + 256, 768, cis, Bs, TOK, TOK, TOK, st));
@@ -1332,6 +1349,9 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (qfuse) {
       GemmPlanes qwp;
       TRY(weight_planes(m->gctx, qw, 256, 256, &qwp, st));
+      char ptag[96] = "";
+      if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_qproj_x4a %d %d %d", qrows, 256, 256);
+      ProfScope _gp(ptag, st, g_prof_gemm);
       TRY(launch_qproj_x4a(q_once ? x1 : x, 256, qrows, m->P(p + ".norm2.weight"), m->P(p + ".norm2.bias"), 1e-5f, qwp.hi, qwp.lo, qwp.ld,
                            m->P(p + ".cross_attn_image.q_proj.bias"), cis, TOK, sc, x4a_ws, q_once ? B : 1, st));
     } else {
