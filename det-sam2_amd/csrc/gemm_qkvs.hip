@@ -33,7 +33,7 @@ constexpr int SD = 256;            // model width (k)
 constexpr int SBR = 128;           // token rows per workgroup
 constexpr int SSLOT = 16384;       // one ring slot: hi plane at +0, lo plane at +8192; 64 rows of 128 bytes (64 k)
 constexpr int SLO = 8192;
-constexpr int SNS = 4;
+constexpr int SNS = 6;            // ring slots: the DMA runs 5 tiles ahead, the fragment reads one tile ahead of the MFMAs
 constexpr int STILES = 48;         // 12 groups of 64 output columns x 4 k tiles of 64
 
 __device__ __forceinline__ unsigned s_cvt_pk_f16(float a, float b) {   // v_cvt_pk_f16_f32, round to nearest even
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void k_qkv_self(QkvsArgs a) {
     off_p[j] = ((unsigned)(32 * (R >> 5) + s_delta(R & 31)) * (unsigned)a.ldw + ch) * 2u;
   }
   const int sw = (l31 >> 1) & 7;
-  // tile T = 4 g + kt: output columns 64 g .., k 64 kt ..; groups 4..7 are the keys
+  // tile T = 4 g + kt: output columns 64 g .., k 64 kt ..; groups 4..7 are the keys; ring slot T % 6
 #define S_DMA(T)                                                                                                          \
   {                                                                                                                       \
     unsigned char* base_ = lds + ((T) % SNS) * SSLOT;                                                                     \
@@ -105,53 +105,62 @@ __global__ __launch_bounds__(256, 1) void k_qkv_self(QkvsArgs a) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the ring's counted waits below assume only DMA in flight)
-    S_DMA(0) S_DMA(1) S_DMA(2)
+    S_DMA(0) S_DMA(1) S_DMA(2) S_DMA(3) S_DMA(4)
     const int t = tokc % a.rope_grid;
+    // fragments of TWO tiles: tile T's MFMAs run on one set while tile T + 1's reads fill the other (one wave per SIMD: nobody else covers
+    // the LDS latency, and hipcc waits for a whole set at once)
+    bf16x8 fh[2][4][2], fl[2][4][2];
+#define S_READ(T, BUF)                                                                                                    \
+  {                                                                                                                       \
+    const unsigned char* base_ = lds + ((T) % SNS) * SSLOT;                                                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                     \
+        const unsigned char* r_ = base_ + (b * 32 + l31) * 128 + (((s * 2 + half) ^ sw) << 4);                            \
+        fh[BUF][s][b] = *reinterpret_cast<const bf16x8*>(r_);                                                             \
+        fl[BUF][s][b] = *reinterpret_cast<const bf16x8*>(r_ + SLO);                                                       \
+      }                                                                                                                   \
+  }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 (tiles 1..4 may stay in flight)
+    __builtin_amdgcn_s_barrier();
+    S_READ(0, 0)
     // the K loop of one 64-column group (4 tiles); KEYS: weights as the A operand.  The group loops below are NOT unrolled (unrolled over
     // all 12 groups hipcc hoists the epilogues' addresses and spills 160 registers)
+    // step T: tile T + 1 landed (this wave's pieces: the count; everybody's: the barrier) -> the DMA of tile T + 5 into the slot of tile
+    // T - 1 (its fragments were consumed before anybody reached this barrier) -> tile T + 1's fragment reads -> tile T's MFMAs
+#define S_STEP(g, KT, KEYS)                                                                                               \
+  {                                                                                                                       \
+    const int T = (g) * 4 + (KT);                                                                                         \
+    const int rem = STILES - 2 - T;   /* tiles behind T + 1 that exist */                                                  \
+    if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                       \
+    else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                   \
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    if (T + 5 < STILES) S_DMA(T + 5)                                                                                      \
+    if (T + 1 < STILES) S_READ(T + 1, ((KT) + 1) & 1)                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                     \
+        constexpr int ks = (KT) * 4;                                                                                      \
+        constexpr int cb = (KT) & 1;                                                                                      \
+        if (KEYS) {   /* weights as the A operand: a_lo w_hi, a_hi w_lo, a_hi w_hi */                                      \
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][s][b], xl[ks + s], acc[b], 0, 0, 0);                    \
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[cb][s][b], xh[ks + s], acc[b], 0, 0, 0);                    \
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][s][b], xh[ks + s], acc[b], 0, 0, 0);                    \
+        } else {      /* activations as the A operand */                                                                  \
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[ks + s], fh[cb][s][b], acc[b], 0, 0, 0);                    \
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks + s], fl[cb][s][b], acc[b], 0, 0, 0);                    \
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks + s], fh[cb][s][b], acc[b], 0, 0, 0);                    \
+        }                                                                                                                 \
+      }                                                                                                                   \
+  }
+    // the K loop of one 64-column group (4 tiles, unrolled: x_hat's fragments and the fragment sets are indexed statically); KEYS: weights
+    // as the A operand.  The group loops below are NOT unrolled (unrolled over all 12 groups hipcc hoists the epilogues' addresses and
+    // spills 160 registers)
 #define S_GROUP_MAIN(g, KEYS)                                                                                             \
   f32x16 acc[2];                                                                                                          \
   _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                           \
     _Pragma("unroll") for (int e = 0; e < 16; ++e) acc[b][e] = 0.f;                                                       \
-  _Pragma("unroll 1") for (int kt = 0; kt < 4; ++kt) {                                                                     \
-    const int T = (g) * 4 + kt;                                                                                           \
-    /* (stores of the previous group's epilogue are younger than the DMA of tiles T + 1, T + 2: the counts only get stricter) */ \
-    if (T + 2 < STILES) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                  \
-    else if (T + 1 < STILES) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                             \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                 \
-    __builtin_amdgcn_s_barrier();                                                                                         \
-    if (T + 3 < STILES) S_DMA(T + 3)                                                                                      \
-    const unsigned char* base_ = lds + (T % SNS) * SSLOT;                                                                 \
-    bf16x8 fh[4][2], fl[4][2];                                                                                            \
-    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
-      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                     \
-        const unsigned char* r_ = base_ + (b * 32 + l31) * 128 + (((s * 2 + half) ^ sw) << 4);                            \
-        fh[s][b] = *reinterpret_cast<const bf16x8*>(r_);                                                                  \
-        fl[s][b] = *reinterpret_cast<const bf16x8*>(r_ + SLO);                                                            \
-      }                                                                                                                   \
-    switch (kt) {                                                                                                         \
-      case 0: S_MFMA(0, KEYS) break;                                                                                      \
-      case 1: S_MFMA(1, KEYS) break;                                                                                      \
-      case 2: S_MFMA(2, KEYS) break;                                                                                      \
-      default: S_MFMA(3, KEYS) break;                                                                                     \
-    }                                                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* fragment reads retired before the next barrier frees the slot */ \
-  }
-    // (x_hat's fragments are indexed statically: one copy of the 24 MFMAs per k tile)
-#define S_MFMA(KT, KEYS)                                                                                                  \
-  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                           \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                       \
-      constexpr int ks = (KT) * 4;                                                                                        \
-      if (KEYS) {   /* weights as the A operand: a_lo w_hi, a_hi w_lo, a_hi w_hi */                                        \
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][b], xl[ks + s], acc[b], 0, 0, 0);                          \
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][b], xh[ks + s], acc[b], 0, 0, 0);                          \
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][b], xh[ks + s], acc[b], 0, 0, 0);                          \
-      } else {      /* activations as the A operand */                                                                    \
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[ks + s], fh[s][b], acc[b], 0, 0, 0);                          \
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks + s], fl[s][b], acc[b], 0, 0, 0);                          \
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[ks + s], fh[s][b], acc[b], 0, 0, 0);                          \
-      }                                                                                                                   \
-    }
+  S_STEP(g, 0, KEYS) S_STEP(g, 1, KEYS) S_STEP(g, 2, KEYS) S_STEP(g, 3, KEYS)
 #pragma unroll 1
     for (int g = 0; g < 4; ++g) {
       S_GROUP_MAIN(g, false)

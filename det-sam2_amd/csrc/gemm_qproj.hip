@@ -29,7 +29,7 @@ constexpr int QD = 256;            // model width (k and n)
 constexpr int QBR = 128;           // token rows per workgroup
 constexpr int QSLOT = 16384;       // one ring slot: hi plane at +0, lo plane at +8192; 64 rows of 128 bytes (64 k)
 constexpr int QLO = 8192;
-constexpr int QNS = 4;
+constexpr int QNS = 6;             // ring slots: the DMA runs 5 tiles ahead, the fragment reads one tile ahead of the MFMAs
 constexpr int QTILES = 16;         // (n-group of 64 dims) x (k tile of 64)
 
 __device__ __forceinline__ unsigned q_cvt_pk_bf16(float a, float b) {
@@ -156,12 +156,27 @@ __global__ __launch_bounds__(256, 1) void k_qproj_x4a(QprojArgs a) {
         xl[s] = __builtin_bit_cast(bf16x8, (u32x4{rl[0], rl[1], rl[2], rl[3]}));
       }
     }
-    // ---- ring prologue
-    Q_DMA(0) Q_DMA(1) Q_DMA(2)
+    // ---- ring prologue; fragments of TWO tiles: tile T's MFMAs run on one set while tile T + 1's reads fill the other
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the ring's counted waits assume only DMA in flight)
+    Q_DMA(0) Q_DMA(1) Q_DMA(2) Q_DMA(3) Q_DMA(4)
     const int t = tokc % a.rope_grid;
     const size_t blk64 = (size_t)(tok >> 6);
     const int qb = (tok >> 5) & 1;
-#pragma unroll
+    bf16x8 fh[2][4][2], fl[2][4][2];
+#define Q_READ(T, BUF)                                                                                                    \
+  {                                                                                                                       \
+    const unsigned char* base_ = lds + ((T) % QNS) * QSLOT;                                                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                                     \
+        const unsigned char* r_ = base_ + (b * 32 + l31) * 128 + (((s * 2 + half) ^ sw) << 4);                            \
+        fh[BUF][s][b] = *reinterpret_cast<const bf16x8*>(r_);                                                             \
+        fl[BUF][s][b] = *reinterpret_cast<const bf16x8*>(r_ + QLO);                                                       \
+      }                                                                                                                   \
+  }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tile 0 (tiles 1..4 may stay in flight)
+    __builtin_amdgcn_s_barrier();
+    Q_READ(0, 0)
+#pragma unroll 1     // (unrolled, hipcc hoists the epilogues' addresses over the groups and spills)
     for (int ng = 0; ng < 4; ++ng) {
       f32x16 acc[2];
 #pragma unroll
@@ -171,32 +186,25 @@ __global__ __launch_bounds__(256, 1) void k_qproj_x4a(QprojArgs a) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         const int T = ng * 4 + kt;
-        // tile T landed (this wave's pieces: tiles T + 1, T + 2 may stay in flight), everybody's pieces after the barrier
-        if (T + 2 < QTILES) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (T + 1 < QTILES) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // step T: tile T + 1 landed (this wave's pieces: the count; everybody's: the barrier) -> the DMA of tile T + 5 into the slot of
+        // tile T - 1 (consumed before anybody reached this barrier) -> tile T + 1's fragment reads -> tile T's MFMAs
+        const int rem = QTILES - 2 - T;
+        if (rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (rem == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (T + 3 < QTILES) Q_DMA(T + 3)     // into the slot of tile T - 1: every wave is past its last fragment read (barrier above)
-        const unsigned char* base_ = lds + (T % QNS) * QSLOT;
-        bf16x8 fh[4][2], fl[4][2];
+        if (T + 5 < QTILES) Q_DMA(T + 5)
+        if (T + 1 < QTILES) Q_READ(T + 1, (kt + 1) & 1)
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const unsigned char* r_ = base_ + (b * 32 + l31) * 128 + (((s * 2 + half) ^ sw) << 4);
-            fh[s][b] = *reinterpret_cast<const bf16x8*>(r_);
-            fl[s][b] = *reinterpret_cast<const bf16x8*>(r_ + QLO);
+            const int ks = kt * 4 + s, cb = kt & 1;
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][s][b], xl[ks], acc[b], 0, 0, 0);   // a_lo w_hi
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[cb][s][b], xh[ks], acc[b], 0, 0, 0);   // a_hi w_lo
+            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[cb][s][b], xh[ks], acc[b], 0, 0, 0);   // a_hi w_hi
           }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int ks = kt * 4 + s;
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][b], xl[ks], acc[b], 0, 0, 0);   // a_lo w_hi
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl[s][b], xh[ks], acc[b], 0, 0, 0);   // a_hi w_lo
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh[s][b], xh[ks], acc[b], 0, 0, 0);   // a_hi w_hi
-          }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (fragment reads retired before the next barrier frees the slot)
       }
       // ---- the 64 dims of this n-group: registers 0..7 / 8..15 of block b are the fragments ks = 2 (2 ng + b), + 1 of this lane
 #pragma unroll
