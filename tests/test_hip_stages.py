@@ -369,3 +369,42 @@ def test_fused_query_kernel_equals_the_three_kernels_it_replaces(rows):
         torch.cuda.synchronize()
         assert torch.equal(got, ref), (layer, int((got != ref).sum()))
     assert ref.view(torch.float16).float().abs().max() > 0.1          # (not a comparison of zeros)
+
+
+@pytest.mark.parametrize("switch", ["DS2_MA_QKVFUSE", "DS2_MA_QFUSE", "DS2_MA_LN3_FUSE", "DS2_ME_LN_FUSE", "DS2_BANK_DIRECT", "DS2_GEMM_K64T"])
+@pytest.mark.parametrize("B,NF,NP", [(3, 2, 3), (16, 7, 16)])
+def test_fused_kernels_of_round_5_are_bit_identical_to_the_chains_they_replace(switch, B, NF, NP, monkeypatch):
+    """Every fusion of round 5 on the tracking chain keeps the per-element arithmetic and its order: with the switch at 0 (the kernels
+    it replaced) ds2_bank_memory_attention / ds2_memory_encoder give the same bits.  k_qkv_self (in_proj + key rotation / plane + V^T
+    tiles), k_qproj_x4a (norm2 + q_proj + query pass), the LayerNorm in the fused MLP's prologue (memory attention, memory encoder),
+    the bank straight to the attention's operands, the key projection's register-transposed epilogue.  (3 objects: the hidden-split form
+    of the fused MLP, a ragged pointer tile; 16 objects: the measured shape.)"""
+    from det_sam2_amd.hip_model import HipSam2
+    cfg = resolve_config("sam2.1_hiera_t")
+    key = ("bitid", B)
+    if key not in _CACHE:
+        _CACHE[key] = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=B)
+    hm = _CACHE[key]
+    hm.set_precision("bf16x3k")
+    g = torch.Generator().manual_seed(5)
+    d = hm.device
+    curr = torch.randn(4096, 256, generator=g).to(d)
+    ents = [(torch.randn(B, 4096, 64, generator=g).to(torch.bfloat16).to(d), 6 - i) for i in range(NF)]
+    ptrs = [(torch.randn(B, 256, generator=g).to(d), i / 15.0) for i in range(NP)]
+    f2 = torch.randn(4096, 256, generator=g).to(d)
+    low = (torch.randn(B, 256, 256, generator=g) * 3).to(d)
+    obj = torch.randn(B, generator=g).to(d)
+
+    def run():
+        a = hm.bank_attention(B, curr, ents, ptrs).clone()
+        e = hm.memory_encoder(B, f2, low, obj, False).clone()
+        torch.cuda.synchronize()
+        return a, e
+
+    monkeypatch.delenv(switch, raising=False)
+    a0, e0 = run()
+    monkeypatch.setenv(switch, "0")
+    a1, e1 = run()
+    assert torch.equal(a0, a1), (switch, float((a0 - a1).abs().max()))
+    assert torch.equal(e0, e1), (switch, float((e0.float() - e1.float()).abs().max()))
+    assert float(a0.abs().max()) > 1.0
