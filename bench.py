@@ -237,7 +237,7 @@ def kernel_probe(pred, gen, st, last_tracked, table_path=None):
     return fam, by_kernel
 
 
-FUSED_GEMM_KERNELS = ("k_mlp256", "k_qkv_self", "k_qproj_x4a")
+FUSED_GEMM_KERNELS = ("k_mlp256", "k_qkv_self", "k_qproj_x4a", "k_vo_merge")
 
 
 def stream_fps(pred, B, n_frames):

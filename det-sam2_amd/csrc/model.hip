@@ -1359,6 +1359,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       TRY(linear(m, st, p + ".cross_attn_image.q_proj", qrows, 256, 256, t, 256, q, 256));
     }
     if (!split) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
+    bool vofuse = false;
+    const float *vo_po = nullptr, *vo_pml = nullptr;
     if (split) {
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
       TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
@@ -1371,10 +1373,16 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
         DS2_CHECK_HIP(hipMemsetAsync(kpl.lo, 0, 32 * 512, st));
       }
       ProfScope _p("kernel.cross_attention", st);
-      ds2_model::ActPlanes cp;
-      TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
+      // the attention's normalisation + the folded value / output projection + residual as ONE kernel (gemm_vo.hip) when the launch has no
+      // key split (DS2_MA_VOFUSE=0: k_w8_merge -> planes -> K = 64 GEMM; same bits either way)
+      const char* voe = getenv("DS2_MA_VOFUSE");
+      vofuse = x4a && m->ma_fold_vo && !(voe && atoi(voe) == 0) && m->P("#ma_cross_vo_w." + ls) &&
+               attention_x4a_single_part(x4a_ws, B, TOK, Nk, &vo_po, &vo_pml) && vo_merge_supported(rows, 64);
+      ds2_model::ActPlanes cp{};
+      if (!vofuse) TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
       if (x4a)
-        TRY(launch_attention_x4a(qfuse ? nullptr : q, 256, khi, vt32, B, TOK, Nk, sc, st, cp.hi, cp.lo, cp.ld, cis, TOK, q_once, x4a_ws, x4a_ws_bytes));
+        TRY(launch_attention_x4a(qfuse ? nullptr : q, 256, khi, vt32, B, TOK, Nk, sc, st, cp.hi, cp.lo, cp.ld, cis, TOK, q_once, x4a_ws, x4a_ws_bytes,
+                                 !vofuse));
       else
         TRY(launch_attention_w8(q, 256, khi, klo, vt_c, nullptr, 64, B, TOK, Nk, sc, 64, st, cp.hi, cp.lo, cp.ld,
                                 Nk - n_ptr_tok, vlo_flag, cis, TOK, nullptr, 0, q_once, ksplit_ws, ksplit_bytes));
@@ -1390,7 +1398,14 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     }
     // out_proj(v_proj(P M)) folded on the host into ONE 64 -> 256 projection (constants.py fold_out_v: exact in real
     // arithmetic): x += (P M) (Wo Wv)^T + (Wo bv + bo) - one K = 64 GEMM instead of a K = 64 and a K = 256 one
-    if (m->ma_fold_vo) {
+    if (vofuse) {
+      GemmPlanes vwp;
+      TRY(weight_planes(m->gctx, m->P("#ma_cross_vo_w." + ls), 256, 64, &vwp, st));
+      char ptag[96] = "";
+      if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_vo_merge %d %d %d", rows, 256, 64);
+      ProfScope _gp(ptag, st, g_prof_gemm);
+      TRY(launch_vo_merge(vo_po, vo_pml, rows, vwp.hi, vwp.lo, vwp.ld, m->P("#ma_cross_vo_b." + ls), q_once ? x1 : x, 256, q_once ? TOK : 0, x, 256, st));
+    } else if (m->ma_fold_vo) {
       TRY(gemm(st, rows, 256, 64, a64, 64, m->P("#ma_cross_vo_w." + ls), 64, m->P("#ma_cross_vo_b." + ls), x, 256, DS2_ACT_NONE,
                q_once ? x1 : x, 256, q_once ? TOK : 0, nullptr, true, m));
     } else {

@@ -371,12 +371,12 @@ def test_fused_query_kernel_equals_the_three_kernels_it_replaces(rows):
     assert ref.view(torch.float16).float().abs().max() > 0.1          # (not a comparison of zeros)
 
 
-@pytest.mark.parametrize("switch", ["DS2_MA_QKVFUSE", "DS2_MA_QFUSE", "DS2_MA_LN3_FUSE", "DS2_ME_LN_FUSE", "DS2_BANK_DIRECT", "DS2_GEMM_K64T"])
+@pytest.mark.parametrize("switch", ["DS2_MA_QKVFUSE", "DS2_MA_QFUSE", "DS2_MA_VOFUSE", "DS2_MA_LN3_FUSE", "DS2_ME_LN_FUSE", "DS2_BANK_DIRECT", "DS2_GEMM_K64T"])
 @pytest.mark.parametrize("B,NF,NP", [(3, 2, 3), (16, 7, 16)])
 def test_fused_kernels_of_round_5_are_bit_identical_to_the_chains_they_replace(switch, B, NF, NP, monkeypatch):
     """Every fusion of round 5 on the tracking chain keeps the per-element arithmetic and its order: with the switch at 0 (the kernels
     it replaced) ds2_bank_memory_attention / ds2_memory_encoder give the same bits.  k_qkv_self (in_proj + key rotation / plane + V^T
-    tiles), k_qproj_x4a (norm2 + q_proj + query pass), the LayerNorm in the fused MLP's prologue (memory attention, memory encoder),
+    tiles), k_qproj_x4a (norm2 + q_proj + query pass), k_vo_merge (the attention's normalisation + the folded value / output projection), the LayerNorm in the fused MLP's prologue (memory attention, memory encoder),
     the bank straight to the attention's operands, the key projection's register-transposed epilogue.  (3 objects: the hidden-split form
     of the fused MLP, a ragged pointer tile; 16 objects: the measured shape.)"""
     from det_sam2_amd.hip_model import HipSam2

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 SWITCHES = ["DS2_ASYNC_ENCODE=0", "DS2_ATTN_HG=0", "DS2_ATTN_KSPLIT=0", "DS2_ATTN_NO_VLO_SKIP=1",
             "DS2_GEMM_K64=0", "DS2_GEMM_PP256=0", "DS2_GEMM_SKINNY=0", "DS2_GEMM_X4G=0", "DS2_GEMM_K64T=0", "DS2_MA_FOLD_VO=0",
-            "DS2_ME_COL_PLANES=0", "DS2_ME_FUSE_UP=0", "DS2_MLP_FUSED=0", "DS2_ENCODE_BATCH=3", "DS2_ATTN_X4A=0", "DS2_F16X2=0", "DS2_MA_FUSE_LN=0", "DS2_ATTN_WINLDS=0", "DS2_MLP_HSPLIT=0", "DS2_BANK_DIRECT=0", "DS2_MA_LN3_FUSE=0", "DS2_ME_LN_FUSE=0", "DS2_MA_QFUSE=0", "DS2_MA_QKVFUSE=0"]
+            "DS2_ME_COL_PLANES=0", "DS2_ME_FUSE_UP=0", "DS2_MLP_FUSED=0", "DS2_ENCODE_BATCH=3", "DS2_ATTN_X4A=0", "DS2_F16X2=0", "DS2_MA_FUSE_LN=0", "DS2_ATTN_WINLDS=0", "DS2_MLP_HSPLIT=0", "DS2_BANK_DIRECT=0", "DS2_MA_LN3_FUSE=0", "DS2_ME_LN_FUSE=0", "DS2_MA_QFUSE=0", "DS2_MA_QKVFUSE=0", "DS2_MA_VOFUSE=0"]
 
 
 @pytest.mark.parametrize("switch", SWITCHES)
