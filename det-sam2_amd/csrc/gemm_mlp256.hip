@@ -46,6 +46,14 @@
 #include X4M_INC_FILE      // (tools/x4m_variant.sh: ablation / parameter variants of the generated body)
 #else
 #include "mlp256_x4m_body.inc"
+#include "mlp256_x4m_gelu_body.inc"      // the same loop with ds2_gelu's instruction sequence as the activation (memory encoder CXBlock)
+#endif
+#endif
+#ifndef X4M_GELU_BODY                    // (a variant build with X4M_INC_FILE carries the ReLU body only)
+#define DS2_MLP_X4M_GELU 0
+#else
+#ifndef DS2_MLP_X4M_GELU
+#define DS2_MLP_X4M_GELU 1
 #endif
 #endif
 
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 
 #if DS2_MLP_X4M
-  constexpr bool X4M = ACT == DS2_ACT_RELU && X2 && DS2_MLP_ABL == 0;
+  constexpr bool X4M = (ACT == DS2_ACT_RELU || (ACT == DS2_ACT_GELU && DS2_MLP_X4M_GELU)) && X2 && DS2_MLP_ABL == 0;
 #else
   constexpr bool X4M = false;
 #endif
@@ -361,15 +369,30 @@ __global__ __launch_bounds__(256, 1) void k_mlp256(MlpArgs a) {
     if constexpr (X4M) {
       // the whole hidden loop of this row block, ring prologue included (mlp256_x4m_body.inc); every wave leaves it with its DMA still
       // in flight (the wrapped-around tail) - drained below like the C++ loop's
-      asm volatile(X4M_BODY
-                   : [o0] "+a"(out[0]), [o1] "+a"(out[1]), [o2] "+a"(out[2]), [o3] "+a"(out[3]), [o4] "+a"(out[4]), [o5] "+a"(out[5]),
-                     [o6] "+a"(out[6]), [o7] "+a"(out[7])
-                   : [x0] "v"(xh[0]), [x1] "v"(xh[1]), [x2] "v"(xh[2]), [x3] "v"(xh[3]), [x4] "v"(xh[4]), [x5] "v"(xh[5]), [x6] "v"(xh[6]),
-                     [x7] "v"(xh[7]), [x8] "v"(xh[8]), [x9] "v"(xh[9]), [x10] "v"(xh[10]), [x11] "v"(xh[11]), [x12] "v"(xh[12]),
-                     [x13] "v"(xh[13]), [x14] "v"(xh[14]), [x15] "v"(xh[15]), [rd0] "v"(m_rd0), [offa0] "v"(m_offa[0]), [offa1] "v"(m_offa[1]),
-                     [offb0] "v"(m_offb[0]), [offb1] "v"(m_offb[1]), [baddr] "v"(m_baddr), [w1h] "s"(m_w1h), [w1l] "s"(m_w1l), [w2h] "s"(m_w2h),
-                     [w2l] "s"(m_w2l), [stridea] "s"(m_stridea), [strideb] "s"(m_strideb), [ldsb] "s"(m_ldsb), [wave] "s"(wave), [nch] "s"(m_nch)
-                   : X4M_CLOBBERS);
+#if DS2_MLP_X4M_GELU
+      if constexpr (ACT == DS2_ACT_GELU) {
+        asm volatile(X4M_GELU_BODY
+                     : [o0] "+a"(out[0]), [o1] "+a"(out[1]), [o2] "+a"(out[2]), [o3] "+a"(out[3]), [o4] "+a"(out[4]), [o5] "+a"(out[5]),
+                       [o6] "+a"(out[6]), [o7] "+a"(out[7])
+                     : [x0] "v"(xh[0]), [x1] "v"(xh[1]), [x2] "v"(xh[2]), [x3] "v"(xh[3]), [x4] "v"(xh[4]), [x5] "v"(xh[5]), [x6] "v"(xh[6]),
+                       [x7] "v"(xh[7]), [x8] "v"(xh[8]), [x9] "v"(xh[9]), [x10] "v"(xh[10]), [x11] "v"(xh[11]), [x12] "v"(xh[12]),
+                       [x13] "v"(xh[13]), [x14] "v"(xh[14]), [x15] "v"(xh[15]), [rd0] "v"(m_rd0), [offa0] "v"(m_offa[0]), [offa1] "v"(m_offa[1]),
+                       [offb0] "v"(m_offb[0]), [offb1] "v"(m_offb[1]), [baddr] "v"(m_baddr), [w1h] "s"(m_w1h), [w1l] "s"(m_w1l), [w2h] "s"(m_w2h),
+                       [w2l] "s"(m_w2l), [stridea] "s"(m_stridea), [strideb] "s"(m_strideb), [ldsb] "s"(m_ldsb), [wave] "s"(wave), [nch] "s"(m_nch)
+                     : X4M_GELU_CLOBBERS);
+      } else
+#endif
+      {
+        asm volatile(X4M_BODY
+                     : [o0] "+a"(out[0]), [o1] "+a"(out[1]), [o2] "+a"(out[2]), [o3] "+a"(out[3]), [o4] "+a"(out[4]), [o5] "+a"(out[5]),
+                       [o6] "+a"(out[6]), [o7] "+a"(out[7])
+                     : [x0] "v"(xh[0]), [x1] "v"(xh[1]), [x2] "v"(xh[2]), [x3] "v"(xh[3]), [x4] "v"(xh[4]), [x5] "v"(xh[5]), [x6] "v"(xh[6]),
+                       [x7] "v"(xh[7]), [x8] "v"(xh[8]), [x9] "v"(xh[9]), [x10] "v"(xh[10]), [x11] "v"(xh[11]), [x12] "v"(xh[12]),
+                       [x13] "v"(xh[13]), [x14] "v"(xh[14]), [x15] "v"(xh[15]), [rd0] "v"(m_rd0), [offa0] "v"(m_offa[0]), [offa1] "v"(m_offa[1]),
+                       [offb0] "v"(m_offb[0]), [offb1] "v"(m_offb[1]), [baddr] "v"(m_baddr), [w1h] "s"(m_w1h), [w1l] "s"(m_w1l), [w2h] "s"(m_w2h),
+                       [w2l] "s"(m_w2l), [stridea] "s"(m_stridea), [strideb] "s"(m_strideb), [ldsb] "s"(m_ldsb), [wave] "s"(wave), [nch] "s"(m_nch)
+                     : X4M_CLOBBERS);
+      }
     } else
 #endif
     {

@@ -20,6 +20,17 @@ def test_committed_body_is_the_generators_output(tmp_path, cfg, epi):
     assert out.read_text() == committed
 
 
+def test_committed_gelu_mlp_loop_is_the_generators_output(tmp_path):
+    """mlp256_x4m_gelu_body.inc (the loop with ds2_gelu's instruction sequence as the activation: memory encoder CXBlock) = X4M_ACT=gelu"""
+    out = tmp_path / "body.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("X4M_")}
+    env["X4M_ACT"] = "gelu"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_mlp256_x4m.py"), str(out)], check=True, env=env, capture_output=True)
+    body = out.read_text()
+    assert body == open(os.path.join(ROOT, "det-sam2_amd", "csrc", "mlp256_x4m_gelu_body.inc")).read()
+    assert body.count("v_mfma_f32_32x32x16_f16") == 128 and body.count("v_exp_f32") == 32 and body.count("v_rcp_f32") == 32
+
+
 def test_committed_mlp_loop_is_the_generators_output(tmp_path):
     """det-sam2_amd/csrc/mlp256_x4m_body.inc (the hidden loop of the fused MLP's ReLU / two-fp16-term form) = tools/gen/gen_mlp256_x4m.py
     today; the generator simulates the in-order LDS queue for every counted wait and checks that the queue at the end of the loop body

@@ -35,8 +35,11 @@ ILV = os.environ.get("X4M_ILV", "0") == "1"             # two units at a time: l
 WAIT1 = os.environ.get("X4M_WAIT1", "1") == "1"         # one lgkm wait per unit (for its hi fragment, the younger one) instead of two
 NONOP = os.environ.get("X4M_NONOP", "1") == "1"         # the wait state between an m0 write and its LDS-DMA is filled by the unit's reads
 FLAGS = set(os.environ.get("X4M_FLAGS", "").split())   # timing ablations (results WRONG): nobar noread nodma noact
+ACT = os.environ.get("X4M_ACT", "relu")                 # relu (memory-attention FFN) | gelu (memory encoder CXBlock: common.h ds2_gelu)
+assert ACT in ("relu", "gelu")
+NTMP = 14 if ACT == "gelu" else 0                       # gelu: 3 temporaries x 4 elements in flight + the polynomial's constant term (+ 1 pad)
 # ---- registers owned by the body (clobbered)
-V0 = 256 - (32 + 16 + 32 + 8 * NBUF + 8 + 2)
+V0 = 256 - (32 + 16 + 32 + 8 * NBUF + 8 + 2 + NTMP)
 assert V0 % 2 == 0
 HID = V0                   # 32: hid[hb] = HID + 16 hb
 FH = HID + 32              # 16: fh[i] = FH + 4 i, i = 2 hb + t
@@ -45,7 +48,9 @@ FR = BIAS + 32             # 40: unit buffer b: lo fragment FR + 8 b, hi fragmen
 RD = FR + 8 * NBUF         # 8: RD + k (slots 0..3), RD + 4 + k (slots 4..7), k = k-step
 VB = RD + 8                # 1: bias read address of the current chunk
 C65 = VB + 1               # 1: 65504.0
-VEND = C65 + 1
+TMP = C65 + 1              # gelu: z, t, p of element i at TMP + 3 i, i = 0..3
+C3 = TMP + 12              # gelu: -1.453152027
+VEND = C65 + 1 + NTMP
 assert VEND == 256, VEND
 S0 = 36
 PA_H, PA_L, PB_H, PB_L = S0, S0 + 2, S0 + 4, S0 + 6            # current chunk: W1 hi / lo, W2 hi / lo (64-bit)
@@ -54,7 +59,9 @@ BA_H, BA_L, BB_H, BB_L = S0 + 16, S0 + 18, S0 + 20, S0 + 22     # first chunk
 T_H, T_L = S0 + 24, S0 + 26                                    # tile base of the DMA being issued
 S_CNT, S_SA, S_DST, S_NEG = S0 + 28, S0 + 29, S0 + 30, S0 + 31
 SB1, SB2, SB3 = S0 + 32, S0 + 33, S0 + 34                      # q * strideb
-SEND = S0 + 35
+S_C1, S_C2 = S0 + 35, S0 + 36                                  # gelu: sqrt(1/2), 0.3275911
+MSK = S0 + 38                                                  # gelu: 4 lane-mask pairs (x >= 0)
+SEND = S0 + 46 if ACT == "gelu" else S0 + 35
 
 L = []                     # emitted instructions
 
@@ -159,8 +166,49 @@ def dma_tile(j, nxt):
     return groups
 
 
+def gelu_ops(hb, t):
+    """bias + ds2_gelu + saturate + pack of hid[hb][8t .. 8t+7] -> fh[2 hb + t]: hipcc's instruction sequence for common.h ds2_gelu (contraction
+    off, explicit fmaf), four elements at a time stage by stage - a transcendental's result is used 3 instructions later, a lane mask 7"""
+    ops = []
+    h, b, f = HID + 16 * hb + 8 * t, BIAS + 16 * hb + 8 * t, FH + 4 * (2 * hb + t)
+    for e0 in (0, 4):
+        x = [h + e0 + i for i in range(4)]
+        bb = [b + e0 + i for i in range(4)]
+        z, tt, pp = [TMP + 3 * i for i in range(4)], [TMP + 3 * i + 1 for i in range(4)], [TMP + 3 * i + 2 for i in range(4)]
+        m = [f"s[{MSK + 2 * i}:{MSK + 2 * i + 1}]" for i in range(4)]
+        stages = [
+            lambda i: f"v_add_f32 v{x[i]}, v{x[i]}, v{bb[i]}",
+            lambda i: f"v_mul_f32_e64 v{z[i]}, |v{x[i]}|, s{S_C1}",                 # z = |x| sqrt(1/2)
+            lambda i: f"v_fma_f32 v{tt[i]}, v{z[i]}, s{S_C2}, 1.0",
+            lambda i: f"v_rcp_f32 v{tt[i]}, v{tt[i]}",                             # t = 1 / (1 + 0.3275911 z)
+            lambda i: f"v_fmamk_f32 v{pp[i]}, v{tt[i]}, 0x3f87dc22, v{C3}",         # p = t 1.061405429 - 1.453152027
+            lambda i: f"v_fmaak_f32 v{pp[i]}, v{tt[i]}, v{pp[i]}, 0x3fb5f0e3",
+            lambda i: f"v_fmaak_f32 v{pp[i]}, v{tt[i]}, v{pp[i]}, 0xbe91a98e",
+            lambda i: f"v_fmaak_f32 v{pp[i]}, v{tt[i]}, v{pp[i]}, 0x3e827906",
+            lambda i: f"v_mul_f32 v{pp[i]}, v{tt[i]}, v{pp[i]}",                    # poly
+            lambda i: f"v_mul_f32 v{pp[i]}, 0.5, v{pp[i]}",
+            lambda i: f"v_mul_f32_e64 v{z[i]}, v{z[i]}, -v{z[i]}",                  # -z^2
+            lambda i: f"v_mul_f32 v{z[i]}, 0x3fb8aa3b, v{z[i]}",
+            lambda i: f"v_exp_f32 v{z[i]}, v{z[i]}",
+            lambda i: f"v_mul_f32 v{pp[i]}, v{z[i]}, v{pp[i]}",                     # erfc(z) / 2
+            lambda i: f"v_cmp_le_f32_e64 {m[i]}, 0, v{x[i]}",
+            lambda i: f"v_sub_f32 v{z[i]}, 1.0, v{pp[i]}",
+            lambda i: f"v_cndmask_b32_e64 v{pp[i]}, v{pp[i]}, v{z[i]}, {m[i]}",
+            lambda i: f"v_mul_f32 v{x[i]}, v{x[i]}, v{pp[i]}",
+            lambda i: f"v_med3_f32 v{x[i]}, v{x[i]}, s{S_NEG}, v{C65}",
+        ]
+        for st in stages:
+            for i in range(4):
+                ops.append(st(i))
+        for pr in range(2):
+            ops.append(f"v_cvt_pk_f16_f32 v{f + e0 // 2 + pr}, v{h + e0 + 2 * pr}, v{h + e0 + 2 * pr + 1}")
+    return ops
+
+
 def act_ops(hb, t):
     """bias + ReLU + saturate + pack of hid[hb][8t .. 8t+7] -> fh[2 hb + t]; the instruction sequence hipcc emits for the C++ loop"""
+    if ACT == "gelu":
+        return gelu_ops(hb, t)
     ops = []
     h, b, f = HID + 16 * hb + 8 * t, BIAS + 16 * hb + 8 * t, FH + 4 * (2 * hb + t)
     for e in range(8):
@@ -204,6 +252,10 @@ def prologue():
     emit(f"s_add_u32 s{S_DST}, s{S_DST}, %[ldsb]")
     emit(f"s_mov_b32 s{S_NEG}, 0xc77fe000")                       # -65504.0
     emit(f"v_mov_b32 v{C65}, 0x477fe000")                         # 65504.0
+    if ACT == "gelu":
+        emit(f"s_mov_b32 s{S_C1}, 0x3f3504f3")                    # sqrt(1/2)
+        emit(f"s_mov_b32 s{S_C2}, 0x3ea7ba05")                    # 0.3275911
+        emit(f"v_mov_b32 v{C3}, 0xbfba00e3")                      # -1.453152027
     emit(f"v_mov_b32 v{VB}, %[baddr]")
     for k in range(4):
         if k == 0:
@@ -406,12 +458,13 @@ def main():
     clob = [f"v{i}" for i in range(V0, 256)] + [f"s{i}" for i in range(S0, SEND)] + ["m0", "scc", "memory"]
     with open(out, "w") as f:
         f.write("// generated by tools/gen/gen_mlp256_x4m.py - do not edit\n")
-        f.write(f"#define X4M_V0 {V0}\n")
-        f.write("#define X4M_BODY \\\n")
+        f.write(f"#define {'X4M_GELU' if ACT == 'gelu' else 'X4M'}_V0 {V0}\n")
+        tag = "X4M_GELU" if ACT == "gelu" else "X4M"
+        f.write(f"#define {tag}_BODY \\\n")
         for ins in L:
             f.write(f'    "{ins}\\n\\t" \\\n')
         f.write('    ""\n')
-        f.write("#define X4M_CLOBBERS " + ", ".join(f'"{c}"' for c in clob if c != "m0") + "\n")
+        f.write(f"#define {tag}_CLOBBERS " + ", ".join(f'"{c}"' for c in clob if c != "m0") + "\n")
     print(out, len(L), "instructions;", sum(1 for x in body if x.startswith("s_waitcnt lgkmcnt")), "lgkm waits in the chunk body")
 
 
