@@ -231,23 +231,22 @@ int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStr
 
 int launch_w8_merge64(const float* part_o, const float* part_ml, int nsplit, size_t rows, void* o_hi, void* o_lo, int ldop, hipStream_t st);
 
-// the un-normalised result of a launch WITHOUT a key split inside its workspace (launch_attention_x4a with merge = false): the consumer
-// normalises it itself (launch_vo_merge, gemm_vo.hip).  false: the launch splits the keys, k_w8_merge has to combine the parts.
-bool attention_x4a_single_part(void* ws, int batch, int Lq, int Lk, const float** part_o, const float** part_ml) {
-  if (x4a_nsplit(batch, Lq, Lk) != 1) return false;
+// the un-normalised part(s) of a launch inside its workspace (launch_attention_x4a with merge = false): the consumer combines and
+// normalises them itself (launch_vo_merge, gemm_vo.hip).  Returns the number of parts (1 = no key split).
+int attention_x4a_parts(void* ws, int batch, int Lq, int Lk, const float** part_o, const float** part_ml) {
+  const int ns = x4a_nsplit(batch, Lq, Lk);
   const size_t rows = (size_t)batch * Lq;
   char* w = reinterpret_cast<char*>(ws);
   const float* po = reinterpret_cast<const float*>(w + (rows / 64) * (32 * 1024));
   if (part_o) *part_o = po;
-  if (part_ml) *part_ml = po + rows * DV;
-  return true;
+  if (part_ml) *part_ml = po + (size_t)ns * rows * DV;
+  return ns;
 }
 
 int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void* vt32, int batch, int Lq, int Lk, float scale,
                          hipStream_t st, void* o_hi, void* o_lo, int ldop, const float* q_rope_cis, int q_rope_grid, bool q_shared,
                          void* ws, size_t ws_bytes, bool merge) {
   DS2_REQUIRE(attention_x4a_supported(batch, Lq, Lk, DV, (o_hi && o_lo) || !merge), "attention_x4a: unsupported shape");
-  DS2_REQUIRE(merge || x4a_nsplit(batch, Lq, Lk) == 1, "attention_x4a: the un-merged form needs a launch without key split");
   // q == nullptr: the Q fragments at the start of `ws` are already there (launch_qproj_x4a, gemm_qproj.hip)
   DS2_REQUIRE(ldq % 4 == 0 && ldop % 4 == 0 && k_f16 && vt32 && ws && ws_bytes >= attention_x4a_ws_bytes(batch, Lq, Lk),
               "attention_x4a: bad argument / scratch too small");

@@ -1,5 +1,5 @@
-// Output side of the memory cross-attention in ONE kernel (mode bf16x3k with the assembly attention, no key split):
-//     o = O / l  (normalisation of the attention's un-normalised result, k_w8_merge<64> with one part)  ->  bf16 planes  ->
+// Output side of the memory cross-attention in ONE kernel (mode bf16x3k with the assembly attention; with or without its key split):
+//     o = merge of the attention's un-normalised part(s) (k_w8_merge<64>: weights exp2(m_s - m), one division)  ->  bf16 planes  ->
 //     x += o (Wo Wv)^T + (Wo bv + bo)   (the folded value / output projection, 64 -> 256, bf16x3: k_gemm_split_k64)
 // instead of k_w8_merge<64> (planes out) -> k_gemm_split_k64<8>: the 64-wide planes never reach HBM, one launch per layer less.
 // (RoPEAttention.forward's out_proj on the restructured product of DESIGN.md section 4; memory_attention.py:83-99.)
@@ -32,7 +32,8 @@ __device__ __forceinline__ float v_bf_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float v_bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 struct VoArgs {
-  const float* part_o; const float* part_ml;    // [rows, 64] un-normalised, [rows, 2] (maximum, sum)
+  const float* part_o; const float* part_ml;    // [nsplit][rows, 64] un-normalised, [nsplit][rows, 2] (maximum, sum)
+  int nsplit;                                   // parts of the key split (few objects: k_attention_x4a's gridDim.y), 1 = none
   const unsigned short *W_hi, *W_lo; int ldw;   // folded projection planes [256, ldw] bf16 (ldw = 64)
   const float* bias;                            // [256]
   const float* R; int ldr, r_mod;               // residual rows (row index modulo r_mod when > 0)
@@ -72,23 +73,37 @@ __global__ __launch_bounds__(256, 1) void k_vo_merge(VoArgs a) {
     // ---- O fragments: A operand (row = lane & 31, k = 16 s + 8 half .. + 7); normalised and split as k_w8_merge does for one part
     bf16x8 fh[4], fl[4];
     {
-      const float2 ml = *reinterpret_cast<const float2*>(a.part_ml + (size_t)rowc * 2);
-      const float w = __builtin_amdgcn_exp2f(ml.x - ml.x);   // (the merge's weight of its only part: exp2(0))
+      // k_w8_merge<64>'s expressions: maximum over the parts, weights exp2(m_s - m), weighted sums of the rows and of the row sums
+      float m = -INFINITY;
+      for (int p = 0; p < a.nsplit; ++p) m = fmaxf(m, a.part_ml[((size_t)p * a.rows + rowc) * 2]);
       float l = 0.f;
-      l += ml.y * w;
+      float4 acc[4][2];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) acc[s][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = 0; p < a.nsplit; ++p) {
+        const float2 ml = *reinterpret_cast<const float2*>(a.part_ml + ((size_t)p * a.rows + rowc) * 2);
+        const float w = __builtin_amdgcn_exp2f(ml.x - m);
+        const float* po = a.part_o + ((size_t)p * a.rows + rowc) * VK + half * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const float4 q = *reinterpret_cast<const float4*>(po + s * 16 + jj * 4);
+            acc[s][jj].x += q.x * w; acc[s][jj].y += q.y * w; acc[s][jj].z += q.z * w; acc[s][jj].w += q.w * w;
+          }
+        l += ml.y * w;
+      }
       const float inv = 1.f / l;
-      const float* po = a.part_o + (size_t)rowc * VK + half * 8;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         unsigned rh[4], rl[4];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          const float4 p = *reinterpret_cast<const float4*>(po + s * 16 + jj * 4);
-          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-          acc.x += p.x * w; acc.y += p.y * w; acc.z += p.z * w; acc.w += p.w * w;
           {
 #pragma clang fp contract(off)
-            const float v0 = acc.x * inv, v1 = acc.y * inv, v2 = acc.z * inv, v3 = acc.w * inv;
+            const float v0 = acc[s][jj].x * inv, v1 = acc[s][jj].y * inv, v2 = acc[s][jj].z * inv, v3 = acc[s][jj].w * inv;
             rh[2 * jj] = v_cvt_pk_bf16(v0, v1);
             rh[2 * jj + 1] = v_cvt_pk_bf16(v2, v3);
             rl[2 * jj] = v_cvt_pk_bf16(v0 - v_bf_lo(rh[2 * jj]), v1 - v_bf_hi(rh[2 * jj]));
@@ -148,11 +163,11 @@ __global__ __launch_bounds__(256, 1) void k_vo_merge(VoArgs a) {
 
 bool vo_merge_supported(int rows, int ldw) { return rows > 0 && ldw == 64; }
 
-int launch_vo_merge(const float* part_o, const float* part_ml, int rows, const void* w_hi, const void* w_lo, int ldw, const float* bias,
+int launch_vo_merge(const float* part_o, const float* part_ml, int nsplit, int rows, const void* w_hi, const void* w_lo, int ldw, const float* bias,
                     const float* R, int ldr, int r_mod, float* out, int ldo, hipStream_t st) {
-  DS2_REQUIRE(part_o && part_ml && w_hi && w_lo && R && out && vo_merge_supported(rows, ldw), "vo_merge: bad argument");
+  DS2_REQUIRE(part_o && part_ml && nsplit >= 1 && w_hi && w_lo && R && out && vo_merge_supported(rows, ldw), "vo_merge: bad argument");
   VoArgs a{};
-  a.part_o = part_o; a.part_ml = part_ml; a.W_hi = reinterpret_cast<const unsigned short*>(w_hi); a.W_lo = reinterpret_cast<const unsigned short*>(w_lo);
+  a.part_o = part_o; a.part_ml = part_ml; a.nsplit = nsplit; a.W_hi = reinterpret_cast<const unsigned short*>(w_hi); a.W_lo = reinterpret_cast<const unsigned short*>(w_lo);
   a.ldw = ldw; a.bias = bias; a.R = R; a.ldr = ldr; a.r_mod = r_mod; a.out = out; a.ldo = ldo; a.rows = rows;
   static int ncu = [] {
     int dev = 0, n = 0;

@@ -229,10 +229,10 @@ int launch_vt_pack32(const float* v, int ldv, int batch, int L, void* vt, hipStr
 int launch_attention_x4a(const float* q, int ldq, const void* k_f16, const void* vt32, int batch, int Lq, int Lk, float scale,
                          hipStream_t st, void* o_hi, void* o_lo, int ldop, const float* q_rope_cis, int q_rope_grid, bool q_shared,
                          void* ws, size_t ws_bytes, bool merge = true);
-bool attention_x4a_single_part(void* ws, int batch, int Lq, int Lk, const float** part_o, const float** part_ml);
-// normalisation of the assembly attention's single part + the folded value / output projection + residual in one kernel (gemm_vo.hip)
+int attention_x4a_parts(void* ws, int batch, int Lq, int Lk, const float** part_o, const float** part_ml);   // -> number of key-split parts
+// merge / normalisation of the assembly attention's part(s) + the folded value / output projection + residual in one kernel (gemm_vo.hip)
 bool vo_merge_supported(int rows, int ldw);
-int launch_vo_merge(const float* part_o, const float* part_ml, int rows, const void* w_hi, const void* w_lo, int ldw, const float* bias,
+int launch_vo_merge(const float* part_o, const float* part_ml, int nsplit, int rows, const void* w_hi, const void* w_lo, int ldw, const float* bias,
                     const float* R, int ldr, int r_mod, float* out, int ldo, hipStream_t st);
 
 // producers that emit bf16x3 operand planes directly (no fp32 round trip, no k_split_rows pre-pass)

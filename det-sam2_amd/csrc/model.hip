@@ -1361,6 +1361,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (!split) TRY(launch_rope(q, 256, cis, B, TOK, TOK, TOK, st));
     bool vofuse = false;
     const float *vo_po = nullptr, *vo_pml = nullptr;
+    int vo_ns = 1;
     if (split) {
       // k_proj + RoPE + split fused: the GEMM epilogue rotates and emits the key planes, no fp32 K round trip
       TRY(gemm(st, B * Nk, 256, 64, kin, 64, m->P(p + ".cross_attn_image.k_proj.weight"), 64,
@@ -1373,11 +1374,11 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
         DS2_CHECK_HIP(hipMemsetAsync(kpl.lo, 0, 32 * 512, st));
       }
       ProfScope _p("kernel.cross_attention", st);
-      // the attention's normalisation + the folded value / output projection + residual as ONE kernel (gemm_vo.hip) when the launch has no
-      // key split (DS2_MA_VOFUSE=0: k_w8_merge -> planes -> K = 64 GEMM; same bits either way)
+      // the merge / normalisation of the attention's part(s) + the folded value / output projection + residual as ONE kernel (gemm_vo.hip;
+      // DS2_MA_VOFUSE=0: k_w8_merge -> planes -> K = 64 GEMM; same bits either way)
       const char* voe = getenv("DS2_MA_VOFUSE");
-      vofuse = x4a && m->ma_fold_vo && !(voe && atoi(voe) == 0) && m->P("#ma_cross_vo_w." + ls) &&
-               attention_x4a_single_part(x4a_ws, B, TOK, Nk, &vo_po, &vo_pml) && vo_merge_supported(rows, 64);
+      vofuse = x4a && m->ma_fold_vo && !(voe && atoi(voe) == 0) && m->P("#ma_cross_vo_w." + ls) && vo_merge_supported(rows, 64);
+      if (vofuse) vo_ns = attention_x4a_parts(x4a_ws, B, TOK, Nk, &vo_po, &vo_pml);
       ds2_model::ActPlanes cp{};
       if (!vofuse) TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
       if (x4a)
@@ -1404,7 +1405,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       char ptag[96] = "";
       if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "kern k_vo_merge %d %d %d", rows, 256, 64);
       ProfScope _gp(ptag, st, g_prof_gemm);
-      TRY(launch_vo_merge(vo_po, vo_pml, rows, vwp.hi, vwp.lo, vwp.ld, m->P("#ma_cross_vo_b." + ls), q_once ? x1 : x, 256, q_once ? TOK : 0, x, 256, st));
+      TRY(launch_vo_merge(vo_po, vo_pml, vo_ns, rows, vwp.hi, vwp.lo, vwp.ld, m->P("#ma_cross_vo_b." + ls), q_once ? x1 : x, 256, q_once ? TOK : 0, x, 256, st));
     } else if (m->ma_fold_vo) {
       TRY(gemm(st, rows, 256, 64, a64, 64, m->P("#ma_cross_vo_w." + ls), 64, m->P("#ma_cross_vo_b." + ls), x, 256, DS2_ACT_NONE,
                q_once ? x1 : x, 256, q_once ? TOK : 0, nullptr, true, m));
