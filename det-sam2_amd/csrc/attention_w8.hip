@@ -834,9 +834,8 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   // merge (k_w8_merge).  The caller provides the scratch for the parts; without it, or when the grid already fills the chip,
   // one workgroup walks all keys.
   const int nblk = batch * (Lq / ((dv == 64 && !qg1) ? 256 : 128));
-  static const bool split_off = [] { const char* e = getenv("DS2_ATTN_KSPLIT"); return e && atoi(e) == 0; }();
   int nsplit = 1;
-  if (split_ws && !split_off && (dv == 64 || dv == 256) && nblk <= 128) {
+  if (split_ws && (dv == 64 || dv == 256) && nblk <= 128) {
     const int nkt = (Lk + BKEYS - 1) / BKEYS;
     nsplit = 256 / nblk;
     if (nsplit > 8) nsplit = 8;

@@ -527,12 +527,10 @@ __global__ __launch_bounds__(512) void k_attention_win2p(AttnArgs a) {
 
 }  // namespace
 
-// 16 x 16 (hiera_l stage 3) or 14 x 14 windows of one or several images, queries and keys on the same grid, head dim 72;
-// DS2_ATTN_WINLDS=0 keeps the general kernel
+// 16 x 16 (hiera_l stage 3) or 14 x 14 windows of one or several images, queries and keys on the same grid, head dim 72
 bool attention_winlds_supported(const AttnArgs& a) {
-  static const bool off = [] { const char* e = getenv("DS2_ATTN_WINLDS"); return e && atoi(e) == 0; }();
   const bool one_phase = a.D == D && (a.win_q == 16 || a.win_q == 14), two_phase = a.D == 96 && a.win_q == 14;
-  return !off && a.DV == a.D && (one_phase || two_phase) && a.win_k == a.win_q && a.Lq == a.win_q * a.win_q && a.Lk == a.Lq &&
+  return a.DV == a.D && (one_phase || two_phase) && a.win_k == a.win_q && a.Lq == a.win_q * a.win_q && a.Lk == a.Lq &&
          a.Hq == a.Hk && a.Wq == a.Wk &&
          a.nwx > 0 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && (a.o_hi ? a.ldop % 4 == 0 : a.ldo % 4 == 0) && a.heads <= 65535 &&
          a.batch <= 65535;

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <mutex>
 #include "kernels.h"
 #ifdef X4A_BODY_INC      // (tools/experiments/x4a_bench.hip: schedule experiments)
 #include X4A_BODY_INC
@@ -144,9 +145,8 @@ bool attention_x4a_enabled() {
 }
 // key split when the grid of batch * Lq / 256 workgroups leaves CUs idle (few objects): parts of >= 16 key tiles, <= 8 parts
 static int x4a_nsplit(int batch, int Lq, int Lk) {
-  static const bool off = [] { const char* e = getenv("DS2_ATTN_KSPLIT"); return e && atoi(e) == 0; }();
   const int nblk = batch * (Lq / 256), nkt = (Lk + BK - 1) / BK;
-  int ns = (off || nblk > 128) ? 1 : 256 / nblk;
+  int ns = nblk > 128 ? 1 : 256 / nblk;
   if (ns > 8) ns = 8;
   while (ns > 1 && (nkt + ns - 1) / ns < 16) --ns;
   while (ns > 1 && (ns - 1) * ((nkt + ns - 1) / ns) >= nkt) --ns;   // (no empty last part)
@@ -194,15 +194,17 @@ int launch_bank_vt32(const BankArgs& a, void* vt32, hipStream_t st) {
   return DS2_OK;
 }
 const unsigned char* attention_x4a_vt_slot_table() {   // vt_pos32 as a device table (per device, built once; k_bank_ptr_planes)
-  static const unsigned char* tab[64] = {};          // (a race between two host threads costs a second 32-byte allocation)
+  static const unsigned char* tab[64] = {};
+  static std::mutex mu;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
   if (!tab[dev]) {
     unsigned char h[32];
     for (int k = 0; k < 32; ++k) h[k] = (unsigned char)vt_pos32(k);
     unsigned char* d = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d), 32) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, h, 32, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h, 32, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
     tab[dev] = d;
   }
   return tab[dev];

@@ -688,11 +688,10 @@ __global__ __launch_bounds__(256) void k_mlp256_merge(MlpArgs a) {
 }  // namespace
 
 // parts of the hidden dimension for `rows` token rows on `ncu` CUs: as many as keep every CU busy, <= 8, each a whole number of
-// chunk pairs (DS2_MLP_HSPLIT=0: never)
+// chunk pairs
 int mlp256_hsplit(int rows, int H, int ncu) {
-  static const bool off = [] { const char* e = getenv("DS2_MLP_HSPLIT"); return e && atoi(e) == 0; }();
   const int nrb = cdiv(rows, MBR), npair = H / (2 * MHC);
-  if (off || nrb * 2 > ncu) return 1;
+  if (nrb * 2 > ncu) return 1;
   int hs = ncu / nrb;
   if (hs > 8) hs = 8;
   while (hs > 1 && npair % hs) --hs;

@@ -352,14 +352,12 @@ int heuristic_tile(const GemmSplitArgs& g) {
   if (cr3 < c128 && cr3 <= c256) tile = 3;
   const bool fits32 = (size_t)g.M * g.lda * 2 < (1ull << 32) && (size_t)g.N * g.ldw * 2 < (1ull << 32);   // 32-bit DMA offsets
   if (c256 < c128 && c256 < cr3) tile = fits32 ? 5 : 3;   // the LDS-DMA 256x256 kernel (else the 256x128 ring)
-  // persistent variant with loader / storer waves for GEMMs without residual / RoPE epilogue (default; DS2_GEMM_PP256=0
-  // keeps the one-tile-per-workgroup kernel for A/B runs)
-  static const bool pp256 = [] { const char* e = getenv("DS2_GEMM_PP256"); return !(e && atoi(e) == 0); }();
-  if (tile == 5 && pp256 && gemm_split_pp256_supported(g)) tile = 10;
+  // persistent variant with loader / storer waves for GEMMs without residual / RoPE epilogue
+  if (tile == 5 && gemm_split_pp256_supported(g)) tile = 10;
   // ... and it also beats the 256x128 ring wherever that one was chosen for its smaller column padding: the GEMMs of Hiera
   // stages 1-2 (K = 144 / 288: five to nine K tiles, i.e. mostly epilogue) run 10-25 % faster persistent
   // (profiles/r02at_tile_time_s12.txt)
-  if (tile == 3 && pp256 && gemm_split_pp256_supported(g) && b256 >= 256 && ncols > 128 && fits32) tile = 10;
+  if (tile == 3 && gemm_split_pp256_supported(g) && b256 >= 256 && ncols > 128 && fits32) tile = 10;
   // the assembly kernel with the overlapped epilogue (gemm_x4g.hip) wherever it takes the shape and fills the chip
   // (DS2_GEMM_X4G=0: the kernels above, for A/B runs)
   const char* x4g_e = getenv("DS2_GEMM_X4G");   // (read per call: the tests compare both paths in one process)
@@ -430,8 +428,7 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
   } else
   if (tile_env != 0) return launch_tile(g, tile_env, st);
   // K = 64 projections over hundreds of thousands of rows (memory-attention keys): HBM-bound weight-stationary kernel
-  static const bool k64 = [] { const char* e = getenv("DS2_GEMM_K64"); return !(e && atoi(e) == 0); }();
-  if ((k64 || g.c_hi_f16) && gemm_split_k64_supported(g)) {
+  if (gemm_split_k64_supported(g)) {
     if (!ds2_prof_kernels()) return launch_gemm_split_k64(g, st);
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return launch_gemm_split_k64(g, st);

@@ -434,8 +434,7 @@ int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st) {
   const bool planes = g.act == DS2_ACT_NONE && !g.gamma && !g.R && !g.C && g.C_hi;
   DS2_REQUIRE(!g.c_hi_f16 || (planes && !g.C_lo), "gemm_split_k64: fp16 hi plane needs the plane-only epilogue without a lo plane");
   // the key projection (256 columns, planes only, axial RoPE with the compact table): the register-transposed epilogue
-  const char* kt_e = getenv("DS2_GEMM_K64T");   // (read per call: the tests compare both forms in one process)
-  const bool k64t = !(kt_e && atoi(kt_e) == 0) && planes && ncols == 256 && g.N == 256 && g.ldcp == 256 && g.rope_cis && g.rope_w == 64 &&
+  const bool k64t = planes && ncols == 256 && g.N == 256 && g.ldcp == 256 && g.rope_cis && g.rope_w == 64 &&
                     g.rope_grid == 4096 && g.rope_L > 0 && (g.c_hi_f16 || g.C_lo) && !g.drop_terms;
   if (k64t && g.c_hi_f16)
     hipLaunchKernelGGL((k_gemm_split_k64t<true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);

@@ -332,7 +332,6 @@ int launch_gemm_split_pp256(const GemmSplitArgs& g, hipStream_t st) {
   static const int ncu = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    if (const char* e = getenv("DS2_GEMM_NCU")) n = atoi(e) > 0 ? atoi(e) : n;   // (experiment: persistent grid on fewer CUs - power limit)
     return n;
   }();
   const int grid = mt * nt < ncu ? mt * nt : ncu;

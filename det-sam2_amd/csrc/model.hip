@@ -255,10 +255,6 @@ static int model_precision(const ds2_model* m) { return m->precision; }
 #ifndef DS2_MA_Q_ONCE
 #define DS2_MA_Q_ONCE 1
 #endif
-static bool ma_fold_vo_enabled() {
-  static const bool v = [] { const char* e = getenv("DS2_MA_FOLD_VO"); return !(e && atoi(e) == 0); }();
-  return v;
-}
 ModelScope::ModelScope(const ds2_model* m) : dg(m->device), ps(m->precision) {}
 
 #define ALLOC(var, n)                                                        \
@@ -321,9 +317,8 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
     return DS2_ERR_STATE;
   }
   // a handful of rows against a model weight (token side of the two-way transformer, small heads): spread over the chip in
-  // exact fp32 instead of one or two latency-bound tiles (gemm_skinny.hip; DS2_GEMM_SKINNY=0 restores the tile kernels)
-  static const bool skinny_on = [] { const char* e = getenv("DS2_GEMM_SKINNY"); return !e || atoi(e) != 0; }();
-  if (skinny_on && M <= 128 && w_static && m && !planes_out && !rope_cis && K % 4 == 0 && lda % 4 == 0 &&
+  // exact fp32 instead of one or two latency-bound tiles (gemm_skinny.hip)
+  if (M <= 128 && w_static && m && !planes_out && !rope_cis && K % 4 == 0 && lda % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(A) & 15) == 0 && !m->act_planes.count(A)) {
     char ptag[96] = "";
     if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "gemm %d %d %d", M, N, K);
@@ -353,9 +348,6 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   char ptag[96] = "";
   if (g_prof_gemm) snprintf(ptag, sizeof(ptag), "gemm %d %d %d", M, N, K);
   ProfScope _gp(ptag, st, g_prof_gemm);
-  static const bool dbg_shapes = getenv("DS2_DEBUG_GEMM") != nullptr;
-  if (dbg_shapes) fprintf(stderr, "GEMM %d %d %d planesA=%d planes_out=%d act=%d R=%d\n", M, N, K,
-                          (int)(m && m->act_planes.count(A)), (int)planes_out, act, (int)(R != nullptr));
   const int Kp = round32(K);
   const size_t w_bytes = (size_t)N * Kp * 2;
   const unsigned short *ahi = nullptr, *alo = nullptr;
@@ -445,11 +437,6 @@ struct LnFuse {
   float* out_f32;                    // fp32 [rows, 256] (nullable)
   const ds2_model::ActPlanes* planes;   // pre-allocated operand planes, ld 256 (nullable)
 };
-// DS2_MLP_FUSED=0 keeps the two-GEMM form (A/B runs)
-static bool mlp_fused_enabled() {
-  static const bool v = [] { const char* e = getenv("DS2_MLP_FUSED"); return !(e && atoi(e) == 0); }();
-  return v;
-}
 // out = (act(A W1^T + b1) W2^T + b2) * gamma + R with the hidden activations kept in registers (gemm_mlp256.hip); bf16x3
 // modes, model width 256 only - the caller falls back to two GEMMs when this returns DS2_ERR_UNSUPPORTED.
 // A's operand planes must be registered (its producer emitted them) or are split here.
@@ -457,7 +444,7 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
                      const float* b1, const float* W2, const float* b2, const float* gamma, const float* R, int ldr, float* out,
                      int ldo, int act, bool planes_too = false, bool f16x2 = false, const LnFuse* lnf = nullptr,
                      const LnFuse* lni = nullptr) {   // lni: LayerNorm of the INPUT rows in the kernel's prologue (A = the un-normalised fp32 rows)
-  if (!ds2_split_mode() || !mlp_fused_enabled() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
+  if (!ds2_split_mode() || !A || !W1 || !W2 || !out) return DS2_ERR_UNSUPPORTED;
   MlpArgs a{};
   a.f16x2 = f16x2 ? 1 : 0;
   if (lnf) {   // LayerNorm of the result rows in the epilogue: planes (and / or fp32) of LN(result)
@@ -718,7 +705,7 @@ extern "C" int ds2_model_finalize(ds2_model* m, void* stream) {
     TRY(m->add_derived("@ma_qkv_b." + std::to_string(l), 768, &fb));
     const char* names[3] = {"q_proj", "k_proj", "v_proj"};
     // (fold: the value rows are out_proj o v_proj, constants.py fold_out_v - the attention output then IS the out_proj result)
-    m->ma_fold_vo = ma_fold_vo_enabled() && m->Pbytes("#ma_self_vo_w." + std::to_string(l)) == 256 * 256 * 4 &&
+    m->ma_fold_vo = m->Pbytes("#ma_self_vo_w." + std::to_string(l)) == 256 * 256 * 4 &&
                     m->Pbytes("#ma_cross_vo_w." + std::to_string(l)) == 256 * 64 * 4;
     for (int j = 0; j < 3; ++j) {
       TRY(expect(m, p + names[j] + ".weight", 256 * 256));
@@ -975,9 +962,8 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
     }
     {
       ProfScope _pa("kernel.hiera_attention", st);
-      // global attention in the split modes: K / V pre-split once per (image, head), attention_hg.hip (DS2_ATTN_HG=0: general kernel)
-      static const bool hg_on = [] { const char* e = getenv("DS2_ATTN_HG"); return !e || atoi(e) != 0; }();
-      if (hg_on && ds2_split_mode() && attention_hg_supported(aa)) {
+      // global attention in the split modes: K / V pre-split once per (image, head), attention_hg.hip
+      if (ds2_split_mode() && attention_hg_supported(aa)) {
         void* kimg = m->alloc_bytes(attention_hg_k_bytes(aa));
         void* vimg = m->alloc_bytes(attention_hg_vt_bytes(aa));
         if (!kimg || !vimg) { ds2_set_error("image encoder: workspace exhausted (global attention planes)"); return DS2_ERR_STATE; }
@@ -1169,8 +1155,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   const bool x4a = split && k_f16 && attention_x4a_enabled() && attention_x4a_supported(B, TOK, Nk, 64, true);
   const size_t x4a_ws_bytes = x4a ? attention_x4a_ws_bytes(B, TOK, Nk) : 0;
   const size_t x4a_bytes = x4a ? x4a_ws_bytes + (size_t)B * nt_c * 4096 + 4096 : 0;
-  const char* bd_env = bank ? getenv("DS2_BANK_DIRECT") : nullptr;   // (read per call: 0 = the fp32 tensors in every mode, for A/B runs)
-  const bool bank_direct = bank && x4a && !(bd_env && atoi(bd_env) == 0);       // entries -> kin planes + V^T tiles, no fp32 memory / memory_pos
+  const bool bank_direct = bank && x4a;       // entries -> kin planes + V^T tiles, no fp32 memory / memory_pos
   const size_t bank_fp32_bytes = (bank && !bank_direct) ? (size_t)2 * B * Nk * 64 * 4 + 512 : 0;
   const size_t need = ((size_t)rows * (256 * 5 + 768 + 64 + F) + (size_t)B * Nk * (64 + 256) + (size_t)TOK * 256 * 4) * 4 + split_bytes + plane_bytes + ksplit_bytes + x4a_bytes + (split ? (size_t)rows * 2048 + 4096 : 0) + mlp256_part_bytes(rows, F) + bank_fp32_bytes + (4u << 20);
   TRY(m->require(need, st));
@@ -1208,8 +1193,6 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     if (!ksplit_ws) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
     vlo_flag = reinterpret_cast<int*>(m->alloc_bytes(256));
     if (!vlo_flag) { ds2_set_error("memory_attention: workspace exhausted"); return DS2_ERR_STATE; }
-    static const bool no_vlo_skip = getenv("DS2_ATTN_NO_VLO_SKIP") != nullptr;
-    if (no_vlo_skip) vlo_flag = nullptr;
     if (x4a) {
       vt32 = m->alloc_bytes((size_t)B * nt_c * 4096);
       x4a_ws = m->alloc_bytes(x4a_ws_bytes);
@@ -1254,10 +1237,9 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   } else {
     TRY(launch_add_bcast(memory, 64, memory_pos, 64, 0, 1.0f, kin, 64, B * Nk, 64, st));
   }
-  // norm1 of layers 1.. and the final norm are computed in the epilogue of the previous layer's fused MLP (DS2_MA_FUSE_LN=0: as
-  // separate passes): their operand planes live outside the per-layer workspace marks, two sets used alternately
-  static const bool fuse_ln_on = [] { const char* e = getenv("DS2_MA_FUSE_LN"); return !(e && atoi(e) == 0); }();
-  const bool fuse_ln = split && fuse_ln_on && mlp_fused_enabled();
+  // norm1 of layers 1.. and the final norm are computed in the epilogue of the previous layer's fused MLP: their operand planes
+  // live outside the per-layer workspace marks, two sets used alternately
+  const bool fuse_ln = split;
   ds2_model::ActPlanes n1p[2] = {};
   if (fuse_ln)
     for (int i = 0; i < 2; ++i) {
@@ -1279,11 +1261,10 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     const float* xin = once ? x1 : x;
     if (n1_ready) m->act_planes[t] = n1p[l & 1];   // emitted by the previous layer's MLP epilogue
     else TRY(layernorm(m, st, p + ".norm1", xin, t, Bs * TOK, 256, 1e-5f, DS2_ACT_NONE, true));
-    // in_proj + the key rotation / fp16 plane + the V^T tiles as ONE kernel (gemm_qkvs.hip; DS2_MA_QKVFUSE=0: the GEMM, k_rope_split and
-    // k_vt_split16; same bits either way).  Mode bf16x3k only: single fp16 planes, the values' lo plane is not read
-    const char* qkve = getenv("DS2_MA_QKVFUSE");
+    // in_proj + the key rotation / fp16 plane + the V^T tiles as ONE kernel (gemm_qkvs.hip; where it does not apply: the GEMM,
+    // k_rope_split and k_vt_split16).  Mode bf16x3k only: single fp16 planes, the values' lo plane is not read
     auto tpl = m->act_planes.find(t);
-    const bool qkvf = split && k_f16 && !klo_planes && !(qkve && atoi(qkve) == 0) && tpl != m->act_planes.end() && tpl->second.ld == 256 &&
+    const bool qkvf = split && k_f16 && !klo_planes && tpl != m->act_planes.end() && tpl->second.ld == 256 &&
                       m->P("@ma_qkv_w." + ls) && qkv_self_supported(Bs * TOK, 256, 256, TOK);
     const int ldq_s = qkvf ? 256 : 768;
     if (qkvf) {
@@ -1340,11 +1321,10 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     //    softmax(QK^T) (M Wv^T + bv) = (softmax(QK^T) M) Wv^T + bv, so P.V runs in the 64-d memory space.
     m->act_planes.erase(a);   // self-attention planes are consumed; `a` is re-used below
     const int qrows = q_once ? TOK : rows;
-    // norm2 -> q_proj -> RoPE -> scale -> fp16 Q fragments of the assembly attention as ONE kernel (gemm_qproj.hip; DS2_MA_QFUSE=0: the
-    // LayerNorm pass, the GEMM and the attention's query pass; same bits either way)
-    const char* qfe = getenv("DS2_MA_QFUSE");
+    // norm2 -> q_proj -> RoPE -> scale -> fp16 Q fragments of the assembly attention as ONE kernel (gemm_qproj.hip; where it does
+    // not apply: the LayerNorm pass, the GEMM and the attention's query pass)
     const float* qw = m->P(p + ".cross_attn_image.q_proj.weight");
-    const bool qfuse = x4a && qw && !(qfe && atoi(qfe) == 0) && qproj_x4a_supported(qrows, 256, 256) &&
+    const bool qfuse = x4a && qw && qproj_x4a_supported(qrows, 256, 256) &&
                        m->P(p + ".norm2.weight") && m->P(p + ".norm2.bias");
     if (qfuse) {
       GemmPlanes qwp;
@@ -1375,9 +1355,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
       }
       ProfScope _p("kernel.cross_attention", st);
       // the merge / normalisation of the attention's part(s) + the folded value / output projection + residual as ONE kernel (gemm_vo.hip;
-      // DS2_MA_VOFUSE=0: k_w8_merge -> planes -> K = 64 GEMM; same bits either way)
-      const char* voe = getenv("DS2_MA_VOFUSE");
-      vofuse = x4a && m->ma_fold_vo && !(voe && atoi(voe) == 0) && m->P("#ma_cross_vo_w." + ls) && vo_merge_supported(rows, 64);
+      // where it does not apply: k_w8_merge -> planes -> K = 64 GEMM)
+      vofuse = x4a && m->ma_fold_vo && m->P("#ma_cross_vo_w." + ls) && vo_merge_supported(rows, 64);
       if (vofuse) vo_ns = attention_x4a_parts(x4a_ws, B, TOK, Nk, &vo_po, &vo_pml);
       ds2_model::ActPlanes cp{};
       if (!vofuse) TRY(new_act_planes(m, a64, rows, 64, &cp, st));   // consumer: v_proj GEMM
@@ -1418,8 +1397,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     //    its own pass writing the operand planes; same bits either way)
     MlpArgs probe{};
     probe.rows = rows; probe.D = 256; probe.H = F; probe.ldx = 256; probe.ldw1 = 256; probe.ldw2 = F; probe.ldo = 256; probe.ldr = 256;
-    const char* l3e = getenv("DS2_MA_LN3_FUSE");
-    const bool ln3_in = split && mlp_fused_enabled() && f16x2_enabled() && mlp256_supported(probe) && !(l3e && atoi(l3e) == 0) &&
+    const bool ln3_in = split && f16x2_enabled() && mlp256_supported(probe) &&
                         m->P(p + ".norm3.weight") && m->P(p + ".norm3.bias");
     const LnFuse lni{m->P(p + ".norm3.weight"), m->P(p + ".norm3.bias"), 1e-5f, nullptr, nullptr};
     if (!ln3_in) TRY(layernorm(m, st, p + ".norm3", x, t, rows, 256, 1e-5f, DS2_ACT_NONE, true));
@@ -1883,9 +1861,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   const std::string me = "memory_encoder", ds = me + ".mask_downsampler.encoder.";
   ALLOC(c1, (size_t)B * 262144 * 4);
   // low-res logits: upsample + sigmoid / binarise + first conv stage in one kernel - the 1024^2 mask is never materialised
-  // (DS2_ME_FUSE_UP=0: the two-kernel path, bit-identical)
-  static const bool fuse_up = [] { const char* e = getenv("DS2_ME_FUSE_UP"); return !e || atoi(e) != 0; }();
-  if (!masks_hi && fuse_up) {
+  if (!masks_hi) {
     TRY(launch_mask_up_conv1(low_res, 256, 1024, binarize ? 1 : 0, m->cfg.sigmoid_scale_for_mem_enc, m->cfg.sigmoid_bias_for_mem_enc,
                              m->P(ds + "0.weight"), m->P(ds + "0.bias"), m->P(ds + "1.weight"), m->P(ds + "1.bias"), c1, B, st));
   } else {
@@ -1905,11 +1881,10 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   TRY(launch_conv3x3s2_small(c1, m->P(ds + "3.weight"), m->P(ds + "3.bias"), m->P(ds + "4.weight"), m->P(ds + "4.bias"), c2, B,
                              512, 4, 16, st));
   // im2col matrices feed one GEMM each: in the split modes they are written as its operand planes directly (no fp32 matrix, no
-  // operand-split pre-pass over 151 MB; DS2_ME_COL_PLANES=0: fp32 + pre-pass, bit-identical)
-  static const bool col_planes = [] { const char* e = getenv("DS2_ME_COL_PLANES"); return !e || atoi(e) != 0; }();
+  // operand-split pre-pass over 151 MB)
   auto im2col = [&](const float* in, float* col, int Hin, int Cin) -> int {
     const int rows_c = B * (Hin / 2) * (Hin / 2), K = 9 * Cin;
-    if (col_planes && ds2_split_mode()) {
+    if (ds2_split_mode()) {
       ds2_model::ActPlanes cp;
       cp.ld = round32i(K);
       cp.hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows_c * cp.ld * 2));
@@ -1949,8 +1924,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
     // own pass; same bits either way)
     MlpArgs probe{};
     probe.rows = rows; probe.D = 256; probe.H = 1024; probe.ldx = 256; probe.ldw1 = 256; probe.ldw2 = 1024; probe.ldo = 256; probe.ldr = 256;
-    const char* lfe = getenv("DS2_ME_LN_FUSE");
-    const bool ln_in = ds2_split_mode() && mlp_fused_enabled() && f16x2_enabled() && mlp256_supported(probe) && !(lfe && atoi(lfe) == 0) &&
+    const bool ln_in = ds2_split_mode() && f16x2_enabled() && mlp256_supported(probe) &&
                        m->P(p + ".norm.weight") && m->P(p + ".norm.bias");
     const LnFuse lni{m->P(p + ".norm.weight"), m->P(p + ".norm.bias"), 1e-6f, nullptr, nullptr};
     if (!ln_in) TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
@@ -2066,8 +2040,7 @@ extern "C" int ds2_op_attention(const float* q, const float* k, const float* v, 
   a.batch = batch; a.heads = heads; a.D = D; a.DV = DV; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
   a.win_q = win_q; a.win_k = win_k; a.Hq = Hq; a.Wq = Wq; a.Hk = Hk; a.Wk = Wk; a.nwx = nwx;
   a.k_pad = k_pad; a.v_pad = v_pad;
-  static const bool hg_on = [] { const char* e = getenv("DS2_ATTN_HG"); return !e || atoi(e) != 0; }();
-  if (hg_on && ds2_split_mode() && attention_hg_supported(a)) {   // as the image encoder does for its global-attention blocks
+  if (ds2_split_mode() && attention_hg_supported(a)) {   // as the image encoder does for its global-attention blocks
     hipStream_t st = (hipStream_t)stream;
     const size_t kb = (attention_hg_k_bytes(a) + 255) & ~(size_t)255, vb = attention_hg_vt_bytes(a);
     TRY(g_gemm_ctx.require(kb + vb, st));

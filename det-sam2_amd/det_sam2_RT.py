@@ -48,7 +48,10 @@ class PackedMasks(Mapping):
 
 
 class _FolderFrames(Sequence):
-    """Lazy list of the decodable image files of a folder (see VideoProcessor.load_frames_from_folder)."""
+    """Lazy list of the image files of a folder (see VideoProcessor.load_frames_from_folder).  Construction only reads the
+    headers (PIL's verify: no pixel is decoded); a frame is decoded when it is accessed.  A file whose header parses but whose
+    payload does not decode (a truncated JPEG) is skipped, with the reference's message, when the stream reaches it -
+    cv2.imread returning None has the same effect there (det_sam2_RT.py:516-518)."""
 
     def __init__(self, folder_path):
         from PIL import Image
@@ -56,8 +59,8 @@ class _FolderFrames(Sequence):
         for name in sorted(f for f in os.listdir(folder_path) if f.endswith((".png", ".jpg", ".jpeg"))):
             try:
                 with Image.open(os.path.join(folder_path, name)) as im:
-                    im.load()       # full decode: a truncated file with a valid header is skipped here, as the reference skips
-                    self.names.append(name)                             # whatever cv2.imread cannot decode (det_sam2_RT.py:507-524)
+                    im.verify()
+                self.names.append(name)
             except Exception:
                 print(f"--- cannot read frame file: {os.path.join(folder_path, name)}")
 
@@ -70,6 +73,13 @@ class _FolderFrames(Sequence):
             return [self[j] for j in range(*i.indices(len(self)))]
         with Image.open(os.path.join(self.folder, self.names[i])) as im:
             return np.ascontiguousarray(np.asarray(ImageOps.exif_transpose(im).convert("RGB"), dtype=np.uint8))
+
+    def __iter__(self):
+        for i in range(len(self.names)):
+            try:
+                yield self[i]
+            except Exception:
+                print(f"--- cannot read frame file: {os.path.join(self.folder, self.names[i])}")
 
 
 class VideoProcessor:

@@ -55,7 +55,7 @@ class SAM2VideoPredictor:
         # Overlapped kernels share CUs, so every per-kernel duration (and the bench's roofline fraction) reads ~5 %
         # worse than in isolation; DS2_ASYNC_ENCODE=0 switches it off.
         self.async_encode = hip is None and os.environ.get("DS2_ASYNC_ENCODE", "1") not in ("", "0")
-        self.async_lookahead = int(os.environ.get("DS2_ASYNC_LOOKAHEAD", "12"))
+        self.async_lookahead = 12
         self._hip_enc, self._enc_stream = None, None
 
     # ------------------------------------------------------------------ frame ingest (A3)
@@ -674,8 +674,11 @@ class SAM2VideoPredictor:
     def _memory_conditioned(self, B, f2, mem_entries, ptr_entries):
         """_prepare_memory_conditioned_features' tensor part (sam2_base.py:565-690): bank -> memory attention.  One fused call when the
         stage interface has it (the fp32 memory / memory_pos tensors are then never materialised), else the two stages."""
+        if not mem_entries:
+            raise RuntimeError("memory attention needs at least one memory frame in the bank (a tracked frame always attends its "
+                               "conditioning frame, sam2_base.py:565-590); got object pointers only")
         fused = getattr(self.hip, "bank_attention", None)
-        if fused is not None and mem_entries:
+        if fused is not None:
             return fused(B, f2, mem_entries, ptr_entries)
         memory, memory_pos = self.hip.bank_assemble(B, mem_entries, ptr_entries)
         return self.hip.memory_attention(B, f2, memory, memory_pos, 4 * len(ptr_entries))

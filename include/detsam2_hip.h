@@ -106,7 +106,11 @@ int ds2_bank_assemble(ds2_model* m, int32_t B, int32_t n_mem, const void* const*
 /* ---- A12: MemoryAttention.forward (sam2/modeling/memory_attention.py:119-176) with RoPEAttention
  * (sam/transformer.py:312-363).  curr [4096,256] is the level-2 feature of the frame, shared by the B
  * objects (the reference .expand()s it, sam2_video_predictor.py:1193-1206); curr_pos is the model
- * constant "#vision_pos".  out [B,4096,256]. */
+ * constant "#vision_pos".  out [B,4096,256].
+ * Contract: the bank holds at least one memory frame - (Nk - num_obj_ptr_tokens) is a positive multiple of 4096 - in every
+ * arithmetic mode (DS2_ERR_ARG otherwise).  A tracked frame of the reference always attends at least its conditioning
+ * frame (sam2_base.py:565-590 adds the selected cond frames before anything else; a frame with no memory at all takes the
+ * no_mem_embed branch :676-690 and never reaches memory_attention), so a pointer-only bank is not a state of the path. */
 int ds2_memory_attention(ds2_model* m, int32_t B, const float* curr, const float* memory, const float* memory_pos,
                          int32_t Nk, int32_t num_obj_ptr_tokens, float* out, void* stream);
 
@@ -240,12 +244,19 @@ int ds2_mask_output(ds2_model* m, const float* low_res, int32_t B, int32_t Hv, i
  *  0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
  *  1 = split-precision bf16x3: x = x0 + x1 in bf16, a0b0 + a0b1 + a1b0 with fp32 accumulation, ~2^-16 relative error
  *      per product;
- *  2 = bf16x3k (default): as 1, except inside the memory attention (cross and self attention,
- *      sam/transformer.py:312-363): the SCORE products are plain bf16 x bf16 with fp32 accumulation - q.k = q0 k0, 1 term -
- *      and the softmax weights (computed and summed in fp32) enter the P.V product rounded to one bf16 plane, as do
- *      the values of the self-attention.  This removes
- *      two thirds of the score MFMAs, a third of the P.V MFMAs and the key lo plane from HBM and LDS.  Passes the precision
- *      gate recorded in DESIGN.md (every reference golden <= 5e-4 in 1 - IoU).
+ *  2 = bf16x3k (default): as 1, except on the tracking chain:
+ *      - inside the memory attention (cross and self attention, sam/transformer.py:312-363) every operand of a matrix product
+ *        is ONE IEEE fp16 plane (11-bit significand; queries after RoPE and scaling, keys after RoPE, the softmax weights
+ *        - computed and summed in fp32 - and the values): q.k = q0 k0 and P.V = p0 v0 with fp32 accumulation, 1 MFMA term
+ *        each (v_mfma_f32_32x32x16_f16).  The value operand keeps a second plane only for the object-pointer tokens (the
+ *        frame tokens are bf16 storage in the bank, exactly representable in one fp16 plane);
+ *      - the fused MLPs of the memory attention (linear1 / linear2, memory_attention.py:90-95) and of the memory encoder's
+ *        CXBlocks (memory_encoder.py:104-117) use two fp16 terms per product: activations one fp16 plane, weights two
+ *        (a0 w0 + a0 w1).
+ *      Everything else (image encoder, SAM heads, projections, convolutions) is the three-term bf16 product of mode 1.
+ *      Compared with mode 1 this removes two thirds of the score MFMAs, a third of the P.V MFMAs and the key lo plane from
+ *      HBM and LDS.  Passes the precision gate recorded in DESIGN.md (every reference golden <= 1e-3 in 1 - IoU; measured
+ *      <= 2.0e-4 at video resolution, tests/test_hip_measured_shape.py).
  * Softmax, LayerNorm, residuals and all storage stay fp32 in every mode. */
 int ds2_set_precision(int32_t mode);
 int ds2_get_precision(void);

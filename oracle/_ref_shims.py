@@ -18,6 +18,10 @@ it (recipe: SURVEY.md section 8c):
   it is the identity; ``cvtColor`` is a channel flip.
 * ``ultralytics.YOLO``: replaced by a scripted detector that replays boxes we give it
   (output contract from ``det_sam2_RT.py:228-238``).
+* ``readerwriterlock`` (``Det_SAM2_pipeline.py:10,71``): ``rwlock.RWLockWrite().gen_wlock()`` as a plain mutex - the
+  pipeline only ever takes the write lock.
+* ``cv2.VideoCapture`` (``Det_SAM2_pipeline.py:115-131``): replays the frames registered under a source name
+  (``ScriptedCapture.sources``), as BGR - the pipeline converts every frame back with ``cvtColor(BGR2RGB)``.
 """
 from __future__ import annotations
 
@@ -65,6 +69,42 @@ class ScriptedDetector:
             yield types.SimpleNamespace(boxes=boxes)
 
 
+class ScriptedCapture:
+    """Stand-in for ``cv2.VideoCapture``: ``sources[name]`` is a list of RGB uint8 frames; ``read()`` hands them out
+    as BGR and reports the end of the stream with ``(False, None)`` like OpenCV does."""
+
+    sources: dict = {}
+
+    def __init__(self, source):
+        self.frames = ScriptedCapture.sources.get(source)
+        self.pos = 0
+
+    def isOpened(self):
+        return self.frames is not None
+
+    def read(self):
+        if self.pos >= len(self.frames):
+            return False, None
+        f = self.frames[self.pos]
+        self.pos += 1
+        return True, f[..., ::-1].copy()
+
+    def release(self):
+        pass
+
+
+class _WriteLock:
+    def __init__(self):
+        import threading
+        self._m = threading.Lock()
+
+    def gen_wlock(self):
+        return self._m
+
+    def gen_rlock(self):
+        return self._m
+
+
 def install_shims() -> None:
     if "sam2" in sys.modules:
         return
@@ -99,7 +139,14 @@ def install_shims() -> None:
     cv2.COLOR_RGB2BGR = 0
     cv2.COLOR_BGR2RGB = 1
     cv2.cvtColor = lambda img, code: img[..., ::-1].copy()
+    cv2.VideoCapture = ScriptedCapture
     sys.modules["cv2"] = cv2
+    # --- readerwriterlock (the pipeline's hand-off lock)
+    rwl = types.ModuleType("readerwriterlock")
+    rwl.rwlock = types.ModuleType("readerwriterlock.rwlock")
+    rwl.rwlock.RWLockWrite = _WriteLock
+    sys.modules["readerwriterlock"] = rwl
+    sys.modules["readerwriterlock.rwlock"] = rwl.rwlock
     # --- ultralytics / IPython / pympler / frames2video
     ul = types.ModuleType("ultralytics")
     ul.checks = lambda: None

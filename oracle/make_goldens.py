@@ -651,6 +651,117 @@ def e2e_nopost(name="sam2.1_hiera_t"):
 
 
 
+PIPE_IDS = [2, 11, 6]          # detector objects -> YOLO class ids: 11 is special (collected, skipped by default), 2 and 6 are tracked
+PIPE_SMALL_KW = dict(frame_buffer_size=4, detect_interval=4, max_frame_num_to_track=8, max_inference_state_frames=2000)
+
+
+class _PipelineRecorder:
+    """Stands where the reference's VideoPostProcessor stands (Det_SAM2_pipeline.py:48,150-151,193-208) and records what the
+    consumer thread hands it: the relative frame index of every accepted delivery with a copy of its masks."""
+
+    def __init__(self):
+        outer = self
+        self.special, self.deliveries, self._pending = None, [], None
+
+        class _Positions(dict):
+            def __setitem__(s, frame_idx, token):      # balls_positions[frame_idx] = process_frame_positions(segments), :196
+                outer.deliveries.append((int(frame_idx), outer._pending))
+                dict.__setitem__(s, frame_idx, token)
+
+        self.balls_positions, self.balls_velocities = _Positions(), {}
+
+    def get_hole_name(self, special):
+        self.special = [np.asarray(b, np.float32).reshape(-1).copy() for b in special]
+
+    def get_boundary_from_holes(self):
+        pass
+
+    def process_frame_positions(self, segments):
+        self._pending = {int(k): np.asarray(v).copy() for k, v in segments.items()}
+        return len(self.deliveries)
+
+    def process_frame_velocities(self, frame_idx, time_interval=1.0):
+        return {}
+
+    def check_ball_disappeared_pot(self, frame_idx):
+        pass
+
+    check_ball_collision = check_ball_rebound = check_ball_disappeared_pot
+
+
+def _run_reference_pipeline(fname, n_frames, max_frames, vp_override=None, name="sam2.1_hiera_t"):
+    """F1: the reference's DetSAM2Pipeline.inference (Det_SAM2_pipeline.py:81-247) itself - constructor, producer thread with
+    cv2.VideoCapture loop, transform_video_segments, consumer thread - over a synthetic stream; only the third-party
+    modules are harness stand-ins (oracle/_ref_shims.py) and the post-processor is a recorder.  ``vp_override`` replaces
+    VideoProcessor keyword arguments that the reference constructor hard-codes (:31-46) to keep a fixture small."""
+    import threading
+
+    RS.install_shims()
+    import det_sam2_RT
+    import Det_SAM2_pipeline as RP          # the reference module (sys.path: /root/reference/det_sam2_inference)
+    assert RP.__file__.startswith(RS.REFERENCE_ROOT), RP.__file__
+    cfg = resolve_config(name)
+    sd = synthetic_state_dict(cfg, 0)
+    det_sam2_RT.build_sam2_video_predictor = lambda c, ckpt: RS.instantiate_from_yaml(c, sd)
+    if vp_override:
+        RP.VideoProcessor = lambda **kw: det_sam2_RT.VideoProcessor(**{**kw, **vp_override})
+    else:
+        RP.VideoProcessor = det_sam2_RT.VideoProcessor
+    pipe = RP.DetSAM2Pipeline(sam2_output_frame_dir="/tmp/ref_pipe_out", sam2_checkpoint_path=None,
+                              sam2_config_path=f"configs/sam2.1/{name}.yaml", detect_model_weights=None,
+                              output_video_dir="/tmp/ref_pipe_out")
+    vp = pipe.video_processor
+    det = SyntheticDetector(len(PIPE_IDS), class_ids=PIPE_IDS)
+    RS.ScriptedDetector.script = [[(d["coordinates"], d["class"][0], d["confidence"][0]) for d in det(t)]
+                                  for t in range(n_frames) if t % vp.detect_interval == 0]
+    RS.ScriptedDetector.cursor = 0
+    RS.ScriptedCapture.sources = {"synthetic": [synthetic_frame(t) for t in range(n_frames)]}
+    rec = _PipelineRecorder()
+    pipe.post_processor = rec
+    enq = []
+    put = pipe.frames_queue.put
+    pipe.frames_queue.put = lambda item: (enq.append(int(item[0])), put(item))[1]
+    before = set(threading.enumerate())
+    t0 = time.time()
+    pipe.inference(video_source="synthetic", max_frames=max_frames)
+    pipe.inference_done_event.wait()
+    while not pipe.frames_queue.empty():           # the consumer drains what is left (:183-185)
+        time.sleep(0.05)
+    time.sleep(1.0)
+    for th in set(threading.enumerate()) - before:
+        th.join(timeout=5.0)                       # the reference's consumer can block in Queue.get() for ever once the
+    dt = time.time() - t0                          # producer is done (:188 has no timeout); its work is complete by then
+    objs = sorted(rec.deliveries[0][1])
+    out = {"seconds": np.float64(dt), "n_frames": np.int64(n_frames), "max_frames": np.int64(max_frames),
+           "enqueued": np.array(enq), "delivered": np.array([d[0] for d in rec.deliveries]),
+           "has_processed": np.array(pipe.has_processed_frames), "obj_ids": np.array(objs),
+           "special": np.stack(rec.special), "left_in_pipeline": np.array(sorted(pipe.video_segments)),
+           "left_in_backbone": np.array(sorted(vp.video_segments)),
+           "vp_kwargs": np.array([vp.frame_buffer_size, vp.detect_interval, vp.max_frame_num_to_track,
+                                  vp.max_inference_state_frames])}
+    for i, (t, seg) in enumerate(rec.deliveries):
+        assert sorted(seg) == objs and all(m.shape == (1, 1024, 1024) and m.dtype == bool for m in seg.values())
+        m = np.stack([seg[o] for o in objs])
+        out[f"bits{i}"] = np.packbits(m[:, :, ::2, ::2])                 # video-res masks, 2x decimated
+        out[f"area{i}"] = m.reshape(len(objs), -1).sum(1)                # exact pixel counts at full resolution
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+    print(fname, dt, "s enqueued", enq, "delivered", out["delivered"], "special", out["special"], "left", out["left_in_pipeline"])
+
+
+def pipeline(which="small"):
+    """``small``: buffers of 4 / track 8 over 14 frames, stream ends -> the flush path (:124-131); ``cut``: max_frames
+    reached with frames still buffered (:159-162: no flush); ``default``: the reference constructor's own 30 / 30 / 60
+    over 70 frames."""
+    if which == "small":
+        _run_reference_pipeline("pipeline_small.npz", 14, 1000, PIPE_SMALL_KW)
+    elif which == "cut":
+        _run_reference_pipeline("pipeline_cut.npz", 12, 10, PIPE_SMALL_KW)
+    else:
+        _run_reference_pipeline("pipeline_default.npz", 70, 1000, None)
+    sys.stdout.flush()
+    os._exit(0)          # a consumer thread blocked in Queue.get() would keep the interpreter alive
+
+
 if __name__ == "__main__":
     assert RS.reference_available(), "needs /root/reference (build container only)"
     os.makedirs(GOLD, exist_ok=True)

@@ -192,14 +192,12 @@ def test_memory_attention_at_bench_size(B, NF, NP, x4a, monkeypatch):
         torch.cuda.synchronize()
         assert torch.equal(again, out), float((again - out).abs().max())
     # the one-call form of the tracking loop: with the assembly attention the bank's entries become kin planes / V^T tiles directly
-    # (no fp32 memory / memory_pos), with DS2_BANK_DIRECT=0 or the 8-wave kernel through fp32 tensors in the workspace - same bits
+    # (no fp32 memory / memory_pos), with the 8-wave kernel through fp32 tensors in the workspace - same bits as the two-call form
     entries = [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)]
     pentries = [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)]
-    for direct in ("1", "0"):
-        monkeypatch.setenv("DS2_BANK_DIRECT", direct)
-        fused = hm.bank_attention(B, curr.to(d), entries, pentries)
-        torch.cuda.synchronize()
-        assert torch.equal(fused, out), (direct, float((fused - out).abs().max()))
+    fused = hm.bank_attention(B, curr.to(d), entries, pentries)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, out), float((fused - out).abs().max())
 
 
 @pytest.mark.parametrize("prompt,multimask", [("box", False), ("none", True), ("click", True), ("clicks", False), ("clicks12", False)])
@@ -325,34 +323,6 @@ def test_model_view_shares_weights_and_gives_identical_results():
         _capi.check(view.lib.ds2_model_set_param(view.h, b"x", a.ctypes.data_as(C.c_void_p), a.nbytes), "ds2_model_set_param")
 
 
-@pytest.mark.parametrize("prec", ["bf16x3k", "bf16x3"])
-@pytest.mark.parametrize("B,NF,NP", [(16, 7, 16), (4, 2, 3), (3, 1, 1)])
-def test_key_projection_epilogues_agree(prec, B, NF, NP, monkeypatch):
-    """Round 5: the key projection's register-transposed epilogue (k_gemm_split_k64t: RoPE table in LDS, 4 x 4 lane-quad transposes,
-    no LDS slab, no table loads behind the stores) against the slab epilogue it replaces (DS2_GEMM_K64T=0) - the memory attention's
-    output must agree BIT FOR BIT (full bank, a ragged row count: 4 x 8204 and 3 x 4100 rows are not multiples of 32)."""
-    from det_sam2_amd.hip_model import HipSam2
-    cfg = resolve_config("sam2.1_hiera_t")
-    hm = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=16)
-    hm.set_precision(prec)
-    d = hm.device
-    g = torch.Generator().manual_seed(5 + NP)
-    curr = torch.randn(4096, 256, generator=g).to(d)
-    feats = [(torch.randn(B, 4096, 64, generator=g).to(torch.bfloat16).to(d), 6 - i) for i in range(NF)]
-    ptrs = [(torch.randn(B, 256, generator=g).to(d), float(i) / 15.0) for i in range(NP)]
-    mem_d, pos_d = hm.bank_assemble(B, feats, ptrs)
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("DS2_GEMM_K64T", mode)
-        hm.profile_enable(True, gemm_shapes=True)
-        for t in hm.profile_tags():
-            hm.profile_read(t)
-        outs[mode] = hm.memory_attention(B, curr, mem_d, pos_d, 4 * NP).clone()
-        torch.cuda.synchronize()
-        hm.profile_enable(False)
-    assert torch.equal(outs["0"], outs["1"]), float((outs["0"] - outs["1"]).abs().max())
-
-
 @pytest.mark.parametrize("rows", [4096, 8192 + 64])
 def test_fused_query_kernel_equals_the_three_kernels_it_replaces(rows):
     """gemm_qproj.hip (norm2 -> q_proj -> RoPE -> scale -> fp16 Q fragments of the assembly cross-attention in one kernel;
@@ -371,40 +341,3 @@ def test_fused_query_kernel_equals_the_three_kernels_it_replaces(rows):
     assert ref.view(torch.float16).float().abs().max() > 0.1          # (not a comparison of zeros)
 
 
-@pytest.mark.parametrize("switch", ["DS2_MA_QKVFUSE", "DS2_MA_QFUSE", "DS2_MA_VOFUSE", "DS2_MA_LN3_FUSE", "DS2_ME_LN_FUSE", "DS2_BANK_DIRECT", "DS2_GEMM_K64T"])
-@pytest.mark.parametrize("B,NF,NP", [(3, 2, 3), (16, 7, 16)])
-def test_fused_kernels_of_round_5_are_bit_identical_to_the_chains_they_replace(switch, B, NF, NP, monkeypatch):
-    """Every fusion of round 5 on the tracking chain keeps the per-element arithmetic and its order: with the switch at 0 (the kernels
-    it replaced) ds2_bank_memory_attention / ds2_memory_encoder give the same bits.  k_qkv_self (in_proj + key rotation / plane + V^T
-    tiles), k_qproj_x4a (norm2 + q_proj + query pass), k_vo_merge (the attention's normalisation + the folded value / output projection), the LayerNorm in the fused MLP's prologue (memory attention, memory encoder),
-    the bank straight to the attention's operands, the key projection's register-transposed epilogue.  (3 objects: the hidden-split form
-    of the fused MLP, a ragged pointer tile; 16 objects: the measured shape.)"""
-    from det_sam2_amd.hip_model import HipSam2
-    cfg = resolve_config("sam2.1_hiera_t")
-    key = ("bitid", B)
-    if key not in _CACHE:
-        _CACHE[key] = HipSam2(cfg, synthetic_state_dict(cfg, 0), "cuda:0", max_batch=B)
-    hm = _CACHE[key]
-    hm.set_precision("bf16x3k")
-    g = torch.Generator().manual_seed(5)
-    d = hm.device
-    curr = torch.randn(4096, 256, generator=g).to(d)
-    ents = [(torch.randn(B, 4096, 64, generator=g).to(torch.bfloat16).to(d), 6 - i) for i in range(NF)]
-    ptrs = [(torch.randn(B, 256, generator=g).to(d), i / 15.0) for i in range(NP)]
-    f2 = torch.randn(4096, 256, generator=g).to(d)
-    low = (torch.randn(B, 256, 256, generator=g) * 3).to(d)
-    obj = torch.randn(B, generator=g).to(d)
-
-    def run():
-        a = hm.bank_attention(B, curr, ents, ptrs).clone()
-        e = hm.memory_encoder(B, f2, low, obj, False).clone()
-        torch.cuda.synchronize()
-        return a, e
-
-    monkeypatch.delenv(switch, raising=False)
-    a0, e0 = run()
-    monkeypatch.setenv(switch, "0")
-    a1, e1 = run()
-    assert torch.equal(a0, a1), (switch, float((a0 - a1).abs().max()))
-    assert torch.equal(e0, e1), (switch, float((e0.float() - e1.float()).abs().max()))
-    assert float(a0.abs().max()) > 1.0

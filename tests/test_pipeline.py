@@ -1,6 +1,7 @@
 """F1: DetSAM2Pipeline hand-off contract (Det_SAM2_pipeline.py:59-78,183-214 of the reference) with a stub backbone -
 CPU only.  The GPU test (tests/test_hip_pipeline.py) runs the real VideoProcessor behind it."""
 import numpy as np
+import pytest
 
 from det_sam2_amd.Det_SAM2_pipeline import DetSAM2Pipeline
 from det_sam2_amd.det_sam2_RT import PackedMasks
@@ -85,3 +86,22 @@ def test_max_frames_and_preload_offset():
     pipe.inference(iter([None] * 100), max_frames=6, wait=True)             # stops after 6 stream frames (:157-159)
     assert vp.passes == 3 and pipe.has_processed_frames == list(range(6))  # consumer sees stream-relative indices (:188)
     assert min(pipe.delivery_log) == 7
+
+
+@pytest.mark.parametrize("which", ["small", "cut", "default"])
+def test_delivery_order_matches_the_reference_pipeline(golden_dir, which):
+    """The hand-off's ORDER against what the reference's own DetSAM2Pipeline.inference did (fixtures pipeline_*.npz recorded
+    by oracle/make_goldens.py `pipeline:<which>` from /root/reference/det_sam2_inference/Det_SAM2_pipeline.py): the queue's
+    enqueue order, the consumer's accepted deliveries and has_processed_frames.  The backbone here is the stub with the
+    fixture's buffer size; the masks themselves are compared on the GPU (tests/test_hip_pipeline.py)."""
+    import os
+    g = np.load(os.path.join(golden_dir, f"pipeline_{which}.npz"))
+    buf, detect, track, _ = (int(x) for x in g["vp_kwargs"])
+    assert track == 2 * buf and detect == buf
+    vp, rec = StubBackbone(buf=buf), Recorder()
+    pipe = DetSAM2Pipeline(video_processor=vp, post_processor=rec)
+    pipe.inference(iter([None] * int(g["n_frames"])), max_frames=int(g["max_frames"]), wait=True)
+    assert pipe.delivery_log == list(g["enqueued"])
+    assert [t for t, _ in rec.seen] == list(g["delivered"])
+    assert pipe.has_processed_frames == list(g["has_processed"])
+    assert sorted(pipe.video_segments) == list(g["left_in_pipeline"]) and sorted(vp.video_segments) == list(g["left_in_backbone"])

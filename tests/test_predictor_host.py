@@ -105,6 +105,14 @@ def test_run_from_a_frame_folder_equals_run_from_memory(tmp_path):
     assert VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(frame_dir=str(empty)) is None
     with pytest.raises(NotImplementedError, match="OpenCV"):
         VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw).run(video_path="x.mp4")
+    # a truncated file is skipped - at construction when the header check notices (PNG: chunk CRCs, no pixel decoded), else
+    # when the stream reaches it (JPEG) - and the remaining frames run as if it were not there
+    raw = (tmp_path / "00003.png").read_bytes()
+    (tmp_path / "00003.png").write_bytes(raw[: len(raw) // 2])
+    c = VideoProcessor(detector=SyntheticDetector(2, size=64), predictor=fake_predictor(), **kw)
+    assert len(c.load_frames_from_folder(str(tmp_path))) in (6, 7)
+    segs_c = c.run(frame_dir=str(tmp_path))
+    assert sorted(segs_c) == list(range(6))
 
 
 def test_remove_object_equals_never_having_added_it():

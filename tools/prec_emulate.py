@@ -148,6 +148,22 @@ def emu_linear(x, w, b=None):
         r = _bf16 if SCHEME == "mx_bf16" else _f16
         xh, wh = r(x), r(w)
         y = mm(_mx8(x - xh), _mx8(w)) + mm(_mx8(x), _mx8(w - wh)) + mm(xh, wh)
+    elif SCHEME in ("sx_f16", "sx_f16_t", "sx_f16_43"):
+        # round 6: fp16 hi.hi + two fp8 cross terms with STATIC power-of-two scales (no block maxima in the producers): the hi operand of a
+        # cross term is e5m2 = the fp16 plane's own top byte (rounded; `_t`: truncated, i.e. literally the byte; `_43`: e4m3 with the
+        # per-tensor scale of the lo plane's tensor), the lo operand e4m3 of (x - x_hi) * 2^S, S from the tensor's absmax
+        xh, wh = _f16(x), _f16(w)
+        def lo8(d, ref):
+            S = torch.floor(torch.log2(448.0 / (ref.abs().max().clamp_min(1e-30) * 2.0 ** -11)))       # lo <= 2^-11 |ref|
+            return (d * torch.exp2(S)).clamp(-448, 448).to(torch.float8_e4m3fn).float() * torch.exp2(-S)
+        def hi8(h):
+            if SCHEME == "sx_f16_t":
+                return (h.to(torch.float16).view(torch.int16) & -256).view(torch.float16).float()
+            if SCHEME == "sx_f16_43":
+                S = torch.floor(torch.log2(448.0 / h.abs().max().clamp_min(1e-30)))
+                return (h * torch.exp2(S)).to(torch.float8_e4m3fn).float() * torch.exp2(-S)
+            return h.clamp(-57344, 57344).to(torch.float8_e5m2).float()
+        y = mm(lo8(x - xh, x), hi8(wh)) + mm(hi8(xh), lo8(w - wh, w)) + mm(xh, wh)
     elif SCHEME in ("mx_f16_a", "mx_f16_w"):      # fp16 hi.hi + ONE MX-fp8 cross term (1.5 equivalents)
         xh, wh = _f16(x), _f16(w)
         y = (mm(_mx8(x - xh), _mx8(w)) if SCHEME == "mx_f16_a" else mm(_mx8(x), _mx8(w - wh))) + mm(xh, wh)
