@@ -420,10 +420,15 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
 #pragma clang fp contract(off)
           const float v0 = o[t][4 * k] * inv, v1 = o[t][4 * k + 1] * inv, v2 = o[t][4 * k + 2] * inv, v3 = o[t][4 * k + 3] * inv;
           uint2 hh, ll;
-          hh.x = cvt_pk_bf16(v0, v1);
-          hh.y = cvt_pk_bf16(v2, v3);
-          ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
-          ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+          if (a.o_mx) {   // "MX" activation planes (common.h)
+            ds2_mx_pair(v0, v1, false, hh.x, ll.x);
+            ds2_mx_pair(v2, v3, false, hh.y, ll.y);
+          } else {
+            hh.x = cvt_pk_bf16(v0, v1);
+            hh.y = cvt_pk_bf16(v2, v3);
+            ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
+            ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+          }
           *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + h * DV + dv) = hh;
           *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + h * DV + dv) = ll;
         }

@@ -137,6 +137,7 @@ struct HgArgs {
   unsigned short *o_hi, *o_lo; int ldop;
   int batch, heads, Lq, Lk;
   float scale;
+  int o_mx;
 };
 
 // DH = head dim (multiple of 8), DQ = DH rounded up to 32 (score k-steps), DVP = DH rounded up to 16 (output row blocks)
@@ -401,10 +402,15 @@ __global__ __launch_bounds__(512, 2) void k_attention_hg(HgArgs a) {
       const float v0 = o[g][t][0] * inv, v1 = o[g][t][1] * inv, v2 = o[g][t][2] * inv, v3 = o[g][t][3] * inv;
       if (a.o_hi) {
         uint2 hh, ll;
-        hh.x = cvt_pk_bf16(v0, v1);
-        hh.y = cvt_pk_bf16(v2, v3);
-        ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
-        ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+        if (a.o_mx) {   // "MX" activation planes (common.h)
+          ds2_mx_pair(v0, v1, false, hh.x, ll.x);
+          ds2_mx_pair(v2, v3, false, hh.y, ll.y);
+        } else {
+          hh.x = cvt_pk_bf16(v0, v1);
+          hh.y = cvt_pk_bf16(v2, v3);
+          ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
+          ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+        }
         *reinterpret_cast<uint2*>(a.o_hi + orow * a.ldop + h * DH + dv) = hh;
         *reinterpret_cast<uint2*>(a.o_lo + orow * a.ldop + h * DH + dv) = ll;
       } else {
@@ -426,7 +432,7 @@ int launch_t(const AttnArgs& a, void* k_hi, void* vt, hipStream_t st) {
                      reinterpret_cast<unsigned short*>(vt));
   DS2_CHECK_LAUNCH();
   HgArgs g{a.q, a.ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(vt),
-           a.o, a.ldo, a.o_hi, a.o_lo, a.ldop, a.batch, a.heads, a.Lq, a.Lk, a.scale};
+           a.o, a.ldo, a.o_hi, a.o_lo, a.ldop, a.batch, a.heads, a.Lq, a.Lk, a.scale, a.o_mx};
   hipLaunchKernelGGL((k_attention_hg<DH, DQ, DVP>), dim3(a.batch * a.heads * (a.Lq / 256)), dim3(512), 0, st, g);
   DS2_CHECK_LAUNCH();
   return DS2_OK;

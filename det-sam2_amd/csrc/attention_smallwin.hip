@@ -184,10 +184,15 @@ __global__ __launch_bounds__(256) void k_attn_smallwin(AttnArgs a, int n_items, 
       const float v0 = o[d][4 * g4] * inv, v1 = o[d][4 * g4 + 1] * inv, v2 = o[d][4 * g4 + 2] * inv, v3 = o[d][4 * g4 + 3] * inv;
       if (a.o_hi) {
         uint2 hh, ll;
-        hh.x = cvt_pk_bf16(v0, v1);
-        hh.y = cvt_pk_bf16(v2, v3);
-        ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
-        ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+        if (a.o_mx) {   // "MX" activation planes (common.h)
+          ds2_mx_pair(v0, v1, false, hh.x, ll.x);
+          ds2_mx_pair(v2, v3, false, hh.y, ll.y);
+        } else {
+          hh.x = cvt_pk_bf16(v0, v1);
+          hh.y = cvt_pk_bf16(v2, v3);
+          ll.x = cvt_pk_bf16(v0 - bf_lo(hh.x), v1 - bf_hi(hh.x));
+          ll.y = cvt_pk_bf16(v2 - bf_lo(hh.y), v3 - bf_hi(hh.y));
+        }
         *reinterpret_cast<uint2*>(a.o_hi + qrow * a.ldop + h * D + dv) = hh;
         *reinterpret_cast<uint2*>(a.o_lo + qrow * a.ldop + h * D + dv) = ll;
       } else {

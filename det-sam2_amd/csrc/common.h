@@ -65,6 +65,50 @@ __device__ __forceinline__ int mfma32_row(int r, int h) { return (r & 3) + 8 * (
 // checkpoint must degrade a product, not turn the frame into NaNs (bf16 planes have fp32's range and need nothing)
 __device__ __forceinline__ float ds2_sat_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 
+// ---- "MX" operand planes of the two-MFMA-equivalent product (round 6; gemm_x4g.hip, tools/gen/gen_gemm_x4g.py "23m"):
+//   a w ~= a16 w16  +  a8 wl8  +  al8 w8     a16 = fp16(a), w16 = fp16(w): v_mfma_f32_32x32x16_f16 (full rate)
+//                                            both cross terms of 32 k's in ONE v_mfma_scale_f32_32x32x64_f8f6f4 (twice the rate):
+//   plane 1 of an operand = fp16 [rows, ld]; plane 2 = one 16-bit word per element, same shape and addressing:
+//     activation:  byte 0 = e4m3(a 2^-EA)                byte 1 = e4m3((a - a16) 2^LA)
+//     weight:      byte 0 = e4m3((w - w16) 2^LW)         byte 1 = e4m3(w 2^-EW)
+//   so that the byte pairs of an A row and a W row multiply to a8 wl8 + al8 w8, both with the factor 2^(EA - LW) = 2^(EW - LA)
+//   (EA + LA = EW + LW), which the instruction's E8M0 scale operand applies.  The scales are STATIC powers of two - no block maxima
+//   in any producer: a value outside e4m3's range saturates (|a| > 448 2^EA = 112, |a - a16| > 448 2^-LA, i.e. |a| > ~56; |w| > 7 resp.
+//   3.5), which degrades THAT element's cross term to the plain fp16 product's error, and a value below the subnormal step loses
+//   a term that is below 2^-21 of the row's largest product.  OCP e4m3 (v_cvt_pk_fp8_f32 on gfx950), round to nearest even.
+#define DS2_MX_EA (-2)
+#define DS2_MX_LA 14
+#define DS2_MX_EW (-6)
+#define DS2_MX_LW 18
+static_assert(DS2_MX_EA + DS2_MX_LA == DS2_MX_EW + DS2_MX_LW, "both cross terms must carry the same power of two");
+enum { DS2_PLANES_BF16 = 0, DS2_PLANES_MX_A = 1, DS2_PLANES_MX_W = 2 };   // format of an operand-plane pair
+#ifdef __HIPCC__
+// (x0, x1) -> low / high half of the plane-2 word pair; e = exponent of the value byte's scale, l = of the remainder byte's
+__device__ __forceinline__ unsigned ds2_mx_word2(float x0, float r0, float x1, float r1, bool weight) {
+  const float sv = weight ? __builtin_ldexpf(1.f, -DS2_MX_EW) : __builtin_ldexpf(1.f, -DS2_MX_EA);
+  const float sr = weight ? __builtin_ldexpf(1.f, DS2_MX_LW) : __builtin_ldexpf(1.f, DS2_MX_LA);
+  const float v0 = __builtin_amdgcn_fmed3f(x0 * sv, -448.f, 448.f), v1 = __builtin_amdgcn_fmed3f(x1 * sv, -448.f, 448.f);
+  const float q0 = __builtin_amdgcn_fmed3f(r0 * sr, -448.f, 448.f), q1 = __builtin_amdgcn_fmed3f(r1 * sr, -448.f, 448.f);
+  int w = 0;
+  if (weight) {   // remainder byte first
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(q0, v0, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(q1, v1, w, true);
+  } else {
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v0, q0, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v1, q1, w, true);
+  }
+  return (unsigned)w;
+}
+// two adjacent values -> their plane-1 word (fp16 pair, saturating) and plane-2 word
+__device__ __forceinline__ void ds2_mx_pair(float x0, float x1, bool weight, unsigned& p1, unsigned& p2) {
+  typedef _Float16 mxh2 __attribute__((ext_vector_type(2)));
+  typedef float mxf2 __attribute__((ext_vector_type(2)));
+  const mxh2 h = __builtin_convertvector((mxf2{__builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f)}), mxh2);
+  p1 = __builtin_bit_cast(unsigned, h);
+  p2 = ds2_mx_word2(x0, x0 - (float)h[0], x1, x1 - (float)h[1], weight);
+}
+#endif
+
 // ---- epilogue / activation codes shared by GEMM and LayerNorm
 enum { DS2_ACT_NONE = 0, DS2_ACT_RELU = 1, DS2_ACT_GELU = 2, DS2_ACT_SIGMOID = 3 };
 
@@ -166,6 +210,7 @@ struct AttnArgs {
   // bf16x3 kernels only: if set, the result is written as two bf16 planes [rows, ldop] (GEMM operand format)
   // instead of fp32 `o`
   unsigned short *o_hi, *o_lo; int ldop;
+  int o_mx;                     // the planes are "MX" activation planes (fp16 + fp8 byte pairs, see above) for an MX GEMM consumer
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);         // dispatches on ds2_precision()
 bool attention_fewq_supported(const AttnArgs& a);                // Lq <= 16 against >= 1024 keys, head dim 16/32

@@ -70,6 +70,35 @@ __global__ void k_split_rows_f16(const float* x, int ldx, int rows, int cols, ui
   lo[i] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 
+// the same with the "MX" planes of the two-MFMA-equivalent product (common.h): WEIGHT selects the byte order of plane 2
+template <bool WEIGHT>
+__global__ void k_split_rows_mx(const float* x, int ldx, int rows, int cols, uint2* hi, uint2* lo, int ldp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = ldp / 4;
+  if (i >= (size_t)rows * q) return;
+  const int c4 = (int)(i % q);
+  const size_t r = i / q;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 * 4 < cols) v = *reinterpret_cast<const float4*>(x + r * ldx + c4 * 4);
+  uint2 h, l;
+  ds2_mx_pair(v.x, v.y, WEIGHT, h.x, l.x);
+  ds2_mx_pair(v.z, v.w, WEIGHT, h.y, l.y);
+  hi[i] = h;
+  lo[i] = l;
+}
+// bf16 hi / lo planes (a = hi + lo to 2^-17) -> MX activation planes of the same shape (the operand of an MX GEMM whose producer
+// emitted bf16 planes)
+__global__ void k_planes_bf16_to_mx(const uint2* hi, const uint2* lo, uint2* p1, uint2* p2, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint2 h = hi[i], l = lo[i];
+  uint2 a, b;
+  ds2_mx_pair(bf_lo(h.x) + bf_lo(l.x), bf_hi(h.x) + bf_hi(l.x), false, a.x, b.x);
+  ds2_mx_pair(bf_lo(h.y) + bf_lo(l.y), bf_hi(h.y) + bf_hi(l.y), false, a.y, b.y);
+  p1[i] = a;
+  p2[i] = b;
+}
+
 template <int DBG>
 __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, int nt) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][2][PLANE];   // [buf][A/B][hi/lo]
@@ -326,11 +355,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
 
 }  // namespace
 
-int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st, bool f16) {
+int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st, bool f16, int mx) {
   DS2_REQUIRE(ldp % 32 == 0 && ldx % 4 == 0 && cols % 4 == 0, "split_rows: ldp must be a multiple of 32, ldx/cols of 4");
   const size_t n = (size_t)rows * (ldp / 4);
-  hipLaunchKernelGGL(f16 ? k_split_rows_f16 : k_split_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, rows, cols,
+  auto kern = mx == DS2_PLANES_MX_A ? k_split_rows_mx<false> : mx == DS2_PLANES_MX_W ? k_split_rows_mx<true> : f16 ? k_split_rows_f16 : k_split_rows;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ldx, rows, cols,
                      reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), ldp);
+  DS2_CHECK_LAUNCH();
+  return DS2_OK;
+}
+int launch_planes_bf16_to_mx(const void* hi, const void* lo, void* p1, void* p2, size_t elems, hipStream_t st) {
+  DS2_REQUIRE(elems % 4 == 0, "planes_bf16_to_mx: element count must be a multiple of 4");
+  const size_t n = elems / 4;
+  hipLaunchKernelGGL(k_planes_bf16_to_mx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint2*>(hi),
+                     reinterpret_cast<const uint2*>(lo), reinterpret_cast<uint2*>(p1), reinterpret_cast<uint2*>(p2), n);
   DS2_CHECK_LAUNCH();
   return DS2_OK;
 }
@@ -421,6 +459,23 @@ int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st) {
               "gemm_split: bad dims M=%d N=%d Kp=%d lda=%d ldw=%d", g.M, g.N, g.Kp, g.lda, g.ldw);
   DS2_REQUIRE(g.C || g.C_hi, "gemm_split: no output");
   DS2_REQUIRE(!g.C_hi || (g.ldcp % 2 == 0), "gemm_split: ldcp must be even");
+  if (g.mx) {   // MX planes: the assembly kernel's 128 x 192 configuration is the only consumer of that format
+    DS2_REQUIRE(gemm_split_x4g_config(g, 23) == 23, "gemm_split: no MX kernel for M=%d N=%d Kp=%d (needs M %% 128 == 0, N %% 192 == 0, Kp %% 64 == 0, Kp >= 576)",
+                g.M, g.N, g.Kp);
+    GemmSplitArgs gm = g;
+    gm.group_m = cdiv(g.N, 128) >= 8 ? 8 : 0;          // (the tile order of the bf16 form, launch_tile_impl)
+    if (!ds2_prof_kernels()) { const char* k; return launch_gemm_split_x4g(gm, 23, st, &k); }
+    const char* k = "?";
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return launch_gemm_split_x4g(gm, 23, st, &k);
+    (void)hipEventRecord(a, st);
+    const int rc = launch_gemm_split_x4g(gm, 23, st, &k);
+    (void)hipEventRecord(b, st);
+    char tag[96];
+    snprintf(tag, sizeof(tag), "kern %s %d %d %d", k, g.M, g.N, g.Kp);
+    ds2_prof_record(tag, a, b);
+    return rc;
+  }
   const char* tile_e = getenv("DS2_GEMM_TILE");   // (read per call: the tests force tiles in one process)
   const int tile_env = tile_e ? atoi(tile_e) : 0;
   if (g.c_hi_f16) {   // fp16 key planes (mode bf16x3k): the K = 64 streaming kernel's epilogue is the one that writes them

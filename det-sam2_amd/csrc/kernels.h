@@ -139,6 +139,10 @@ struct GemmSplitArgs {
   // C_hi is written as IEEE fp16 (11 significant bits) instead of bf16: the single-plane keys of the memory attention in
   // mode bf16x3k (attention_w8.hip).  Honoured by the K = 64 streaming kernel only (launch_gemm_split checks).
   int c_hi_f16;
+  // the operand planes are "MX" planes (common.h: fp16 + fp8 byte pairs) and the product is the two-MFMA-equivalent one: taken by
+  // the assembly kernel's 128 x 192 configuration only (gemm_x4g.hip "23m"; launch_gemm_split checks).  c_mx: the result planes
+  // (C_hi / C_lo) are written as MX ACTIVATION planes for an MX consumer.
+  int mx, c_mx;
 };
 int launch_gemm_split(const GemmSplitArgs& g, hipStream_t st);
 int launch_gemm_split_r3(const GemmSplitArgs& g, hipStream_t st);           // 256x128 blocks, 8 waves, 3-stage LDS-DMA ring
@@ -152,7 +156,8 @@ int launch_gemm_split_x4g(const GemmSplitArgs& g, int cfg, hipStream_t st, const
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel
 int launch_split_rows(const float* x, int ldx, int rows, int cols, void* hi, void* lo, int ldp, hipStream_t st,
-                      bool f16 = false);   // f16: IEEE fp16 planes instead of bf16
+                      bool f16 = false, int mx = 0);   // f16: IEEE fp16 planes instead of bf16; mx = DS2_PLANES_MX_A / _W: common.h
+int launch_planes_bf16_to_mx(const void* hi, const void* lo, void* p1, void* p2, size_t elems, hipStream_t st);
 // gemm_skinny.hip: fp32 linear layer for M <= 128 rows over the transposed weight Wt[K,N]
 struct SkinnyArgs {
   int M, N, K;
@@ -244,6 +249,6 @@ int launch_layernorm_add_split(const float* x, int ldx, const float* w, const fl
 int launch_sam_keys_init(const float* src, int src_mod, const float* vec, const float* pe, int pe_mod, float* keys, void* khi,
                          void* klo, void* phi, void* plo, int rows, hipStream_t st);
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
-                           int C, float eps, int act, hipStream_t st);
+                           int C, float eps, int act, hipStream_t st, int mx = 0);
 int launch_add_bcast_split(const float* a, int lda, const float* b, int ldb, int b_mod, float alpha, void* hi, void* lo,
                            int ldp, int rows, int C, hipStream_t st);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
                                                        uint2* __restrict__ hi, uint2* __restrict__ lo, int ldp, int rows, int C,
                                                        float eps, int act, const float* __restrict__ add = nullptr,
                                                        float* __restrict__ y2 = nullptr, int add_mod = 0,
-                                                       uint2* __restrict__ hi0 = nullptr, uint2* __restrict__ lo0 = nullptr) {
+                                                       uint2* __restrict__ hi0 = nullptr, uint2* __restrict__ lo0 = nullptr, int mx = 0) {
   // add (row stride ldy, row index modulo add_mod when > 0): a second result y + add - as fp32 y2 (!SPLIT: the "queries +
   // query_pe" of the two-way transformer) or as THE operand planes (SPLIT: "keys + key_pe"; y, when given, still gets LN(x))
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -159,10 +159,15 @@ __global__ __launch_bounds__(256) void k_layernorm_vec(const float* __restrict__
       }
       if (c < ldp) {   // columns C..ldp are zero in both planes
         uint2 h, l;
+        if (mx) {      // "MX" activation planes (common.h) for a consumer that multiplies in the two-MFMA-equivalent form
+          ds2_mx_pair(o.x, o.y, false, h.x, l.x);
+          ds2_mx_pair(o.z, o.w, false, h.y, l.y);
+        } else {
         h.x = ln_cvt_pk_bf16(o.x, o.y);
         h.y = ln_cvt_pk_bf16(o.z, o.w);
         l.x = ln_cvt_pk_bf16(o.x - __uint_as_float(h.x << 16), o.y - __uint_as_float(h.x & 0xffff0000u));
         l.y = ln_cvt_pk_bf16(o.z - __uint_as_float(h.y << 16), o.w - __uint_as_float(h.y & 0xffff0000u));
+        }
         hi[(size_t)row * (ldp / 4) + (c >> 2)] = h;
         lo[(size_t)row * (ldp / 4) + (c >> 2)] = l;
       }
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void k_layernorm_c64(const float* __restrict__
 template <bool SPLIT>
 static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, void* hi, void* lo,
                                  int ldp, int rows, int C, float eps, int act, hipStream_t st, const float* add = nullptr,
-                                 float* y2 = nullptr, int add_mod = 0, void* hi0 = nullptr, void* lo0 = nullptr) {
+                                 float* y2 = nullptr, int add_mod = 0, void* hi0 = nullptr, void* lo0 = nullptr, int mx = 0) {
   const int width = SPLIT ? ldp : C;
   const bool ok = C % 4 == 0 && ldx % 4 == 0 && ((SPLIT && !y && !add) || ldy % 4 == 0) && width <= 5 * 256 &&
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
@@ -225,7 +230,7 @@ static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const 
   uint2* h2 = reinterpret_cast<uint2*>(hi);
   uint2* l2 = reinterpret_cast<uint2*>(lo);
 #define DS2_LN_CASE(N) \
-  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act, add, y2, add_mod, reinterpret_cast<uint2*>(hi0), reinterpret_cast<uint2*>(lo0)); break;
+  case N: hipLaunchKernelGGL((k_layernorm_vec<N, SPLIT>), grid, blk, 0, st, x, ldx, w, b, y, ldy, h2, l2, ldp, rows, C, eps, act, add, y2, add_mod, reinterpret_cast<uint2*>(hi0), reinterpret_cast<uint2*>(lo0), mx); break;
   switch (nv) {
     DS2_LN_CASE(1) DS2_LN_CASE(2) DS2_LN_CASE(3) DS2_LN_CASE(4) DS2_LN_CASE(5)
     default: return false;
@@ -1232,12 +1237,13 @@ int launch_sam_keys_init(const float* src, int src_mod, const float* vec, const 
   return DS2_OK;
 }
 int launch_layernorm_split(const float* x, int ldx, const float* w, const float* b, void* hi, void* lo, int ldp, int rows,
-                           int C, float eps, int act, hipStream_t st) {
+                           int C, float eps, int act, hipStream_t st, int mx) {
   DS2_REQUIRE(rows > 0 && C > 0 && ldp % 32 == 0 && ldp >= C, "layernorm_split: bad dims");
-  if (launch_layernorm_vec<true>(x, ldx, w, b, nullptr, 0, hi, lo, ldp, rows, C, eps, act, st)) {
+  if (launch_layernorm_vec<true>(x, ldx, w, b, nullptr, 0, hi, lo, ldp, rows, C, eps, act, st, nullptr, nullptr, 0, nullptr, nullptr, mx)) {
     DS2_CHECK_LAUNCH();
     return DS2_OK;
   }
+  DS2_REQUIRE(!mx, "layernorm_split: MX planes need the vectorised kernel (C %% 4 == 0, 16-byte aligned operands, width <= 1280)");
   hipLaunchKernelGGL(k_layernorm_split, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, ldx, w, b, reinterpret_cast<unsigned*>(hi),
                      reinterpret_cast<unsigned*>(lo), ldp, rows, C, eps, act);
   DS2_CHECK_LAUNCH();

