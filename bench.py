@@ -37,8 +37,10 @@ PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16x3k": 2500.0}
 DTYPE = {"fp32": "f32",
          "bf16x3": "bf16x3 (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product, fp32 accumulate/softmax/storage)",
          "bf16x3k": "bf16x3k (fp32 operands split into 2 bf16 planes, 3 bf16 MFMAs per product; in the memory attention the q / k / "
-                    "softmax-weight / value operands are ONE fp16 plane each, and the fused MLPs of the memory attention and memory "
-                    "encoder use 2 fp16 MFMAs per product (activations one fp16 plane, weights two); fp32 accumulate/softmax/storage)"}
+                    "softmax-weight / value operands are ONE fp16 plane each, the fused MLPs of the memory attention and memory "
+                    "encoder use 2 fp16 MFMAs per product (activations one fp16 plane, weights two), and the Linear layers of Hiera stages "
+                    "3 / 4 at widths that are multiples of 192 (hiera_l) use the two-MFMA-equivalent 'MX' product - fp16 hi.hi + both cross "
+                    "terms in scaled fp8 MFMAs (e4m3, static power-of-two scales); fp32 accumulate/softmax/storage)"}
 
 
 def cross_attention_flops(B, Nk, tokens=4096, d=256, dv=64):
@@ -63,7 +65,7 @@ def committed_pmc_traffic(kernel_key, B, nk, precision):
     source file).  None if no committed file matches this workload."""
     if B != 16 or nk != 28736 or precision != "bf16x3k":
         return None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_cross_attention.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -169,7 +171,7 @@ def cross_kernel_name(precision):
     if precision == "fp32":
         return "k_attention<256,64>"
     if precision == "bf16x3k" and os.environ.get("DS2_ATTN_X4A", "1") != "0":
-        return "k_attention_x4a + k_x4a_qprep + k_w8_merge<64>"
+        return "k_attention_x4a"
     return "k_attention_w8<64,2>"
 
 
@@ -569,17 +571,16 @@ def main():
                  "traffic": None, "traffic_from_committed_pmc": committed_pmc_traffic("cross_attention", B, nk, a.precision),
                  "algorithmic_bytes": cross_attention_bytes(B, nk, precision=a.precision),
                  "algorithmic_bytes_definition": "ONE definition for the launch: the one-kernel form - Q fp32 + K plane + V^T planes read once, "
-                                                 "output planes written once.  The launch's three kernels move more (Q re-written as fp16 "
-                                                 "fragments and read again, unnormalised O + (max, sum) written and re-read: 1.27 x, "
-                                                 "profiles/r04_pmc_traffic.json); traffic_from_committed_pmc is the main kernel alone",
+                                                 "output planes written once; traffic_from_committed_pmc is k_attention_x4a's own (Q as fp16 "
+                                                 "fragments + K plane + V^T planes in, unnormalised rows + (max, sum) out)",
                  "avg_launch_ms": ca_ms / max(ca_n, 1), "launches": ca_n,
                  "peak_sustained_measured": SUSTAINED_MFMA_TFLOPS,
                  "frac_of_sustained": None if achieved is None else achieved / SUSTAINED_MFMA_TFLOPS,
                  "sustained_note": "the fully loaded chip is POWER-limited: this kernel's own MFMA stream (real operands, nothing else) runs "
                                    "at 1.67 PFLOP/s on 256 CUs and at the nominal 2.5 on 128 (profiles/r04_mfma_power_calibration.txt); "
                                    "`peak` stays the guide's dense figure",
-                 "note": "(mode bf16x3k: one 'launch' = k_x4a_qprep + k_attention_x4a + k_w8_merge<64>, ~28 + 980 + 7 us at the full bank - the "
-                         "rocprofv3 rows of the three kernels add up to avg_launch_ms) "
+                 "note": "(mode bf16x3k, 16 objects: one 'launch' = k_attention_x4a alone - its query pass is the epilogue of k_qproj_x4a, its "
+                         "normalisation / merge the prologue of k_vo_merge since round 5; with a key split (few objects) the parts are merged there too) "
                          "achieved = algorithmic FLOPs 2*B*4096*Nk*(256+64) per launch / mean HIP-event launch time INSIDE the timed "
                          "region (with async_encode the next encoder batch shares the CUs for ~60 % of it: reads ~5 % longer than the "
                          "kernel alone, which `by_kernel` below gives); executed MFMA FLOPs per algorithmic FLOP: bf16x3 3.0 "

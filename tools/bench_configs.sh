@@ -1,8 +1,8 @@
 #!/bin/bash
 # `bench.py` at the other model sizes / object counts of BASELINE.json's configs (run on the GPU box: bash tools/bench_configs.sh);
-# one line per configuration into gpurun_out/r05_bench_configs.txt.  40 timed steps, stream leg of 120 frames, no CPU baseline.
+# one line per configuration into gpurun_out/r06_bench_configs.txt.  40 timed steps, stream leg of 120 frames, no CPU baseline.
 R=${GRAFT_REPO_ROOT:-.}
-OUT=$R/gpurun_out/r05_bench_configs.txt
+OUT=$R/gpurun_out/r06_bench_configs.txt
 echo "# python bench.py --model M --objects B --steps 40 --warmup 3 --no-cpu-baseline --stream-frames 120 (one MI355X, bf16x3k)" > $OUT
 for cfg in "sam2.1_hiera_t 4" "sam2.1_hiera_t 16" "sam2.1_hiera_s 16" "sam2.1_hiera_b+ 16" "sam2.1_hiera_l 4" "sam2.1_hiera_l 8" "sam2.1_hiera_l 16"; do
   set -- $cfg

@@ -63,6 +63,7 @@ STMOD = (" " + _stmod) if _stmod and _stmod != "none" else ""      # cache polic
 STDEFER = os.environ.get("X4G_STDEFER", "0") == "1"
 GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
 GAP8 = int(os.environ.get("X4G_GAP8", 56))    # ... behind one v_mfma_scale_f32_32x32x64_f8f6f4 (16 passes = 64 cycles)
+RD_EARLY = int(os.environ.get("X4G_RD_EARLY", 0))   # MX: the last LDS read of a stage is issued this many MFMA slots before its barrier
 assert not MX or (KSUB == 2 and CFG == "23m"), "the MX form exists for the 128 x 192 tile with 64-deep K tiles"
 
 # VGPR map (v0..v31 are left to the compiler)
@@ -809,7 +810,8 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
         spent = 0
         if q + 1 < NQ and rq[q + 1]:
             # (MX: a sub-step has NB slots for MBW + NBW reads of the next sub-step and its share of the plane-2 reads)
-            for _ in range(2 if (MX and len(rq[q + 1]) > NB - 1 - si % NB) else 1):
+            early = RD_EARLY if (MX and q + 1 == NQ - 1) else 0      # (the sub-step in front of the barrier)
+            for _ in range(2 if (MX and len(rq[q + 1]) > NB - 1 - early - si % NB) else 1):
                 if rq[q + 1]:
                     k, i = rq[q + 1].pop(0)
                     nset, npre = (FY, "Y") if (q + 1) % 2 else (FX, "X")
@@ -818,7 +820,7 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
                     lg.issue(f"{npre}{k}{i}")
                     spent += ISSUE
         if r8 and si < BAR_SLOT:
-            left = BAR_SLOT - si                       # slots up to the barrier, this one included
+            left = max(BAR_SLOT - RD_EARLY - si, 1)    # slots up to the barrier (less RD_EARLY), this one included
             for _ in range((len(r8) + left - 1) // left):
                 k, i, qp = r8.pop(0)
                 if "noread" not in FLAGS:

@@ -24,6 +24,11 @@ KERNELS = {   # key -> (name pattern, algorithmic bytes per launch)
     "k_gemm_x4g_23_e3": ("%k_gemm_x4g_23_e3%", 65536.0 * 2304 * 4 + 576.0 * 2304 * 4 + 2 * 65536.0 * 576 * 4),
     # mlp.layers.0 (65536 x 2304 x 576, GELU): A planes + W planes in, result planes out
     "k_gemm_x4g_23_e2": ("%k_gemm_x4g_23_e2%", 65536.0 * 576 * 4 + 2304.0 * 576 * 4 + 65536.0 * 2304 * 4),
+    # round 6, the MX form of the same layers (same plane bytes: fp16 + 2 x fp8 per element) and of attn.qkv (65536 x 1728 x 576: A planes +
+    # W planes in, fp32 result out)
+    "k_gemm_x4gm_23_e3": ("%k_gemm_x4gm_23_e3%", 65536.0 * 2304 * 4 + 576.0 * 2304 * 4 + 2 * 65536.0 * 576 * 4),
+    "k_gemm_x4gm_23_e2": ("%k_gemm_x4gm_23_e2%", 65536.0 * 576 * 4 + 2304.0 * 576 * 4 + 65536.0 * 2304 * 4),
+    "k_gemm_x4gm_23_e1": ("%k_gemm_x4gm_23_e1%", 65536.0 * 576 * 4 + 1728.0 * 576 * 4 + 65536.0 * 1728 * 4),
     # (round 5, LayerNorm inside: the un-normalised fp32 rows in - they are the residual as well, read twice -, result out, LN(result) planes out)
     "k_mlp256": ("%k_mlp256<1%", B * TOK * 256 * (4.0 + 4.0 + 4.0 + 4.0) + 2 * 2048 * 256 * 4.0),
     # round 5, fused kernels of a memory-attention layer (16 objects): planes in / fp32 q + fp16 k plane + V^T hi plane out; fp32 rows in /
