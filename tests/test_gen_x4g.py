@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("cfg", ["42", "23"])
+@pytest.mark.parametrize("cfg", ["42", "23", "23m"])      # 23m: the MX form of the 128 x 192 tile (round 6)
 @pytest.mark.parametrize("epi", ["e1", "e2", "e3"])
 def test_committed_body_is_the_generators_output(tmp_path, cfg, epi):
     out = tmp_path / "body.inc"
@@ -18,6 +18,20 @@ def test_committed_body_is_the_generators_output(tmp_path, cfg, epi):
                    capture_output=True)
     committed = open(os.path.join(ROOT, "det-sam2_amd", "csrc", f"gemm_x4g_body_{cfg}_{epi}.inc")).read()
     assert out.read_text() == committed
+    if cfg == "23m":     # per K tile and wave: 6 blocks x (4 fp16 sub-steps + 2 scaled fp8 MFMAs); 8 drain bodies + plain + last
+        assert committed.count("v_mfma_f32_32x32x16_f16") == 240 and committed.count("v_mfma_scale_f32_32x32x64_f8f6f4") == 120
+        assert ("v_cvt_scalef32_pk_fp8_f32" in committed) == (epi == "e2")        # only the GELU form writes MX planes
+        assert ("hwreg(HW_REG_MODE, 23, 1), 1" in committed) == (epi == "e2")     # ... with saturating conversions
+
+
+def test_mx_scale_constants_agree():
+    """the generator's static scales (tools/gen/gen_gemm_x4g.py MX_*) are those of the producers (csrc/common.h DS2_MX_*)"""
+    import re
+    gen = open(os.path.join(ROOT, "tools", "gen", "gen_gemm_x4g.py")).read()
+    m = re.search(r"MX_EA, MX_LA, MX_EW, MX_LW = (-?\d+), (-?\d+), (-?\d+), (-?\d+)", gen)
+    hdr = open(os.path.join(ROOT, "det-sam2_amd", "csrc", "common.h")).read()
+    want = tuple(int(re.search(rf"#define DS2_MX_{k} \(?(-?\d+)\)?", hdr).group(1)) for k in ("EA", "LA", "EW", "LW"))
+    assert tuple(int(x) for x in m.groups()) == want and want[0] + want[1] == want[2] + want[3]
 
 
 def test_committed_gelu_mlp_loop_is_the_generators_output(tmp_path):

@@ -19,9 +19,10 @@ from det_sam2_amd.weights import synthetic_state_dict
 
 pytestmark = pytest.mark.gpu
 LARGE, BPLUS = "sam2.1_hiera_l", "sam2.1_hiera_b+"
-# max |dlogit| per fixture and mode: 2 x the value measured on MI355X in round 5 (profiles/r05_final_metrics.jsonl; the kernels are
-# deterministic) - VERDICT r4 weak #1(b): the relative bound of 4e-3 x |logit|max used before was 19 - 80 x the measured values
-DLOGIT_TOL = {("large", "seed0"): 3.1e-3, ("large", "s1"): 3.2e-3, ("large", "lm"): 1e-4, ("large", "s2"): 4.1e-3,
+# max |dlogit| per fixture and mode: 2 x the value measured on MI355X (the kernels are deterministic) - hiera_l re-measured in round 6
+# with the MX product in Hiera stages 3 / 4 (profiles/r06_final_metrics.jsonl: 1.0e-3 / 1.5e-3 in mode bf16x3, 1.7e-3, 5.2e-5, 3.3e-3),
+# hiera_b+ as in round 5 (no MX layer at its widths)
+DLOGIT_TOL = {("large", "seed0"): 3.0e-3, ("large", "s1"): 3.4e-3, ("large", "lm"): 1.1e-4, ("large", "s2"): 6.6e-3,
               ("bplus", "seed0"): 7.7e-3, ("bplus", "seed0", "fp32"): 8e-4, ("bplus", "s1"): 4.1e-3, ("bplus", "s2"): 1.5e-2}
 
 

@@ -23,7 +23,18 @@ the workgroup's last tile, not overlapped).  Every wait is COUNTED: vmcnt by sim
 residual / bias loads), lgkmcnt by simulating the LDS stream.  `lint()` checks the manual hazards (trans -> use, VALU vcc / SGPR ->
 mask, DPP source, m0 -> LDS-DMA, readfirstlane -> SALU).
 
-usage: gen_gemm_x4g.py <out.inc> <cfg: 42|23> <epi: e1|e2|e3> [flags: nodrain nostore nodma ...]  (flags: timing experiments only)
+MX form (cfg "23m", round 6; det-sam2_amd/csrc/common.h "MX" operand planes): the two-MFMA-equivalent product a w ~= a16 w16 + a8 wl8 + al8 w8.
+Plane 1 of an operand is fp16, plane 2 one 16-bit word per element (value byte | remainder byte, swapped for weights) with plane 1's
+layout, so DMA, LDS image, swizzle and the four chunk addresses of a K tile are those of the bf16 form.  Per K tile (64 deep) and
+32 x 32 block: four v_mfma_f32_32x32x16_f16 (one per 16-deep sub-step, fragment sets X / Y alternate) and TWO
+v_mfma_scale_f32_32x32x64_f8f6f4 whose 8-register operands are the plane-2 chunk pairs (q' = 0, 1) and (2, 3) - each instruction is both
+cross terms of 32 k's, scaled by the E8M0 byte 127 + EA - LW on the A side (static scales; the K order inside a tile is free because
+every block carries the same scale; operand layout and scale semantics measured by tools/ubench/mx_*.hip).  Body: fp16 sub-steps 0..2
+(behind them: the fp16 fragments of the next sub-step AND the 20 plane-2 reads of THIS tile), barrier, sub-step 3, the 12 fp8 MFMAs
+(64 cycles each: the DMA block of K tile t+2 and the drain fillers are paced under them).  e2 writes MX ACTIVATION planes
+(v_cvt_pk_f16_f32, v_cvt_scalef32_pk_fp8_f32 x 2, v_perm_b32 under MODE.FP16_OVFL = saturating conversions).
+
+usage: gen_gemm_x4g.py <out.inc> <cfg: 42|23|23m> <epi: e1|e2|e3> [flags: nodrain nostore nodma ...]  (flags: timing experiments only)
 """
 import os
 import sys
