@@ -301,14 +301,14 @@ def test_classes_match_reference(golden_dir, prec):
     assert worst <= 1e-3 and worst_logit <= (5e-3 if prec == "fp32" else 5e-2), (worst, worst_logit)
 
 
-def test_three_pass_stream_matches_oracle():
+def test_three_pass_stream_matches_oracle(golden_dir):
     """Error accumulation through the memory bank: 12 frames, 3 overlapping reverse passes with eviction, 3 objects (one
-    appearing in the second pass), default bf16x3k arithmetic, against the oracle run alongside (about 1.5 minutes of
-    host time; the 16-frame / 4-pass version of this test measured 1 - IoU = 4.2e-5).  Every final mask within
+    appearing in the second pass), default bf16x3k arithmetic, against the ORACLE's run of the same stream - its masks are the
+    committed fixture oracle_three_pass.npz (oracle/make_oracle_fixtures.py three_pass; the run takes 1.5 minutes of host time, which
+    this test spent on the GPU box until round 6; DS2_SLOW_ORACLE=1 runs the oracle alongside instead).  Every final mask within
     1 - IoU <= 1e-3."""
     from det_sam2_amd.det_sam2_RT import VideoProcessor
     from det_sam2_amd.sam2_video_predictor import SAM2VideoPredictor
-    from oracle.video_processor import OracleVideoProcessor
     import torch
     cfg = resolve_config(TINY)
     sd = synthetic_state_dict(cfg, 0)
@@ -317,18 +317,30 @@ def test_three_pass_stream_matches_oracle():
     pred = SAM2VideoPredictor(cfg, sd, "cuda:0", max_batch=4)
     pred.hip.set_precision("bf16x3k")
     vp = VideoProcessor(model_cfg=TINY, detector=det(), predictor=pred, **kw)
-    ovp = OracleVideoProcessor(sd, cfg, det(), **kw)
-    with torch.inference_mode():
+    for t in range(12):
+        vp.process_frame(t, synthetic_frame(t))
+    if os.environ.get("DS2_SLOW_ORACLE"):
+        from oracle.video_processor import OracleVideoProcessor
+        ovp = OracleVideoProcessor(sd, cfg, det(), **kw)
+        with torch.inference_mode():
+            for t in range(12):
+                ovp.process_frame(t, synthetic_frame(t))
+        want_passes = [(p[0], list(p[1])) for p in ovp.pass_log]
+        want = {t: {o: ovp.video_segments[t][o] for o in ovp.video_segments[t]} for t in range(12)}
+    else:
+        g = np.load(os.path.join(golden_dir, "oracle_three_pass.npz"))
+        want_passes = [(int(s0), list(g[f"pass{i}"])) for i, s0 in enumerate(g["passes"])]
+        want = {}
         for t in range(12):
-            f = synthetic_frame(t)
-            vp.process_frame(t, f)
-            ovp.process_frame(t, f)
-    assert [p[:2] for p in vp.pass_log] == [p[:2] for p in ovp.pass_log]
+            objs = [int(o) for o in g[f"objs{t}"]]
+            bits = np.unpackbits(g[f"bits{t}"])[: len(objs) * 1024 * 1024].reshape(len(objs), 1, 1024, 1024).astype(bool)
+            want[t] = {o: bits[j] for j, o in enumerate(objs)}
+    assert [(p[0], list(p[1])) for p in vp.pass_log] == want_passes
     worst = 0.0
     for t in range(12):
-        assert sorted(vp.video_segments[t]) == sorted(ovp.video_segments[t]), t
+        assert sorted(vp.video_segments[t]) == sorted(want[t]), t
         for o in vp.video_segments[t]:
-            worst = max(worst, 1.0 - _iou(vp.video_segments[t][o], ovp.video_segments[t][o]))
+            worst = max(worst, 1.0 - _iou(vp.video_segments[t][o], want[t][o]))
     record("e2e_three_pass", one_minus_iou=worst)
     assert worst <= 1e-3, worst
 

@@ -153,37 +153,40 @@ def test_memory_attention_at_bench_size(B, NF, NP, x4a, monkeypatch):
     gridDim.y + k_w8_merge, BASELINE config 2's shape) with the full bank and with the SHORT bank of a pass's first tracked frame
     (one conditioning frame + one pointer: Nk = 4100, a ragged tile inside the last split part), 16 objects with a short bank."""
     from det_sam2_amd.hip_model import HipSam2
+    from oracle.make_oracle_fixtures import MEMATTN_CASES, memattn_inputs
     monkeypatch.setenv("DS2_ATTN_X4A", x4a)
     cfg = resolve_config("sam2.1_hiera_t")          # the memory-attention weights have the same shapes in every config
     sd = synthetic_state_dict(cfg, 0)
     hm = HipSam2(cfg, sd, "cuda:0", max_batch=16)
     hm.set_precision("bf16x3k")
-    g = torch.Generator().manual_seed(21)
-    curr = torch.randn(4096, 256, generator=g)
-    feats = [torch.randn(B, 64, 64, 64, generator=g).to(torch.bfloat16) for _ in range(NF)]
-    ptrs = [torch.randn(B, 256, generator=g) for _ in range(NP)]
-    tpos_rows = [6, 5, 4, 3, 2, 1, 0][:NF]
-    ptr_pos = [float(i) for i in range(NP)]
-    pos2 = M.sine_pos_2d(64, 64, 64)
-    mems, poss = [], []
-    for f, r in zip(feats, tpos_rows):
-        mems.append(f.float().flatten(2).permute(2, 0, 1))
-        poss.append(pos2[None].expand(B, -1, -1, -1).flatten(2).permute(2, 0, 1) + sd["maskmem_tpos_enc"][r])
-    op = M.linear(sd, "obj_ptr_tpos_proj", M.sine_pe_1d(torch.tensor(ptr_pos) / 15.0, 256))
-    op = op.unsqueeze(1).expand(-1, B, 64).repeat_interleave(4, dim=0)
-    pt = torch.stack(ptrs, 0).reshape(-1, B, 4, 64).permute(0, 2, 1, 3).flatten(0, 1)
-    memory, memory_pos = torch.cat(mems + [pt], 0), torch.cat(poss + [op], 0)
-    assert memory.shape[0] == 4096 * NF + 4 * NP
-    vis_pos = M.sine_pos_2d(256, 64, 64).flatten(1).T
-    with torch.inference_mode():
-        ref = M.memory_attention(sd, cfg, curr[:, None].expand(-1, B, -1), vis_pos[:, None].expand(-1, B, -1), memory,
-                                 memory_pos, 4 * NP)
+    curr, feats, ptrs, tpos_rows, ptr_pos = memattn_inputs(B, NF, NP)
+    if (B, NF, NP) in MEMATTN_CASES and not os.environ.get("DS2_SLOW_ORACLE"):
+        # the oracle's result for the 16-object cases is a committed fixture (oracle/make_oracle_fixtures.py memattn_bench: every 64th
+        # token, fp32) - 17 s of host time each, which this test spent on the GPU box until round 6
+        gfx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_memattn_bench.npz"))
+        ref_sub, ref = torch.from_numpy(gfx[f"ref_{B}_{NF}_{NP}"]), None
+    else:
+        pos2 = M.sine_pos_2d(64, 64, 64)
+        mems, poss = [], []
+        for f, r in zip(feats, tpos_rows):
+            mems.append(f.float().flatten(2).permute(2, 0, 1))
+            poss.append(pos2[None].expand(B, -1, -1, -1).flatten(2).permute(2, 0, 1) + sd["maskmem_tpos_enc"][r])
+        op = M.linear(sd, "obj_ptr_tpos_proj", M.sine_pe_1d(torch.tensor(ptr_pos) / 15.0, 256))
+        op = op.unsqueeze(1).expand(-1, B, 64).repeat_interleave(4, dim=0)
+        pt = torch.stack(ptrs, 0).reshape(-1, B, 4, 64).permute(0, 2, 1, 3).flatten(0, 1)
+        memory, memory_pos = torch.cat(mems + [pt], 0), torch.cat(poss + [op], 0)
+        assert memory.shape[0] == 4096 * NF + 4 * NP
+        vis_pos = M.sine_pos_2d(256, 64, 64).flatten(1).T
+        with torch.inference_mode():
+            ref = M.memory_attention(sd, cfg, curr[:, None].expand(-1, B, -1), vis_pos[:, None].expand(-1, B, -1), memory,
+                                     memory_pos, 4 * NP)
+        ref_sub = ref.transpose(0, 1)[:, ::64]
     d = hm.device
     mem_d, pos_d = hm.bank_assemble(B, [(f.flatten(2).transpose(1, 2).contiguous().to(d), r) for f, r in zip(feats, tpos_rows)],
                                     [(p.to(d), q / 15.0) for p, q in zip(ptrs, ptr_pos)])
     out = hm.memory_attention(B, curr.to(d), mem_d, pos_d, 4 * NP).clone()
     torch.cuda.synchronize()
-    e = rel_err(out, ref.transpose(0, 1))
+    e = rel_err(out[:, ::64], ref_sub) if ref is None else rel_err(out, ref.transpose(0, 1))
     record("memory_attention_bench_size", B=B, Nk=4096 * NF + 4 * NP, x4a=x4a, err=e)
     assert e < 1e-3, e        # measured 2.9e-4 (4.4e-5 with DS2_F16X2=0; rounds 2-3: 3.4e-4); (a racy epilogue variant of the K = 64 GEMM once showed up here as 2-4e-3)
     # no atomics anywhere on this path: a second run must agree bit for bit (a difference is a race in a kernel)
