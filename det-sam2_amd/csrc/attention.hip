@@ -249,11 +249,8 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
   DS2_REQUIRE(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0, "attention: row strides must be multiples of 4");
   DS2_REQUIRE(a.batch <= 65535 && a.heads <= 65535, "attention: grid too large");
   if (attention_fewq_supported(a)) return launch_attention_fewq(a, st);   // few queries x many keys: split-key fp32 path
-#ifndef DS2_SMALLWIN
-#define DS2_SMALLWIN 1
-#endif
   if (ds2_split_mode() && attention_winlds_supported(a)) return launch_attention_winlds(a, st);
-  if (DS2_SMALLWIN && ds2_split_mode() && attention_smallwin_supported(a)) return launch_attention_smallwin(a, st);
+  if (ds2_split_mode() && attention_smallwin_supported(a)) return launch_attention_smallwin(a, st);
   if (ds2_split_mode()) {
     const int rc = launch_attention_bf16x3(a, st);
     if (rc != DS2_ERR_UNSUPPORTED) return rc;

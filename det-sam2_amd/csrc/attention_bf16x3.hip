@@ -41,9 +41,6 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p0, bf16x8& p1) {
   p1 = __builtin_bit_cast(bf16x8, l);
 }
 
-#ifndef DS2_HATT_CRESCALE
-#define DS2_HATT_CRESCALE 1
-#endif
 #ifndef DS2_HATT_VEARLY
 #define DS2_HATT_VEARLY 1
 #endif
@@ -338,10 +335,8 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(k0p + ks * 32);
         const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(k1p + ks * 32);
-        if (!DS2_EXP_HQK1) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], acc, 0, 0, 0);
-        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0[ks], acc, 0, 0, 0);
       }
       ATT_T()   // 2: QK MFMAs issued
@@ -374,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void k_attention_bf16x3(AttnArgs a) {
     }
     ATT_T()   // 4: K staged, V loads issued
     if (wave_active) {
-      if (!DS2_HATT_CRESCALE || __any(alpha != 1.f)) {   // (exact: alpha == 1 leaves o unchanged; after the first tiles the common case)
+      if (__any(alpha != 1.f)) {   // (exact: alpha == 1 leaves o unchanged; after the first tiles the common case)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll

@@ -109,10 +109,8 @@ __global__ __launch_bounds__(256) void k_attn_smallwin(AttnArgs a, int n_items, 
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 k0, k1;
       split8(load8<D>(kp, ks * 16 + half * 8, 1.f), k0, k1);
-      if (!DS2_EXP_HQK1) {
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], s[t], 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], s[t], 0, 0, 0);
-      }
+      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, q0[ks], s[t], 0, 0, 0);
+      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q1[ks], s[t], 0, 0, 0);
       s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, q0[ks], s[t], 0, 0, 0);
     }
   }

@@ -86,17 +86,8 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 #define DS2_ATTN_ILV 1
 #endif
 // DS2_ATTN_DMA (ILV instantiation): tiles staged by LDS-DMA into swizzled LDS images instead of through registers
-#ifndef DS2_ATTN_RING4
-#define DS2_ATTN_RING4 1
-#endif
-#ifndef DS2_ATTN_ILV256
-#define DS2_ATTN_ILV256 0
-#endif
 #ifndef DS2_ATTN_DMA
 #define DS2_ATTN_DMA 1
-#endif
-#ifndef DS2_ATTN_QG1_SMALL
-#define DS2_ATTN_QG1_SMALL 1
 #endif
 #ifndef DS2_ATTN_PRIO
 #define DS2_ATTN_PRIO 0
@@ -276,12 +267,12 @@ __global__ __launch_bounds__(512, 2) void k_attention_w8(W8Args a) {
   constexpr int VPL = (DV == 256 && !KLO) ? 1 : 2;
   // (DV = 256, the self-attention, keeps the compiler's own order: with 64 accumulator registers on top the interleaved
   // schedule spills the staged K rows to scratch inside the loop - measured 1.39 -> 1.89 ms/frame)
-  constexpr bool ILV = DS2_ATTN_ILV && !KLO && (DV == 64 || (DS2_ATTN_ILV256 && DV == 256));
+  constexpr bool ILV = DS2_ATTN_ILV && !KLO && DV == 64;
   // ONE LDS array addressed by byte offsets (with separate typed arrays hipcc waits for every pending LDS-DMA before a ds_read
   // that might alias it): K buffer b, plane p at KP(b, p, 0); V^T buffers behind them
   // RING = tile slots per operand: tile j lives in slot j % RING.  2 = double buffer, one barrier per tile.  4 (DMA-staged
   // cross-attention): the frame-token loop runs TWO tiles per barrier - its copies target the two slots the pair does not read.
-  constexpr int RING = (SWZ && ILV && DV == 64 && QG == 2 && DS2_ATTN_RING4) ? 4 : 2, NVB = RING;
+  constexpr int RING = (SWZ && ILV && DV == 64 && QG == 2) ? 4 : 2, NVB = RING;
   constexpr int KNP = KLO ? 2 : 1, VOFF = RING * KNP * KPLANE;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[RING * KNP * KPLANE + NVB * VPL * VPLANE];
 #define KP(b_, p_, off_) (lds + ((b_) * KNP + (p_)) * KPLANE + (off_))
@@ -818,7 +809,7 @@ int launch_attention_w8(const float* q, int ldq, const void* k_hi, const void* k
   // Few objects: with 256 queries per workgroup the grid is batch * Lq / 256 workgroups - 64 for 4 objects, a quarter of the chip.
   // Up to 128 of them the 128-query form (QG = 1) doubles the grid and still fits one round; per query both forms run the same
   // instruction sequence over the same tiles (bit-identical: tools/stage_hash_check.py against -DDS2_ATTN_QG1_SMALL=0).
-  const bool qg1 = DS2_ATTN_QG1_SMALL && batch * (Lq / 256) <= 128;
+  const bool qg1 = batch * (Lq / 256) <= 128;
   W8Args a{q, ldq, reinterpret_cast<const uint4*>(k_hi), reinterpret_cast<const uint4*>(k_lo),
            reinterpret_cast<const uint4*>(vt), o, ldo, batch, Lq, Lk, scale,
            reinterpret_cast<unsigned short*>(o_hi), reinterpret_cast<unsigned short*>(o_lo), ldop,

@@ -34,23 +34,6 @@ void ds2_set_error(const char* fmt, ...);
     }                                              \
   } while (0)
 
-// Precision experiments (tools/ab.py build NAME -DDS2_EXP_...=1; never set in the shipped build, see DESIGN.md "precision
-// margin"): drop ONE of the three bf16x3 product terms - the activation's lo plane (GEMM2A), the weight's lo plane
-// (GEMM2W), or the key's lo plane in the memory-attention scores of the full bf16x3 mode (QK2).
-#ifndef DS2_EXP_GEMM2A
-#define DS2_EXP_GEMM2A 0
-#endif
-#ifndef DS2_EXP_GEMM2W
-#define DS2_EXP_GEMM2W 0
-#endif
-#ifndef DS2_EXP_HQK1   /* Hiera attention scores as plain bf16 x bf16 products (precision experiment) */
-#define DS2_EXP_HQK1 0
-#endif
-#ifndef DS2_EXP_QK2
-#define DS2_EXP_QK2 0
-#endif
-#define DS2_MFMA_IF(cond, acc, a, b) ((cond) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (acc), 0, 0, 0) : (acc))
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -182,10 +182,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
     }                                                                                     \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
       _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                    \
-        acc[tm][tn] = DS2_MFMA_IF(!(DS2_EXP_GEMM2A || (g.drop_terms & 1)), acc[tm][tn], fa1[tm], fb0[tn]); \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[tm], fb0[tn], acc[tm][tn], 0, 0, 0); \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
       _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                    \
-        acc[tm][tn] = DS2_MFMA_IF(!(DS2_EXP_GEMM2W || (g.drop_terms & 2)), acc[tm][tn], fa0[tm], fb1[tn]); \
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb1[tn], acc[tm][tn], 0, 0, 0); \
     _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                      \
       _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                    \
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[tm], fb0[tn], acc[tm][tn], 0, 0, 0); \
@@ -230,10 +230,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_split(GemmSplitArgs g, int mt, 
 #define G_MFMA(A0, A1, B0, B1)                                                            \
   _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
     _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                      \
-      acc[tm][tn] = DS2_MFMA_IF(!(DS2_EXP_GEMM2A || (g.drop_terms & 1)), acc[tm][tn], A1[tm], B0[tn]); \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[tm], B0[tn], acc[tm][tn], 0, 0, 0); \
   _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
     _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                      \
-      acc[tm][tn] = DS2_MFMA_IF(!(DS2_EXP_GEMM2W || (g.drop_terms & 2)), acc[tm][tn], A0[tm], B1[tn]); \
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B1[tn], acc[tm][tn], 0, 0, 0); \
   _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)                                        \
     _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                      \
       acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[tm], B0[tn], acc[tm][tn], 0, 0, 0);

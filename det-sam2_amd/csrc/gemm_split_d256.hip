@@ -87,17 +87,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const int nk = g.Kp / BK;
   const int last = nk - 1;
-// DS2_ABL_*: ablation builds for profiling only (results are WRONG): drop the LDS-DMA, the MFMAs or the fragment reads
-#ifndef DS2_ABL_NODMA
-#define DS2_ABL_NODMA 0
-#endif
-#ifndef DS2_ABL_NOMFMA
-#define DS2_ABL_NOMFMA 0
-#endif
-#ifndef DS2_ABL_NOREAD
-#define DS2_ABL_NOREAD 0
-#endif
-#define D2_DMA(src, dstoff) if (!DS2_ABL_NODMA) __builtin_amdgcn_global_load_lds((src), (lds_ptr)(lds + (dstoff)), 16, 0, 0);
+#define D2_DMA(src, dstoff) __builtin_amdgcn_global_load_lds((src), (lds_ptr)(lds + (dstoff)), 16, 0, 0);
 #define D2_FILL(kt, so)                                                                        \
   if (loader) {                                                                                \
     const unsigned ko = (unsigned)((kt) < last ? (kt) : last) * (BK * 2);                      \
@@ -112,7 +102,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   const int sw = (l31 >> 2) & 3;
   const int fra = (wm * 128 + l31) * ROWB, frb = 2 * PL + (wn * 64 + l31) * ROWB;
 #define D2_READ(F, so, s)                                                                      \
-  if (!DS2_ABL_NOREAD || kt_first) {                                                           \
+  {                                                                                            \
     const unsigned char* b_ = lds + (so) + ((((s) * 2 + half) ^ sw) << 4);                     \
     _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                            \
       F.bh[t] = *reinterpret_cast<const bf16x8*>(b_ + frb + t * 32 * ROWB);                    \
@@ -127,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
 #define D2_MFMA_TERM(F, X, Y)                                                                  \
   _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                             \
     _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)                                           \
-      if (!DS2_ABL_NOMFMA) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.X[tm], F.Y[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.X[tm], F.Y[tn], acc[tm][tn], 0, 0, 0);
 
   // L2 prefetch.  A K tile is published by ONE barrier, so its latency is that of its slowest cache line - and some
   // lines always miss L2 (activations come from HBM / Infinity Cache on first touch; a weight matrix of several MiB
@@ -159,7 +149,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
   }
 
   FragsD F0, F1;
-  bool kt_first = true;         // (ablation builds read the fragments once)
   int s0 = 0, s1 = STAGE;       // stage offsets of tiles t, t+1
   for (int t = 2 - pf; t < 2; ++t) D2_TOUCH(t)          // tiles 2 .. pf+1 (tiles 0 and 1 are fetched right away)
   D2_FILL(0, s0)
@@ -172,11 +161,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     // flight); tile kt+1 in flight into s1 (issued one step ago)
     // (the first MFMA term goes ahead of the sub-step-1 reads: hipcc guards the first use of F0 with lgkmcnt(0), which
     // would otherwise also wait for the twelve reads just issued)
-    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) D2_MFMA_TERM(F0, al, bh)
+    D2_MFMA_TERM(F0, al, bh)
     __builtin_amdgcn_sched_barrier(0);
     D2_READ(F1, s0, 1)
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) D2_MFMA_TERM(F0, ah, bl)
+    D2_MFMA_TERM(F0, ah, bl)
     D2_MFMA_TERM(F0, ah, bh)
     __builtin_amdgcn_sched_barrier(0);
     // F1 landed => this wave no longer reads stage s0; its own pieces of tile kt+1 landed.  After the barrier: stage s0
@@ -188,14 +177,13 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_d256(GemmSplitArgs g, int
     D2_FILL(kt + 2, s0)
     D2_TOUCH(kt + 2)
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) D2_MFMA_TERM(F1, al, bh)
+    D2_MFMA_TERM(F1, al, bh)
     __builtin_amdgcn_sched_barrier(0);
     D2_READ(F0, s1, 0)
     __builtin_amdgcn_sched_barrier(0);
-    if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) D2_MFMA_TERM(F1, ah, bl)
+    D2_MFMA_TERM(F1, ah, bl)
     D2_MFMA_TERM(F1, ah, bh)
     const int t_ = s0; s0 = s1; s1 = t_;
-    if (DS2_ABL_NOREAD && kt >= 1) kt_first = false;
   }
   asm volatile("" ::"v"(junk));
 

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
         const unsigned char* wp = lds + (t * 32 + l31) * WROWB + coff;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + WPL);
-        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2A || (g.drop_terms & 1)), acc[t], F.l[s], bh);
-        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2W || (g.drop_terms & 2)), acc[t], F.h[s], bl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.l[s], bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bh, acc[t], 0, 0, 0);
       }
     }
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64t(GemmSplitArgs g, int
         const unsigned char* wp = lds + (t * 32 + l31) * WROWB + coff;
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wp);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wp + WPL);
-        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2A || (g.drop_terms & 1)), acc[t], F.l[s], bh);
-        acc[t] = DS2_MFMA_IF(!(DS2_EXP_GEMM2W || (g.drop_terms & 2)), acc[t], F.h[s], bl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.l[s], bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bl, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.h[s], bh, acc[t], 0, 0, 0);
       }
     }
@@ -435,7 +435,7 @@ int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st) {
   DS2_REQUIRE(!g.c_hi_f16 || (planes && !g.C_lo), "gemm_split_k64: fp16 hi plane needs the plane-only epilogue without a lo plane");
   // the key projection (256 columns, planes only, axial RoPE with the compact table): the register-transposed epilogue
   const bool k64t = planes && ncols == 256 && g.N == 256 && g.ldcp == 256 && g.rope_cis && g.rope_w == 64 &&
-                    g.rope_grid == 4096 && g.rope_L > 0 && (g.c_hi_f16 || g.C_lo) && !g.drop_terms;
+                    g.rope_grid == 4096 && g.rope_L > 0 && (g.c_hi_f16 || g.C_lo);
   if (k64t && g.c_hi_f16)
     hipLaunchKernelGGL((k_gemm_split_k64t<true>), dim3(blocks), dim3(512), 0, st, g, tiles_per_wave);
   else if (k64t)

@@ -43,9 +43,6 @@ struct FragW {
   bf16x8 h[2], l[2];   // [16-deep sub-step]
 };
 
-#ifndef DS2_ABL_NOSTORE
-#define DS2_ABL_NOSTORE 0
-#endif
 // DS2_PP_TRACE (profiling builds only): the waves of workgroup 0 stamp s_memtime around every barrier of their first tile
 // (DS2_PP_TRACE=1: every step of the first tile; =2: the coarse events of the first three tiles, see tools/pp_trace.py)
 #ifdef DS2_PP_TRACE
@@ -175,10 +172,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_pp256(GemmSplitArgs g, in
 #define PP_MFMA(qm, qn, F)                                                                                      \
   if (!deadq[qn])                                                                                               \
   _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                               \
-    if (!(g.drop_terms & 1))                                                                                    \
       _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
         acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[t][s], F.h[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
-    if (!(g.drop_terms & 2))                                                                                    \
       _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                             \
         acc[(qm) * 2 + t][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[t][s], F.l[s], acc[(qm) * 2 + t][qn], 0, 0, 0); \
     _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
@@ -280,7 +275,6 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_pp256(GemmSplitArgs g, in
             if (m >= g.M) continue;
             const float4 a4 = *reinterpret_cast<const float4*>(&eps[rr * EPLD + c4 * 4]);
             float v[4] = {a4.x, a4.y, a4.z, a4.w};
-            if (DS2_ABL_NOSTORE) { asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
             if (g.C) {
               float* cp = g.C + (size_t)m * g.ldc + n;
               if (vec_ok && (g.ldc & 3) == 0) {   // (asm: hipcc otherwise merges this with the ragged path into dword + dwordx3)

@@ -13,9 +13,6 @@
 #include "common.h"
 #include "kernels.h"
 
-#ifndef DS2_R3_NODEAD
-#define DS2_R3_NODEAD 0   // (A/B builds: 1 = every wave multiplies its padding columns as before)
-#endif
 
 namespace {
 
@@ -118,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
   // a wave whose columns lie (partly) beyond N (N = 576: the second wave column of the fifth 128-wide tile) multiplies zeros
   // there: it keeps staging, reading and meeting the barriers but issues no MFMA for its dead 32-column blocks - on a
   // power-limited chip that is time for the others.  live = 32-column blocks of this wave with at least one real column
-  int live_ = DS2_R3_NODEAD ? 2 : (g.N - (n0 + wn * 64) + 31) / 32;
+  int live_ = (g.N - (n0 + wn * 64) + 31) / 32;
   live_ = live_ < 0 ? 0 : (live_ > 2 ? 2 : live_);
   const int live = __builtin_amdgcn_readfirstlane(live_);
   const bool dead = live == 0;
@@ -136,10 +133,10 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
     R3_FILL(kt + 2, s2)
     __builtin_amdgcn_sched_barrier(0);
     if (!dead) {
-      if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F0, al, bh)
-      if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F0, ah, bl)
+      R3_MFMA_TERM(F0, al, bh)
+      R3_MFMA_TERM(F0, ah, bl)
       R3_MFMA_TERM(F0, ah, bh)
-      if (!(DS2_EXP_GEMM2A || (g.drop_terms & 1))) R3_MFMA_TERM(F1, al, bh)
+      R3_MFMA_TERM(F1, al, bh)
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile kt+1 landed; tile kt+2's 6 pieces stay in flight
@@ -148,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_r3(GemmSplitArgs g, int m
     R3_READ(F0, s1, 0)
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's first reads AHEAD of the trailing MFMAs
     if (!dead) {
-      if (!(DS2_EXP_GEMM2W || (g.drop_terms & 2))) R3_MFMA_TERM(F1, ah, bl)
+      R3_MFMA_TERM(F1, ah, bl)
       R3_MFMA_TERM(F1, ah, bh)
     }
     const int t_ = s0; s0 = s1; s1 = s2; s2 = t_;

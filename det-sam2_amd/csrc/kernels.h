@@ -128,8 +128,6 @@ struct GemmSplitArgs {
   // rope_w > 0 lets a kernel read row x resp. row y * rope_w instead of row pos (identical values): the rows touched shrink
   // from rope_grid (4 MiB of table, competing with the streamed operands for L2) to 2 * rope_w (64 KiB).
   int rope_w;
-  // precision experiments (DESIGN.md "precision margin"): drop the a_lo . w_hi term (1) and / or the a_hi . w_lo term (2)
-  int drop_terms;
   // block -> tile order inside an XCD's share of the grid: 0/1 = row-major over n; > 1 = groups of group_m tile rows
   // walked column-major (the ~32 blocks an XCD runs at once then share A rows AND W rows through its L2).  Set by
   // launch_gemm_split.

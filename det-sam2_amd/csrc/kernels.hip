@@ -209,12 +209,6 @@ __global__ __launch_bounds__(256) void k_layernorm_c64(const float* __restrict__
   if (live) *reinterpret_cast<float4*>(y + (size_t)row * ldy + 4 * l) = o;
 }
 
-#ifndef DS2_LN_C64
-#define DS2_LN_C64 1
-#endif
-#ifndef DS2_LN_VEC
-#define DS2_LN_VEC 1
-#endif
 template <bool SPLIT>
 static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, void* hi, void* lo,
                                  int ldp, int rows, int C, float eps, int act, hipStream_t st, const float* add = nullptr,
@@ -224,7 +218,7 @@ static bool launch_layernorm_vec(const float* x, int ldx, const float* w, const 
                   (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(b) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(add) & 15) == 0 && (reinterpret_cast<uintptr_t>(y2) & 15) == 0;
-  if (!ok || !DS2_LN_VEC) return false;
+  if (!ok) return false;
   const int nv = (width + 255) / 256;
   const dim3 grid(cdiv(rows, 4)), blk(256);
   uint2* h2 = reinterpret_cast<uint2*>(hi);
@@ -683,9 +677,6 @@ __global__ __launch_bounds__(256) void k_dwconv7_t4(const float* __restrict__ in
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[(((size_t)b * H + y0 + oy) * H + x0 + j) * C + c] = acc[oy][j];
 }
-#ifndef DS2_DWCONV_T4
-#define DS2_DWCONV_T4 1
-#endif
 __global__ void k_dwconv7(const float* in, const float* w, const float* bias, float* out, int B, int H, int C) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int XB = H / 8;
@@ -1159,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_mask_downscale_add(const float* mask, M
 int launch_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int rows, int C,
                      float eps, int act, hipStream_t st) {
   DS2_REQUIRE(rows > 0 && C > 0, "layernorm: bad dims");
-  if (DS2_LN_C64 && C == 64 && ldx % 4 == 0 && ldy % 4 == 0 &&
+  if (C == 64 && ldx % 4 == 0 && ldy % 4 == 0 &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
     hipLaunchKernelGGL(k_layernorm_c64, dim3(cdiv(rows, 16)), dim3(256), 0, st, x, ldx, w, b, y, ldy, rows, eps, act);
     DS2_CHECK_LAUNCH();
@@ -1374,7 +1365,7 @@ int launch_im2col3x3s2_split(const float* in, void* hi, void* lo, int ldp, int B
 }
 int launch_dwconv7(const float* in, const float* w49c, const float* bias, float* out, int B, int H, int C, hipStream_t st) {
   DS2_REQUIRE(H % 8 == 0, "dwconv7: H must be a multiple of 8");
-  if (DS2_DWCONV_T4 && H % 4 == 0) {
+  if (H % 4 == 0) {
     hipLaunchKernelGGL(k_dwconv7_t4, grid1((size_t)B * (H / 4) * (H / 8) * C), dim3(256), 0, st, in, w49c, bias, out, B, H, C);
     DS2_CHECK_LAUNCH();
     return DS2_OK;

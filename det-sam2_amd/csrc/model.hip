@@ -254,9 +254,6 @@ struct ds2_model {
 
 static int model_precision(const ds2_model* m) { return m->precision; }
 // DS2_MA_FOLD_VO=0: keep out_proj of the memory attention's two attentions as its own GEMM (A/B runs)
-#ifndef DS2_MA_Q_ONCE
-#define DS2_MA_Q_ONCE 1
-#endif
 ModelScope::ModelScope(const ds2_model* m) : dg(m->device), ps(m->precision) {}
 
 #define ALLOC(var, n)                                                        \
@@ -299,16 +296,6 @@ static int new_act_planes(ds2_model* m, const void* key, int rows, int cols, ds2
 // C = act(A W^T + bias) * gamma + R.   bf16x3 mode: A is taken from registered planes when its producer emitted
 // them (else split by a pre-pass); with planes_out the result is emitted as planes registered under key C and
 // the fp32 buffer C is NOT written (its only consumers must be GEMMs).
-// precision experiment scope (DS2_EXP_MA_DROP=1|2|3): GEMMs issued while this is non-zero drop product terms (GemmSplitArgs)
-static thread_local int g_gemm_drop_terms = 0;
-struct GemmDropScope {
-  int prev;
-  explicit GemmDropScope(const char* env) : prev(g_gemm_drop_terms) {
-    const char* e = getenv(env);
-    if (e) g_gemm_drop_terms = atoi(e);
-  }
-  ~GemmDropScope() { g_gemm_drop_terms = prev; }
-};
 // Would gemm() run this Linear layer as the two-MFMA-equivalent ("MX") product?  Shape rules of the assembly kernel's 128 x 192
 // configuration (gemm_x4g.hip) - NOT its chip-filling rule: the arithmetic of a layer must not depend on the batch size (a sharded
 // stream encodes other batch sizes than a sequential one).  DS2_GEMM_MX=0: the three-term bf16 product everywhere (A/B runs).
@@ -419,7 +406,6 @@ static int gemm(hipStream_t st, int M, int N, int K, const float* A, int lda, co
   g.A_hi = ahi; g.A_lo = alo; g.lda = a_ld;
   g.W_hi = wp.hi; g.W_lo = wp.lo; g.ldw = wp.ld;
   g.bias = bias; g.C = C; g.ldc = ldc; g.act = act; g.gamma = gamma; g.R = R; g.ldr = ldr; g.r_mod = r_mod;
-  g.drop_terms = g_gemm_drop_terms;
   if (planes_out && m) {
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, C, M, N, &op, st));
@@ -1070,15 +1056,9 @@ static int image_encoder_impl(ds2_model* m, const void* frames, bool frames_f32,
     ALLOC(t2, (size_t)hwq * b.dim_out);
     TRY(layernorm(m, st, p + ".norm2", xn, t2, hwq, b.dim_out, 1e-6f, DS2_ACT_NONE, true, mx_mlp));
     ALLOC(h, (size_t)hwq * 4 * b.dim_out);
-    {
-      GemmDropScope _d1("DS2_EXP_FC1_DROP");
-      TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU,
-                 nullptr, 0, 0, nullptr, true, mx_mlp));   // hidden activations only feed mlp.layers.1: planes only
-    }
-    {
-      GemmDropScope _d2("DS2_EXP_FC2_DROP");
-      TRY(linear(m, st, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, h, 4 * b.dim_out, xn, b.dim_out, DS2_ACT_NONE, xn, b.dim_out));
-    }
+    TRY(linear(m, st, p + ".mlp.layers.0", hwq, 4 * b.dim_out, b.dim_out, t2, b.dim_out, h, 4 * b.dim_out, DS2_ACT_GELU,
+               nullptr, 0, 0, nullptr, true, mx_mlp));   // hidden activations only feed mlp.layers.1: planes only
+    TRY(linear(m, st, p + ".mlp.layers.1", hwq, b.dim_out, 4 * b.dim_out, h, 4 * b.dim_out, xn, b.dim_out, DS2_ACT_NONE, xn, b.dim_out));
     m->release(mark);
     x = xn;
     side = side_q;
@@ -1224,7 +1204,6 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
   DS2_REQUIRE(m && m->finalized && B > 0 && curr && (bank || (memory && memory_pos)) && out && Nk > 0 && n_ptr_tok >= 0 && n_ptr_tok <= Nk,
               "ds2_memory_attention: bad argument");
   ModelScope _dg(m);
-  GemmDropScope _gds("DS2_EXP_MA_DROP");
   // the layer-0 self-attention is shared by the B objects only when they all see the same tokens AND positions
   const bool shared0 = curr_shared && (curr_pos == nullptr || pos_shared);
   DS2_REQUIRE((Nk - n_ptr_tok) % TOK == 0, "ds2_memory_attention: Nk - num_obj_ptr_tokens must be a multiple of 4096");
@@ -1404,7 +1383,7 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
     // layer 0, shared input: the residual stream is still the same for every object up to the cross-attention's result, so
     // norm2 and q_proj run on ONE copy (TOK rows), the attention kernel reads those queries for every object, and the folded
     // value projection adds its result to x1 broadcast by row (r_mod) - no replication of x1, 15/16 of two passes saved
-    const bool q_once = once && split && m->ma_fold_vo && DS2_MA_Q_ONCE;
+    const bool q_once = once && split && m->ma_fold_vo;
     if (once) {
       if (!m->ma_fold_vo) TRY(linear(m, st, p + ".self_attn.out_proj", TOK, 256, 256, a, 256, x1, 256, DS2_ACT_NONE, x1, 256));
       if (!q_once) TRY(launch_bcast_rows(x1, x, TOK * 256, B, st));   // one launch instead of B device copies
@@ -1525,26 +1504,11 @@ namespace {
 #ifndef DS2_HEADS_LN_KPE
 #define DS2_HEADS_LN_KPE 1
 #endif
-#ifndef DS2_ME_X_PLANES
-#define DS2_ME_X_PLANES 1
-#endif
-#ifndef DS2_HEADS_I2T_PLANES
-#define DS2_HEADS_I2T_PLANES 1
-#endif
-#ifndef DS2_HEADS_U1_PLANES
-#define DS2_HEADS_U1_PLANES 1
-#endif
 #ifndef DS2_HEADS_O_PLANES
 #define DS2_HEADS_O_PLANES 1
 #endif
-#ifndef DS2_HEADS_KQ
-#define DS2_HEADS_KQ 1
-#endif
 #ifndef DS2_HEADS_LN_PE
 #define DS2_HEADS_LN_PE 1
-#endif
-#ifndef DS2_HEADS_BATCHED
-#define DS2_HEADS_BATCHED 1
 #endif
 #ifndef DS2_KPE_PLANES
 #define DS2_KPE_PLANES 1
@@ -1596,7 +1560,7 @@ int sam_attention(ds2_model* m, hipStream_t st, const std::string& p, int B, int
   a.scale = 1.0f / sqrtf((float)a.D);
   // image-side queries (image -> token): the tile kernel writes its result as the operand planes of out_proj (no fp32 `o`,
   // no split pre-pass); the few-query kernels of the token side have no plane output
-  if (DS2_HEADS_O_PLANES && DS2_HEADS_I2T_PLANES && ds2_split_mode() && Lq >= 1024 && a.D == 16) {
+  if (DS2_HEADS_O_PLANES && ds2_split_mode() && Lq >= 1024 && a.D == 16) {
     ds2_model::ActPlanes op;
     TRY(new_act_planes(m, o, B * Lq, internal, &op, st));
     a.o_hi = op.hi; a.o_lo = op.lo; a.ldop = op.ld;
@@ -1821,7 +1785,7 @@ static int sam_heads_impl(ds2_model* m, int32_t B, const float* pix_feat, int32_
     // tokens -> image
     TRY(norm_pe(p + ".norm1"));
     if (!kpe_ready) TRY(keys_plus_pe(m, st, keys, dense_pe, kpe, rows));
-    const float* kq_w = (DS2_HEADS_KQ && m->Pbytes("@sam_kq_w." + std::to_string(l))) ? m->P("@sam_kq_w." + std::to_string(l)) : nullptr;
+    const float* kq_w = (m->Pbytes("@sam_kq_w." + std::to_string(l))) ? m->P("@sam_kq_w." + std::to_string(l)) : nullptr;
     if (kq_w)   // k_proj of this attention and q_proj of the image->token attention below read the same keys + key_pe: one GEMM
       TRY(gemm(st, rows, 256, 256, kpe, 256, kq_w, 256, m->P("@sam_kq_b." + std::to_string(l)), kq, 256, DS2_ACT_NONE, nullptr, 0, 0,
                nullptr, true, m));
@@ -1876,14 +1840,14 @@ static int sam_heads_impl(ds2_model* m, int32_t B, const float* pix_feat, int32_
   ALLOC(u1, (size_t)B * 16384 * 64);
   {   // u1 feeds the second upscaling GEMM only: written as its operand planes in the split modes
     ds2_model::ActPlanes up{};
-    if (DS2_HEADS_O_PLANES && DS2_HEADS_U1_PLANES && ds2_split_mode()) TRY(new_act_planes(m, u1, B * 16384, 64, &up, st));
+    if (DS2_HEADS_O_PLANES && ds2_split_mode()) TRY(new_act_planes(m, u1, B * 16384, 64, &up, st));
     TRY(launch_upscale1(g1, fpn1, m->P(md + ".output_upscaling.1.weight"), m->P(md + ".output_upscaling.1.bias"), u1, B, st, up.hi, up.lo));
   }
   ALLOC(g2, (size_t)B * 16384 * 128);
   TRY(gemm(st, B * 16384, 128, 64, u1, 64, m->P("@up2_w"), 64, m->P("@up2_b"), g2, 128, DS2_ACT_NONE, nullptr, 0, 0, nullptr, true, m));
   ALLOC(hyper, (size_t)B * 128);
   ALLOC(iou4, (size_t)B * 4);
-  const bool heads_batched = DS2_MLP3_FUSED && DS2_HEADS_BATCHED && B <= 64;
+  const bool heads_batched = DS2_MLP3_FUSED && B <= 64;
   if (heads_batched) {   // the six MLPs that read the output tokens (4 hypernetworks, IoU, object score) as ONE launch
     Mlp3Batch jb{};
     auto job = [&](int i, const std::string& p, const float* A, int n_out, float* out, int ldc, int last_act) {
@@ -2023,7 +1987,7 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
     const LnFuse lni{m->P(p + ".norm.weight"), m->P(p + ".norm.bias"), 1e-6f, nullptr, nullptr};
     if (!ln_in) TRY(layernorm(m, st, p + ".norm", d, t, rows, 256, 1e-6f, DS2_ACT_NONE, true));
     TRY(mlp2(m, st, p + ".pwconv1", p + ".pwconv2", rows, 1024, ln_in ? d : t, h, x, DS2_ACT_GELU, x, m->P(p + ".gamma"),
-             DS2_ME_X_PLANES && l == 1, f16x2_enabled(), nullptr, nullptr, ln_in ? &lni : nullptr));   // the last block's result feeds out_proj
+             l == 1, f16x2_enabled(), nullptr, nullptr, ln_in ? &lni : nullptr));   // the last block's result feeds out_proj
   }
   if (out_f32) {      // MemoryEncoder.forward's own output (no no_obj_embed_spatial, no bf16 storage rounding)
     TRY(linear(m, st, me + ".out_proj", rows, 64, 256, x, 256, out_f32, 64));
