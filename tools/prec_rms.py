@@ -38,7 +38,34 @@ def run(scheme, name, nobj, nframes):
     return np.stack(out)
 
 
+_orig_sdpa = F.scaled_dot_product_attention
+HATT = [None]          # DS2_RMS_HATT=<scheme>: the attention cores of the IMAGE ENCODER (hieradet.py:40-82) in a reduced-term arithmetic,
+                       # Linear layers as PE.SCHEME says: f16x1 (q, k, p, v one fp16 plane each: 2 MFMAs instead of 6), f16_pv2 (v two fp16
+                       # planes: 3), f16_qk2 (k two planes: 3), bf16x1 (the rejected HQK1 family, calibration)
+
+
+def emu_sdpa(q, k, v, *a, **kw):
+    if HATT[0] is None or PE.REGION[0] != "enc" or a or kw:
+        return _orig_sdpa(q, k, v, *a, **kw)
+    sch = HATT[0]
+    r = (lambda x: x.to(torch.bfloat16).float()) if sch == "bf16x1" else (lambda x: x.to(torch.float16).float())
+    scale = q.shape[-1] ** -0.5
+    qs = q * scale
+    qh, kh = r(qs), r(k)
+    s_ = qh @ kh.transpose(-1, -2)
+    if sch == "f16_qk2":
+        s_ = s_ + qh @ r(k - kh).transpose(-1, -2)
+    p = torch.softmax(s_, dim=-1)
+    ph, vh = r(p), r(v)
+    o = ph @ vh
+    if sch in ("f16_pv2", "f16_qk2"):
+        o = o + ph @ r(v - vh)
+    return o
+
+
 if __name__ == "__main__":
+    F.scaled_dot_product_attention = emu_sdpa
+    HATT[0] = os.environ.get("DS2_RMS_HATT")
     F.linear = PE.emu_linear
     import oracle.modeling as _M
     for _n, _t in (("forward_image", "enc"), ("memory_attention", "ma"), ("mask_decoder", "dec"), ("memory_encoder", "menc")):
@@ -48,7 +75,12 @@ if __name__ == "__main__":
     ref = run("exact", name, 16, 3)
     print(f"# {name}, 16 objects, 3 frames, weight seed 1, structured frames; logits rms {np.sqrt((ref ** 2).mean()):.3f}; DS2_EMU_ONLY={PE.ONLY}", flush=True)
     for sch in sys.argv[1:]:
+        if ":" in sch:                 # <linear scheme>:<hiera attention scheme>
+            sch, HATT[0] = sch.split(":")
+        else:
+            HATT[0] = os.environ.get("DS2_RMS_HATT")
         got = run(sch, name, 16, 3)
         d = got - ref
         flips = int(((got > 0) != (ref > 0)).sum())
-        print(f"{sch:10s} rms dlogit {np.sqrt((d ** 2).mean()):.3e}   max {np.abs(d).max():.3e}   sign flips {flips} of {ref.size}", flush=True)
+        sch = sch + (":" + HATT[0] if HATT[0] else "")
+        print(f"{sch:18s} rms dlogit {np.sqrt((d ** 2).mean()):.3e}   max {np.abs(d).max():.3e}   sign flips {flips} of {ref.size}", flush=True)
