@@ -71,6 +71,7 @@ SIGNATURES = {
     "ds2_profile_tags": (C.c_int, [C.c_char_p, C.c_int64]),
     "ds2_op_gemm": (C.c_int, [i32, i32, i32, c_vp, i32, c_vp, i32, c_vp, c_vp, i32, i32, c_vp, c_vp, i32, i32, c_vp]),
     "ds2_op_gemm_planes": (C.c_int, [i32, i32, i32, c_vp, i32, c_vp, i32, c_vp, i32, c_vp, c_vp, c_vp]),
+    "ds2_op_split_planes": (C.c_int, [c_vp, i32, i32, i32, i32, c_vp, c_vp, c_vp]),
     "ds2_op_linear_small": (C.c_int, [i32, i32, i32, c_vp, i32, c_vp, i32, c_vp, c_vp, i32, i32, c_vp, c_vp, i32, i32, c_vp]),
     "ds2_op_mlp": (C.c_int, [i32, i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, i32, c_vp]),
     "ds2_op_layernorm": (C.c_int, [c_vp, c_vp, c_vp, c_vp, i32, i32, C.c_float, i32, c_vp]),

@@ -2052,6 +2052,17 @@ extern "C" int ds2_op_gemm_planes(int32_t M, int32_t N, int32_t K, const float* 
   unsigned short* al = ah + (size_t)M * Kp;
   unsigned short* wh = al + (size_t)M * Kp;
   unsigned short* wl = wh + (size_t)N * Kp;
+  // mode bf16x3k at a shape the MX form takes (what mlp.layers.0 of Hiera stages 3 / 4 is at hiera_l): the product is the
+  // two-MFMA-equivalent one and the planes are MX ACTIVATION planes (common.h) - what that layer hands to mlp.layers.1
+  if (gemm_mx_wanted(M, N, K, act, false, 0, false, false, true, false, bias != nullptr, false) && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out_hi) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_lo) & 15) == 0) {
+    TRY(launch_split_rows(A, lda, M, K, ah, al, Kp, st, false, DS2_PLANES_MX_A));
+    TRY(launch_split_rows(W, ldw, N, K, wh, wl, Kp, st, false, DS2_PLANES_MX_W));
+    GemmSplitArgs g{};
+    g.M = M; g.N = N; g.Kp = Kp; g.A_hi = ah; g.A_lo = al; g.lda = Kp; g.W_hi = wh; g.W_lo = wl; g.ldw = Kp;
+    g.bias = bias; g.act = act; g.C_hi = out_hi; g.C_lo = out_lo; g.ldcp = ldcp; g.mx = 1; g.c_mx = 1;
+    return launch_gemm_split(g, st);
+  }
   TRY(launch_split_rows(A, lda, M, K, ah, al, Kp, st));
   TRY(launch_split_rows(W, ldw, N, K, wh, wl, Kp, st));
   if (ldcp != N) {
@@ -2062,6 +2073,12 @@ extern "C" int ds2_op_gemm_planes(int32_t M, int32_t N, int32_t K, const float* 
   g.M = M; g.N = N; g.Kp = Kp; g.A_hi = ah; g.A_lo = al; g.lda = Kp; g.W_hi = wh; g.W_lo = wl; g.ldw = Kp;
   g.bias = bias; g.act = act; g.C_hi = out_hi; g.C_lo = out_lo; g.ldcp = ldcp;
   return launch_gemm_split(g, st);
+}
+// x [rows, cols] fp32 -> its two operand planes [rows, round-up-32(cols)] in one of the formats of common.h: 0 bf16 hi / lo, 1 MX
+// activation, 2 MX weight, 3 fp16 hi / lo (test hook of the plane formats)
+extern "C" int ds2_op_split_planes(const float* x, int32_t ldx, int32_t rows, int32_t cols, int32_t fmt, uint16_t* p1, uint16_t* p2, void* stream) {
+  DS2_REQUIRE(x && p1 && p2 && rows > 0 && cols > 0 && cols % 4 == 0 && ldx % 4 == 0 && fmt >= 0 && fmt <= 3, "ds2_op_split_planes: bad argument");
+  return launch_split_rows(x, ldx, rows, cols, p1, p2, round32i(cols), (hipStream_t)stream, fmt == 3, fmt == 3 ? 0 : fmt);
 }
 extern "C" int ds2_op_linear_small(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
                                    const float* bias, float* C, int32_t ldc, int32_t act, const float* gamma, const float* R,

@@ -99,6 +99,17 @@ class HipOps:
                                                 self._stream()), "ds2_op_gemm_planes")
         return hi, lo
 
+    def op_split_planes(self, x, fmt):
+        """The operand planes of x [rows, cols] (ds2_op_split_planes): fmt 0 bf16 hi / lo, 1 MX activation, 2 MX weight, 3 fp16 hi / lo
+        -> (p1, p2) int16 tensors [rows, round32(cols)]."""
+        import torch
+        rows, cols = x.shape
+        ld = (cols + 31) // 32 * 32
+        p1 = torch.empty(rows, ld, dtype=torch.int16, device=self.device)
+        p2 = torch.empty(rows, ld, dtype=torch.int16, device=self.device)
+        _capi.check(self.lib.ds2_op_split_planes(_p(x), x.stride(0), rows, cols, int(fmt), _p(p1), _p(p2), self._stream()), "ds2_op_split_planes")
+        return p1, p2
+
     def op_linear_small(self, A, W, bias=None, act=0, gamma=None, R=None, r_mod=0):
         """Few-row Linear layer in exact fp32 (ds2_op_linear_small): A [M<=128,K], W [N,K] -> [M,N]."""
         M, K = A.shape

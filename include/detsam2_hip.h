@@ -279,9 +279,15 @@ int ds2_op_gemm(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, co
                 int32_t ldr, int32_t r_mod, void* stream);
 /* The same GEMM with the result returned as bf16 operand planes (hi, lo: [M, round-up-32(N)] uint16 each, pad columns zero) instead of
  * fp32 - the form the first Linear layer of the Hiera MLP hands to the second (hieradet.py:160-166 via sam2_utils.py MLP); split
- * arithmetic modes only. */
+ * arithmetic modes only.  In mode 2 (bf16x3k), at a shape the MX product takes (M % 128 == 0, N % 192 == 0, K % 64 == 0, K >= 576, GELU,
+ * 16-byte aligned bias / planes), the product is the two-MFMA-equivalent one and the planes are MX ACTIVATION planes: hi = IEEE fp16
+ * (saturating), lo = one 16-bit word per element, byte 0 = e4m3(v * 4), byte 1 = e4m3((v - fp16(v)) * 2^14) (OCP e4m3, saturating). */
 int ds2_op_gemm_planes(int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* W, int32_t ldw,
                        const float* bias, int32_t act, uint16_t* out_hi, uint16_t* out_lo, void* stream);
+/* x [rows, cols] fp32 (row stride ldx) -> its operand planes p1, p2 [rows, round-up-32(cols)]: fmt 0 = bf16 hi / lo; 1 = MX activation
+ * planes (above); 2 = MX weight planes (p1 fp16; p2: byte 0 = e4m3((w - fp16(w)) * 2^18), byte 1 = e4m3(w * 64)); 3 = fp16 hi / lo.
+ * The formats the producers inside the library emit for their consumer GEMMs; exported as a test hook. */
+int ds2_op_split_planes(const float* x, int32_t ldx, int32_t rows, int32_t cols, int32_t fmt, uint16_t* p1, uint16_t* p2, void* stream);
 /* fused two-layer MLP of width 256: out = (act(X W1^T + b1) W2^T + b2) * gamma + R with X [rows,256], W1 [H,256], W2 [256,H],
  * R / out [rows,256]; b1, b2, gamma, R may be NULL.  The kernel behind MemoryAttentionLayer's FFN (memory_attention.py:93-98)
  * and CXBlock's pwconv1 / pwconv2 (memory_encoder.py:104-117) in the bf16x3 modes. */
