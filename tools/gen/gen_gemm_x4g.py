@@ -62,7 +62,7 @@ NDRAIN = 16 // KSUB                           # bodies that carry a drain step
 RP = MBW // 2                                 # (narrow drain) row pairs (of 8 per block) per step, 16 steps
 STEPS_PER_MB = 8 // RP
 PA_N, PW_N = MBW * KSUB, NBW * KSUB           # LDS-DMA pieces (1 KiB) per plane, wave and body
-NP = 2 * ((0 if 'onlyw' in FLAGS else PA_N) + (0 if 'onlya' in FLAGS else PW_N))   # pieces per wave and body
+NP = 0 if 'nodma' in FLAGS else 2 * ((0 if 'onlyw' in FLAGS else PA_N) + (0 if 'onlya' in FLAGS else PW_N))   # pieces per wave and body
 ISSUE = int(os.environ.get("X4G_ISSUE", 4))
 # form of the drain per epilogue, measured in one call (profiles/r05_f_stores.txt; X4G_WIDE / X4G_STMOD override for A/B builds):
 #   e1 (fp32, 453 MB at the qkv shape): quad transposes + 16-byte non-temporal stores 384 us, plain 403, dword stores 440 (pp256: 405)
@@ -1154,7 +1154,7 @@ def main():
     e("s_cbranch_scc1 L_plain")
     e("L_last:")
     li = body("last", None, (pl, pl))
-    assert li == last_info, (li, last_info)
+    assert li == last_info or 'nodma' in FLAGS, (li, last_info)
     e(f"s_mov_b32 {sr(S_KC)}, 0")
     e(f"s_sub_u32 {sr(S_TLEFT)}, {sr(S_TLEFT)}, 1")
     e(f"s_cmp_eq_u32 {sr(S_TLEFT)}, 0")
