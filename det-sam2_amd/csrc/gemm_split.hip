@@ -402,7 +402,7 @@ int heuristic_tile(const GemmSplitArgs& g) {
   const bool x4g = !(x4g_e && atoi(x4g_e) == 0);
   if (x4g && (tile == 3 || tile == 5 || tile == 10)) {
     const int cfg = gemm_split_x4g_config(g, 0);
-    if (cfg != 0 && (long)(g.M / (cfg == 42 ? 256 : 128)) * (g.N / (cfg == 42 ? 128 : 192)) >= 256) tile = 11;
+    if (cfg != 0 && (long)(g.M / (cfg == 42 ? 256 : 128)) * (g.N / (cfg == 42 ? 128 : 192)) >= gemm_x4g_ncu()) tile = 11;
   }
   return tile;
 }

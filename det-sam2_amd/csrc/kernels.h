@@ -150,6 +150,7 @@ bool gemm_split_pp256_supported(const GemmSplitArgs& g);
 // gemm_x4g.hip: assembly persistent kernel, epilogue of tile i under the main loop of tile i+1 (cfg 42: 256x128, 23: 128x192, 0: auto)
 int gemm_split_x4g_config(const GemmSplitArgs& g, int cfg);                 // configuration that can take the GEMM, 0 if none
 bool gemm_split_x4g_supported(const GemmSplitArgs& g);
+int gemm_x4g_ncu();                                                         // CUs of the current device (the persistent grid)
 int launch_gemm_split_x4g(const GemmSplitArgs& g, int cfg, hipStream_t st, const char** kname);
 bool gemm_split_k64_supported(const GemmSplitArgs& g);                      // K = 64, N in {128, 256}, many rows
 int launch_gemm_split_k64(const GemmSplitArgs& g, hipStream_t st);          // weight-stationary persistent streaming kernel

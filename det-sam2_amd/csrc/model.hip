@@ -8,6 +8,7 @@
 
 #include <string>
 #include <mutex>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -508,6 +509,25 @@ struct LnFuse {
   float* out_f32;                    // fp32 [rows, 256] (nullable)
   const ds2_model::ActPlanes* planes;   // pre-allocated operand planes, ld 256 (nullable)
 };
+// Scratch of the model-less fused-MLP op (ds2_op_mlp): one buffer per (host thread, device, purpose).  A call on another stream than the
+// previous one first waits for that stream - the buffer may still be read by its kernels; growing frees the old buffer
+// (hipFree waits for the device).
+static char* op_scratch(int kind, size_t need, hipStream_t st) {
+  struct Buf { char* p = nullptr; size_t bytes = 0; hipStream_t last = nullptr; bool used = false; };
+  static thread_local std::map<std::pair<int, int>, Buf> bufs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Buf& b = bufs[{dev, kind}];
+  if (b.used && b.last != st && hipStreamSynchronize(b.last) != hipSuccess) return nullptr;
+  if (b.bytes < need) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&b.p), need) != hipSuccess) return nullptr;
+    b.bytes = need;
+  }
+  b.last = st; b.used = true;
+  return b.p;
+}
 // out = (act(A W1^T + b1) W2^T + b2) * gamma + R with the hidden activations kept in registers (gemm_mlp256.hip); bf16x3
 // modes, model width 256 only - the caller falls back to two GEMMs when this returns DS2_ERR_UNSUPPORTED.
 // A's operand planes must be registered (its producer emitted them) or are split here.
@@ -532,14 +552,9 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
     // primitive call (ds2_op_mlp): the caller owns its weight tensors and may free / reuse their addresses between calls, so nothing
     // is cached under them - the planes of both weights are rebuilt into a per-thread scratch on the caller's stream (the
     // earlier insert-then-forget paid a device synchronisation, hipFree and four hipMallocs per call)
-    static thread_local char* op_w = nullptr;
-    static thread_local size_t op_w_bytes = 0;
     const size_t pl = (size_t)H * 256 * 2, need = 4 * pl + (size_t)256 * H * 4;
-    if (op_w_bytes < need) {
-      if (op_w) (void)hipFree(op_w);
-      DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&op_w), need));
-      op_w_bytes = need;
-    }
+    char* op_w = op_scratch(0, need, st);
+    if (!op_w) { ds2_set_error("ds2_op_mlp: scratch allocation failed"); return DS2_ERR_HIP; }
     w1p.hi = reinterpret_cast<unsigned short*>(op_w); w1p.lo = reinterpret_cast<unsigned short*>(op_w + pl); w1p.ld = 256;
     w2p.hi = reinterpret_cast<unsigned short*>(op_w + 2 * pl); w2p.lo = reinterpret_cast<unsigned short*>(op_w + 3 * pl); w2p.ld = H;
     float* tmp = reinterpret_cast<float*>(op_w + 4 * pl);
@@ -587,14 +602,8 @@ static int mlp_fused(ds2_model* m, GemmCtx& ctx, hipStream_t st, int rows, int H
   if (const size_t pb = mlp256_part_bytes(rows, H)) {   // few rows: hidden dimension split over workgroups, parts merged after
     a.part = reinterpret_cast<float*>(m ? m->alloc_bytes(pb) : nullptr);
     if (!a.part && !m) {   // primitive call: a scratch of its own behind the operand split
-      static thread_local float* op_part = nullptr;
-      static thread_local size_t op_part_bytes = 0;
-      if (op_part_bytes < pb) {
-        if (op_part) (void)hipFree(op_part);
-        DS2_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&op_part), pb));
-        op_part_bytes = pb;
-      }
-      a.part = op_part;
+      a.part = reinterpret_cast<float*>(op_scratch(1, pb, st));
+      if (!a.part) { ds2_set_error("ds2_op_mlp: scratch allocation failed"); return DS2_ERR_HIP; }
     }
     a.part_bytes = a.part ? pb : 0;
   }
@@ -618,7 +627,18 @@ static int mlp2(ds2_model* m, hipStream_t st, const std::string& p1, const std::
                            m->P(p2 + ".bias"), gamma, R, 256, out, 256, act, planes_too, f16x2, lnf, lni);
   if (ln_done) *ln_done = lnf && rc == DS2_OK;
   if (rc != DS2_ERR_UNSUPPORTED) return rc;
-  DS2_REQUIRE(!lni, "mlp2: the fused kernel cannot take this shape and the input was left un-normalised for it");
+  if (lni) {   // the caller left the input un-normalised for the fused kernel's prologue and the kernel declined: that LayerNorm as its
+               // own pass (operand planes for the first GEMM), then the two-GEMM form
+    float* tn = m->alloc((size_t)rows * 256);
+    ds2_model::ActPlanes op;
+    op.hi = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * 512));
+    op.lo = reinterpret_cast<unsigned short*>(m->alloc_bytes((size_t)rows * 512));
+    op.ld = 256;
+    if (!tn || !op.hi || !op.lo) { ds2_set_error("mlp2: workspace exhausted (LayerNorm fall-back)"); return DS2_ERR_STATE; }
+    m->act_planes[tn] = op;
+    TRY(launch_layernorm_split(A, 256, lni->w, lni->b, op.hi, op.lo, 256, rows, 256, lni->eps, DS2_ACT_NONE, st));
+    A = tn;
+  }
   TRY(linear(m, st, p1, rows, H, 256, A, 256, hbuf, H, act, nullptr, 0, 0, nullptr, true));
   return linear(m, st, p2, rows, 256, H, hbuf, H, out, 256, DS2_ACT_NONE, R, 256, 0, gamma);
 }
