@@ -74,6 +74,8 @@ STMOD = (" " + _stmod) if _stmod and _stmod != "none" else ""      # cache polic
 STDEFER = os.environ.get("X4G_STDEFER", "0") == "1"
 GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
 GAP8 = int(os.environ.get("X4G_GAP8", 56))    # ... behind one v_mfma_scale_f32_32x32x64_f8f6f4 (16 passes = 64 cycles)
+MX_SPLIT = int(os.environ.get("X4G_MX_SPLIT", 1))   # MX: 1 = two barriers per K tile, the two operand planes of a stage re-filled separately (body_mx2)
+DMA_PACE = int(os.environ.get("X4G_DMA_PACE", 1))   # MX: 1 = the DMA block paced under the MFMAs behind the barrier, 0 = one burst
 RD_EARLY = int(os.environ.get("X4G_RD_EARLY", 0))   # MX: the last LDS read of a stage is issued this many MFMA slots before its barrier
 assert not MX or (KSUB == 2 and CFG == "23m"), "the MX form exists for the 128 x 192 tile with 64-deep K tiles"
 
@@ -242,11 +244,13 @@ def read_ins(setbase, kind, i, q):
 
 
 # ------------------------------------------------------------------------------------------------ pieces of a body
-def dma_pieces():
-    """LDS-DMA of the DMA cursor's K tile into stage S_DDST: NP (m0 write, copy) pairs"""
+def dma_pieces(planes=(0, 1)):
+    """LDS-DMA of the DMA cursor's K tile into stage S_DDST: NP (m0 write, copy) pairs (planes: which operand planes)"""
     L = []
     ldmod = " nt" if "ldnt" in FLAGS else ""
     for plane, (pa, pw) in enumerate(((P_AH, P_WH), (P_AL, P_WL))):
+        if plane not in planes:
+            continue
         for j in range(PA_N):
             if "onlyw" in FLAGS:
                 continue
@@ -800,8 +804,10 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
             e(f"v_add_u32 {vr(RA)}, {sr(S_RDELTA)}, {vr(RA)}")
             e(f"v_add_u32 {vr(RW)}, {sr(S_RDELTA)}, {vr(RW)}")
             xq = [("X", k, i) for k, i in x_order()]
-            if MX:
+            if MX and DMA_PACE:
                 debt[0] = min(debt[0], 0.0)     # the DMA block is PACED under the fp16 / long fp8 MFMAs behind the barrier, not dumped in one gap
+            elif MX:
+                debt[0] = max(debt[0], 10000.0) # ... or issued in ONE burst right behind the barrier (the window of a piece ends at the next barrier)
             if DMA_POST:
                 Q[pos[0]:pos[0]] = Qdma
         b = mb * NBW + nb
@@ -871,6 +877,185 @@ def body(kind, d=None, hist=((0, 0), (0, 0)), prev_after=0):
             pos[0] = 0
             flush()
     return (vm_issued[0], vm_issued[0] - (dma_last[0] or 0))
+
+def body_mx2(kind, d=None, prev_after=0):
+    """The MX K-tile body with the stage's two operand planes re-filled SEPARATELY (round 6, second form).  With one barrier per K tile
+    and two stages only ONE tile's LDS-DMA is ever in flight, issued behind barrier t and needed at barrier t+1: the L2 -> LDS stream
+    idles from its completion to the next barrier and every tile pays the L2 latency (measured: 0.72 us of the 1.22 us a tile's 80 KB
+    take at the CU's share of the L2 rate stay exposed, profiles/r06_mx_time.txt).  Here:
+        q0 q1 | B1 | F F | q2 | B2 | q3        (q: 6 fp16 MFMAs of a 16-deep sub-step, F: 6 scaled fp8 MFMAs)
+      * the plane-2 (fp8) fragments of tile t are read behind q0 / q1; B1 = every wave is past them -> the plane-2 region of the stage
+        is free and plane 2 of tile t+2 is issued under the long fp8 MFMAs (window: to B2 of the NEXT body, 1.6 K tiles);
+      * the fp16 fragments of q2 / q3 are read behind q1 / F; B2 = plane 1 of the stage is free and tile t+1 has landed -> plane 1 of
+        tile t+2 and the first fragments of tile t+1 are issued under q3.
+    The vmcnt of B2 is counted inside the body: everything older than this body's own plane-2 pieces must be complete.
+    Returns (VMEM ops of the body, VMEM ops issued after its last bias / residual load or None)."""
+    n = body_n[0]
+    body_n[0] += 1
+    lg = Stream(POST_BAR)
+    vm_issued, vm_names = [0], []
+    dma2_start = [None]
+
+    def emit_vm(ins, name):
+        e(ins)
+        vm_names.append(name)
+        vm_issued[0] += 1
+
+    def need_lg(name):
+        c = lg.need(name)
+        if c is not None:
+            e(f"s_waitcnt lgkmcnt({min(c, 15)})")
+
+    nodma = "nodma" in FLAGS
+    Qd2 = [("blk", advance_block(n))] + dma_dst_setup()          # behind B1: cursor -> tile t+2, destinations, plane 2
+    Qd1 = []                                                     # behind B2: plane 1, stage rotation
+    if not nodma:
+        for m0w, cp in dma_pieces((1,)):
+            Qd2 += [m0w, ("dma2", cp)]
+        for m0w, cp in dma_pieces((0,)):
+            Qd1 += [m0w, ("dma", cp)]
+    Qd1 += rotate_dma_dst()
+    Q = []
+    if kind == "last":
+        Q += last_setup()
+    Q += rotate_read_delta()
+    if kind == "drain":
+        if d == 0:
+            Q.append(("waitvm_setup",))
+        Q += drain_items(d)
+    pos, debt = [0], [0.0]
+
+    def emit_one():
+        it = Q[pos[0]]
+        pos[0] += 1
+        if isinstance(it, str):
+            e(it)
+            return cost(it)
+        if it[0] == "blk":
+            for s_ in it[1]:
+                e(s_)
+            return 6 * ISSUE
+        if it[0] in ("dma", "dma2"):
+            e("s_nop 0")
+            if it[0] == "dma2" and dma2_start[0] is None:
+                dma2_start[0] = vm_issued[0]
+            emit_vm(it[1], it[0])
+            return 2 * ISSUE
+        if it[0] == "vm":
+            emit_vm(it[1], it[2])
+            return ISSUE
+        if it[0] == "needvm":
+            idx = max(i for i, nm in enumerate(vm_names) if nm == it[1])
+            e(f"s_waitcnt vmcnt({min(vm_issued[0] - idx - 1, 63)})")
+            return ISSUE
+        if it[0] in ("needprev", "waitvm_setup"):      # loads the PREVIOUS body issued (it issued prev_after VMEM ops behind them)
+            e(f"s_waitcnt vmcnt({min(prev_after + vm_issued[0], 63)})")
+            return ISSUE
+        raise ValueError(it)
+
+    def fill(budget):
+        debt[0] += budget
+        while pos[0] < len(Q) and debt[0] > 0:
+            debt[0] -= emit_one()
+
+    # ---- slots: (kind, mb, nb, q | j)
+    blocks = [(mb, nb) for mb in range(MBW) for nb in range(NBW)]
+    S = [("h", mb, nb, 0) for mb, nb in blocks] + [("h", mb, nb, 1) for mb, nb in blocks]
+    S += [("f", mb, nb, j) for j in range(2) for mb, nb in blocks]
+    S += [("h", mb, nb, 2) for mb, nb in blocks] + [("h", mb, nb, 3) for mb, nb in blocks]
+    assert len(S) == NSLOT and NQ == 4
+    B1, B2 = 2 * NB, 5 * NB
+    pre = "XYZW"
+    setof = lambda q: FX if q % 2 == 0 else FY                   # noqa: E731
+    # read queues: (slot from which it may be issued, instruction, stream name)
+    R = []
+    r8 = f8_order()
+    for i_, (k, i, qp) in enumerate(r8):                         # plane 2 of THIS tile: slots 0.., three per slot
+        R.append((i_ // 3, read8_ins(k, i, qp), f"F8{k}{i}{qp}"))
+    for i_, (k, i) in enumerate(y_order()):                      # q1's fragments (set Y): behind the first MFMAs of q0
+        R.append((0, read_ins(FY, k, i, 1), f"Y{k}{i}"))
+    for i_, (k, i) in enumerate(y_order()):                      # q2's fragments (set X again): X is free once q0 has issued
+        R.append((NB, read_ins(FX, k, i, 2), f"Z{k}{i}"))
+    for i_, (k, i) in enumerate(y_order()):                      # q3's fragments (set Y again): behind B1, under the fp8 MFMAs
+        R.append((B1, read_ins(FY, k, i, 3), f"W{k}{i}"))
+    for i_, (k, i) in enumerate(x_order()):                      # the NEXT tile's q0 fragments: behind B2
+        R.append((B2, read_ins(FX, k, i, 0), f"X{k}{i}"))
+    R.sort(key=lambda r: r[0])
+    rp = [0]
+    park_q = []
+    first = kind == "drain" and d == 0
+
+    def barrier(wait_vm, lg_last=None):
+        if wait_vm is not None:
+            e(f"s_waitcnt vmcnt({min(wait_vm, 63)})")
+        if lg_last is None:
+            e("s_waitcnt lgkmcnt(0)")
+            lg.wait_all()
+        else:                      # (B1: this wave's plane-2 reads only - the younger fp16 reads of q2 stay in flight)
+            need_lg(lg_last)
+        if "nobarrier" not in FLAGS:
+            e("s_barrier")
+
+    for si, (kd, mb, nb, q) in enumerate(S):
+        if si == B1:
+            assert all(r[0] >= B1 for r in R[rp[0]:]), "plane-2 reads must be issued before B1"
+            k_, i_, qp_ = r8[-1]
+            barrier(None, f"F8{k_}{i_}{qp_}")
+            debt[0] = min(debt[0], 0.0)
+            Q[pos[0]:pos[0]] = Qd2
+        if si == B2:
+            while any((not isinstance(x, str)) and x[0] == "dma2" for x in Q[pos[0]:]):     # (never taken at the default gaps)
+                emit_one()
+            assert all(r[0] >= B2 for r in R[rp[0]:]), "every read of this stage must be issued before B2"
+            # tile t+1 (both planes) landed: everything older than this body's plane-2 pieces is complete
+            barrier(None if (nodma or dma2_start[0] is None) else vm_issued[0] - dma2_start[0])
+            e(f"v_add_u32 {vr(RA)}, {sr(S_RDELTA)}, {vr(RA)}")
+            e(f"v_add_u32 {vr(RW)}, {sr(S_RDELTA)}, {vr(RW)}")
+            debt[0] = min(debt[0], 0.0)
+            Q[pos[0]:pos[0]] = Qd1
+        b = mb * NBW + nb
+        if kd == "f":
+            for nm in (f"F8a{mb}{2 * q}", f"F8a{mb}{2 * q + 1}", f"F8w{nb}{2 * q}", f"F8w{nb}{2 * q + 1}"):
+                need_lg(nm)
+            if "nomfma" not in FLAGS:
+                e(f"v_mfma_scale_f32_32x32x64_f8f6f4 {acc(b)}, {f8('a', mb, q)}, {f8('w', nb, q)}, {acc(b)}, {vr(SCA)}, {vr(SCB)} op_sel_hi:[0,0,0]")
+        else:
+            need_lg(f"{pre[q]}ah{mb}")
+            need_lg(f"{pre[q]}wh{nb}")
+            c = "0" if (first and q == 0) else acc(b)
+            if "nomfma" not in FLAGS:
+                e(f"v_mfma_f32_32x32x16_f16 {acc(b)}, {frag(setof(q), 'ah', mb)}, {frag(setof(q), 'wh', nb)}, {c}")
+        spent = 0
+        for _ in range(3 if si < B1 else 2):
+            if rp[0] < len(R) and R[rp[0]][0] <= si:
+                _, ins, nm = R[rp[0]]
+                rp[0] += 1
+                if "noread" not in FLAGS:
+                    e(ins)
+                lg.issue(nm)
+                spent += ISSUE
+        if kind == "last" and kd == "h" and q == NQ - 1:
+            park_q.append((si + 3, b))
+        while park_q and park_q[0][0] <= si:
+            _, pb = park_q.pop(0)
+            for r in range(16):
+                e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
+            spent += 16 * ISSUE
+        fill((GAP8 if kd == "f" else GAP) - spent)
+    assert rp[0] == len(R), (rp[0], len(R))
+    while pos[0] < len(Q):
+        emit_one()
+    for q in range(1, NQ):
+        e(f"v_add_u32 {vr(RA + q)}, {sr(S_RDELTA)}, {vr(RA + q)}")
+        e(f"v_add_u32 {vr(RW + q)}, {sr(S_RDELTA)}, {vr(RW + q)}")
+    if kind == "last":
+        e("s_nop 15")
+        while park_q:
+            _, pb = park_q.pop(0)
+            for r in range(16):
+                e(f"v_accvgpr_mov_b32 {ar(128 + 16 * pb + r)}, {ar(16 * pb + r)}")
+    loads = [i for i, nm in enumerate(vm_names) if nm == "bias" or nm.startswith("Rstep")]
+    return vm_issued[0], (vm_issued[0] - max(loads) - 1) if loads else None
 
 
 def last_setup():
@@ -1130,7 +1315,42 @@ def lint(L):
                     assert dst(ins).isdisjoint(srcs(x)), (i, ins, x)
 
 
+def main_mx2():
+    """bodies of the split form: `last` is generated first (the drain bodies count the VMEM ops behind ITS loads) and emitted last"""
+    prologue()
+    mark = len(out)
+    e("L_last:")
+    n_last, after_last = body_mx2("last")
+    e(f"s_mov_b32 {sr(S_KC)}, 0")
+    e(f"s_sub_u32 {sr(S_TLEFT)}, {sr(S_TLEFT)}, 1")
+    e(f"s_cmp_eq_u32 {sr(S_TLEFT)}, 0")
+    e("s_cbranch_scc0 L_drain")
+    last_lines = out[mark:]
+    del out[mark:]
+    e("L_drain:")
+    infos, prev = [], after_last
+    for d in range(NDRAIN):
+        nv, aft = body_mx2("drain", d, prev if prev is not None else 0)
+        infos.append((nv, aft))
+        prev = aft
+        e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
+    e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
+    e("s_cbranch_scc0 L_last")
+    e("L_plain:")
+    body_mx2("plain")
+    e(f"s_add_u32 {sr(S_KC)}, {sr(S_KC)}, 1")
+    e(f"s_cmp_lt_u32 {sr(S_KC)}, {sr(S_NKM1)}")
+    e("s_cbranch_scc1 L_plain")
+    out.extend(last_lines)
+    tail()
+    return infos
+
+
 def main():
+    if MX and MX_SPLIT:
+        infos = main_mx2()
+        finish(infos)
+        return
     prologue()
     e3on = EPI == "e3" and "nodrain" not in FLAGS
     nst = lambda d: n_stores(d) if (e3on and "nostore" not in FLAGS) else 0   # stores of e3 step d (issued behind the loads of d + 1)
@@ -1160,6 +1380,10 @@ def main():
     e(f"s_cmp_eq_u32 {sr(S_TLEFT)}, 0")
     e("s_cbranch_scc0 L_drain")
     tail()
+    finish(infos)
+
+
+def finish(infos):
     lint(out)
     import re
     out[:] = [re.sub(r"\bL_\w+", lambda m: m.group(0) + "_%=", ln) for ln in out]
