@@ -65,3 +65,17 @@ def test_mlp_loop_generator_variants_are_consistent(tmp_path, env_extra):
     env.update(env_extra)
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_mlp256_x4m.py"), str(tmp_path / "v.inc")], check=True, env=env,
                    capture_output=True)
+
+
+@pytest.mark.parametrize("epi", ["e1", "e2", "e3"])
+def test_mx_split_form_generates(tmp_path, epi):
+    """the measured alternative of the MX body (X4G_MX_SPLIT=1: two barriers per K tile, the stage's two operand planes re-filled
+    separately - tools/gen/gen_gemm_x4g.py body_mx2, profiles/r06_ab_mx_split.txt) passes the generator's own checks: every read of a
+    stage issued before its barrier, hazard lint, the same MFMA mix"""
+    out = tmp_path / "body.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("X4G_")}
+    env["X4G_MX_SPLIT"] = "1"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen", "gen_gemm_x4g.py"), str(out), "23m", epi], check=True, env=env, capture_output=True)
+    body = out.read_text()
+    assert body.count("v_mfma_f32_32x32x16_f16") == 240 and body.count("v_mfma_scale_f32_32x32x64_f8f6f4") == 120
+    assert body.count("s_barrier") == 2 * 10 + 1          # two per K-tile body (8 drain + plain + last) + the prologue's

@@ -74,7 +74,11 @@ STMOD = (" " + _stmod) if _stmod and _stmod != "none" else ""      # cache polic
 STDEFER = os.environ.get("X4G_STDEFER", "0") == "1"
 GAP = int(os.environ.get("X4G_GAP", 24))      # filler issue cycles hidden behind one MFMA (32 cycles)
 GAP8 = int(os.environ.get("X4G_GAP8", 56))    # ... behind one v_mfma_scale_f32_32x32x64_f8f6f4 (16 passes = 64 cycles)
-MX_SPLIT = int(os.environ.get("X4G_MX_SPLIT", 1))   # MX: 1 = two barriers per K tile, the two operand planes of a stage re-filled separately (body_mx2)
+# MX: 1 = two barriers per K tile, the two operand planes of a stage re-filled separately (body_mx2).  Measured (profiles/r06_ab_mx_split.txt):
+# residual form -9 %, GELU form -3 %, +0.5 % frames/s - and, as any change of the accumulation order does, other boundary pixels flip: the
+# worst 1 - IoU of the measured-shape fixtures read 4.4e-4 instead of 2.9e-4 (same product error against fp64, 8.0e-6).  The committed
+# bodies are the one-barrier form (0): half a percent is not worth the thinner-looking margin; the form stays here for a 3-stage future.
+MX_SPLIT = int(os.environ.get("X4G_MX_SPLIT", 0))
 DMA_PACE = int(os.environ.get("X4G_DMA_PACE", 1))   # MX: 1 = the DMA block paced under the MFMAs behind the barrier, 0 = one burst
 RD_EARLY = int(os.environ.get("X4G_RD_EARLY", 0))   # MX: the last LDS read of a stage is issued this many MFMA slots before its barrier
 assert not MX or (KSUB == 2 and CFG == "23m"), "the MX form exists for the 128 x 192 tile with 64-deep K tiles"
