@@ -573,3 +573,29 @@ def test_e2e_without_postprocessing_matches_reference_golden(tiny, golden_dir):
         ref = np.unpackbits(g["bits"][i]).reshape(2, 1, 1024, 1024).astype(bool)
         for o in range(2):
             assert 1.0 - _iou(m[o], ref[o]) <= 1e-3
+
+
+def test_oracle_fixture_of_the_gpu_suite_is_the_oracles_output(golden_dir):
+    """tests/golden/oracle_memattn_bench.npz (oracle/make_oracle_fixtures.py: results of the ORACLE that the GPU suite compares the HIP
+    memory attention with at 16 objects) is what the oracle computes today - the short-bank case, 5 s of CPU."""
+    import torch
+    from oracle import modeling as M
+    from oracle.make_oracle_fixtures import memattn_inputs
+    B, NF, NP = 16, 1, 3
+    cfg = resolve_config("sam2.1_hiera_t")
+    sd = synthetic_state_dict(cfg, 0)
+    curr, feats, ptrs, tpos_rows, ptr_pos = memattn_inputs(B, NF, NP)
+    pos2 = M.sine_pos_2d(64, 64, 64)
+    mems = [f.float().flatten(2).permute(2, 0, 1) for f in feats]
+    poss = [pos2[None].expand(B, -1, -1, -1).flatten(2).permute(2, 0, 1) + sd["maskmem_tpos_enc"][r] for r in tpos_rows]
+    op = M.linear(sd, "obj_ptr_tpos_proj", M.sine_pe_1d(torch.tensor(ptr_pos) / 15.0, 256))
+    op = op.unsqueeze(1).expand(-1, B, 64).repeat_interleave(4, dim=0)
+    pt = torch.stack(ptrs, 0).reshape(-1, B, 4, 64).permute(0, 2, 1, 3).flatten(0, 1)
+    memory, memory_pos = torch.cat(mems + [pt], 0), torch.cat(poss + [op], 0)
+    vis_pos = M.sine_pos_2d(256, 64, 64).flatten(1).T
+    with torch.inference_mode():
+        ref = M.memory_attention(sd, cfg, curr[:, None].expand(-1, B, -1), vis_pos[:, None].expand(-1, B, -1), memory, memory_pos, 4 * NP)
+    g = np.load(os.path.join(golden_dir, "oracle_memattn_bench.npz"))
+    want = torch.from_numpy(g[f"ref_{B}_{NF}_{NP}"])
+    got = ref.transpose(0, 1)[:, ::64]
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
