@@ -6,8 +6,8 @@
 // instead of k_gemm_split_pp256 (fp32 qkv [rows, 768] out) -> k_rope_split -> k_vt_split16: three launches, 500 MB of traffic per layer
 // for 67 MB of input and 133 MB of output.  (MemoryAttentionLayer._forward_sa, memory_attention.py:59-66; RoPEAttention, transformer.py:312-363.)
 //
-// Same arithmetic, same order per element as the three kernels (tools/ma_switch_check.py DS2_MA_QKVFUSE=0 compares the layer output bit for
-// bit): the tile kernels' term order per 16-deep k-step (a_lo w_hi, a_hi w_lo, a_hi w_hi); + bias; k_rope_split's rotation in the form
+// Same arithmetic, same order per element as the three kernels (the layer output was compared bit for bit with the
+// three-kernel chain in round 5, profiles/HISTORY.md): the tile kernels' term order per 16-deep k-step (a_lo w_hi, a_hi w_lo, a_hi w_hi); + bias; k_rope_split's rotation in the form
 // hipcc contracts it to; the saturating fp16 pack of both producers.
 // Orientation per 64-column group of the 768 outputs (a wave owns 32 tokens; x_hat's fragments are the same registers either way):
 //   q, v : activations as the A operand - accumulator lane = output column, registers = tokens: q rows leave as 128-byte segments, a V^T row

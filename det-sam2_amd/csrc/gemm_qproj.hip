@@ -4,7 +4,7 @@
 // fp32 queries written and read back per layer.  (RoPEAttention.forward, sam2/modeling/sam/transformer.py:312-363; norm2 + the query of
 // cross_attn_image: memory_attention.py:74-87.)
 //
-// Same arithmetic, same order per element as the three kernels (tools/ma_switch_check.py DS2_MA_QFUSE=0 compares bit for bit):
+// Same arithmetic, same order per element as the three kernels (compared bit for bit with the three-kernel chain in round 5, profiles/HISTORY.md; tests/test_hip_stages.py: the query fragments through ds2_op_query_fragments):
 //   * LayerNorm statistics as the tree k_layernorm_vec's wave_sum butterfly evaluates (see gemm_mlp256.hip, input LayerNorm), the
 //     normalised row split into bf16 hi / lo planes in registers;
 //   * the product transposed (accumulators = q^T: lane = token, registers = output dims) with the tile kernels' term order per 16-deep

@@ -262,8 +262,8 @@ __global__ __launch_bounds__(512, 1) void k_gemm_split_k64(GemmSplitArgs g, int 
 //   * the accumulators go from "lane = column, registers = rows" to "lane i of a quad = row i, 4 consecutive columns" by a 4 x 4
 //     transpose inside every lane quad (two DPP butterfly stages, as in gemm_x4g): the two complex pairs of a lane are its own, the
 //     rotation needs no neighbour, and a store instruction writes 8 rows x 64 B (fp16) with nothing parked in LDS.
-// Same arithmetic, same order per element: bit-identical to k_gemm_split_k64<8, true, *> (tests/test_hip_stages.py: the memory attention
-// at bench size is unchanged to the bit; DS2_GEMM_K64T=0 keeps the slab epilogue for A/B runs).
+// Same arithmetic, same order per element: bit-identical to k_gemm_split_k64<8, true, *> (the memory attention at bench size
+// was unchanged to the bit against the slab epilogue in round 5, profiles/HISTORY.md).
 template <int CTL>
 __device__ __forceinline__ float dpp_quad(float x) {
   return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTL, 0xf, 0xf, false));

@@ -4,8 +4,8 @@
 // instead of k_w8_merge<64> (planes out) -> k_gemm_split_k64<8>: the 64-wide planes never reach HBM, one launch per layer less.
 // (RoPEAttention.forward's out_proj on the restructured product of DESIGN.md section 4; memory_attention.py:83-99.)
 //
-// Same arithmetic, same order per element as the two kernels (tests/test_hip_stages.py compares the layer outputs bit for bit with
-// DS2_MA_VOFUSE=0): v = O * (1 / l) and its bf16 split without contraction, the tile kernels' term order per 16-deep k-step
+// Same arithmetic, same order per element as the two kernels (the layer outputs were compared bit for bit with the
+// two-kernel chain in round 5, profiles/HISTORY.md): v = O * (1 / l) and its bf16 split without contraction, the tile kernels' term order per 16-deep k-step
 // (a_lo w_hi, a_hi w_lo, a_hi w_hi), then (acc + bias) + residual.
 // Weight-stationary like the K = 64 kernel: the whole weight (256 x 64, two planes = 64 KiB) is staged once per workgroup; a wave owns 32
 // token rows, its O fragments come straight from HBM in the MFMA's operand shape; the product is transposed (accumulator lane = token), the

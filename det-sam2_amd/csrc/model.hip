@@ -254,7 +254,6 @@ struct ds2_model {
 };
 
 static int model_precision(const ds2_model* m) { return m->precision; }
-// DS2_MA_FOLD_VO=0: keep out_proj of the memory attention's two attentions as its own GEMM (A/B runs)
 ModelScope::ModelScope(const ds2_model* m) : dg(m->device), ps(m->precision) {}
 
 #define ALLOC(var, n)                                                        \
@@ -1486,8 +1485,8 @@ static int memory_attention_impl(ds2_model* m, int32_t B, const float* curr, boo
                  true));   // only consumer: out_proj GEMM
       TRY(linear(m, st, p + ".cross_attn_image.out_proj", rows, 256, 256, a, 256, x, 256, DS2_ACT_NONE, x, 256));
     }
-    // -- FFN.  norm3 runs in the fused MLP's prologue when that kernel takes the layer in its two-fp16-term form (DS2_MA_LN3_FUSE=0: as
-    //    its own pass writing the operand planes; same bits either way)
+    // -- FFN.  norm3 runs in the fused MLP's prologue when that kernel takes the layer in its two-fp16-term form (else as its
+    //    own pass writing the operand planes; same bits either way - verified bit for bit in round 5)
     MlpArgs probe{};
     probe.rows = rows; probe.D = 256; probe.H = F; probe.ldx = 256; probe.ldw1 = 256; probe.ldw2 = F; probe.ldo = 256; probe.ldr = 256;
     const bool ln3_in = split && f16x2_enabled() && mlp256_supported(probe) &&
@@ -1998,8 +1997,8 @@ static int memory_encoder_impl(ds2_model* m, int32_t B, const float* fpn2, bool 
   for (int l = 0; l < 2; ++l) {
     const std::string p = me + ".fuser.layers." + std::to_string(l);
     TRY(launch_dwconv7(x, m->P("@dw_w." + std::to_string(l)), m->P(p + ".dwconv.bias"), d, B, 64, 256, st));
-    // the CXBlock's LayerNorm in the fused MLP's prologue when that kernel takes the block in its two-fp16-term form (DS2_ME_LN_FUSE=0: as its
-    // own pass; same bits either way)
+    // the CXBlock's LayerNorm in the fused MLP's prologue when that kernel takes the block in its two-fp16-term form (else as its
+    // own pass; same bits either way - verified bit for bit in round 5)
     MlpArgs probe{};
     probe.rows = rows; probe.D = 256; probe.H = 1024; probe.ldx = 256; probe.ldw1 = 256; probe.ldw2 = 1024; probe.ldo = 256; probe.ldr = 256;
     const bool ln_in = ds2_split_mode() && f16x2_enabled() && mlp256_supported(probe) &&
